@@ -1,0 +1,131 @@
+"""ctypes binding of libhpfg_hip.so (C ABI declared in include/hpfg_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If it is missing or a call fails the error is raised
+immediately (``HipLibraryError``), never swallowed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
+
+# enums from include/hpfg_hip.h
+BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
+ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ = range(7)
+LOSS_NSUM = 32
+VERSION = 100
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class Act(C.Structure):
+    _fields_ = [("z", C.c_void_p), ("bn", C.c_void_p), ("aux", C.c_void_p), ("mode", C.c_int32), ("C", C.c_int32),
+                ("Hs", C.c_int32), ("Ws", C.c_int32), ("pstride", C.c_int32), ("aux_pstride", C.c_int32),
+                ("bn_stride", C.c_int32), ("bn_coff", C.c_int32), ("sn", C.c_int32), ("sc", C.c_int32), ("sy", C.c_int32),
+                ("sx", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("drop_mask", C.c_void_p), ("seed_dev", C.c_void_p)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("a0", Act), ("a1", Act), ("wpk", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+                ("stat_partials", C.c_void_p), ("out_pstride", C.c_int32), ("Cout", C.c_int32), ("CoutPad", C.c_int32),
+                ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("taps", C.c_int32)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("a0", Act), ("a1", Act), ("g", Act), ("slab", C.c_void_p), ("dw_oihw", C.c_void_p), ("Cin", C.c_int32),
+                ("CinPad", C.c_int32), ("Cout", C.c_int32), ("CoutPad", C.c_int32), ("N", C.c_int32), ("H", C.c_int32),
+                ("W", C.c_int32), ("taps", C.c_int32), ("S", C.c_int32)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("w_oihw", C.c_void_p), ("b", C.c_void_p), ("wpk_fwd", C.c_void_p), ("wpk_dgrad", C.c_void_p),
+                ("bias_pad", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32), ("CoutPad", C.c_int32),
+                ("CinPad", C.c_int32), ("taps", C.c_int32)]
+
+
+class LossArgs(C.Structure):
+    _fields_ = [("logits", C.c_void_p), ("t_logits", C.c_void_p), ("labels0", C.c_void_p), ("labels1", C.c_void_p),
+                ("coef", C.c_void_p), ("partials", C.c_void_p), ("sums", C.c_void_p), ("out", C.c_void_p),
+                ("dlogits", C.c_void_p), ("N", C.c_int32), ("n_lab", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("C", C.c_int32), ("world", C.c_int32), ("input_is_prob", C.c_int32)]
+
+
+_i, _l, _f, _d, _p, _u32 = C.c_int, C.c_long, C.c_float, C.c_double, C.c_void_p, C.c_uint32
+
+# name -> (restype, argtypes); must list every symbol include/hpfg_hip.h declares (checked by tests/test_abi.py)
+PROTOTYPES = {
+    "hpfg_version": (_i, []),
+    "hpfg_last_error": (C.c_char_p, []),
+    "hpfg_conv3x3_first_fwd": (_i, [C.POINTER(Act), _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "hpfg_conv_fwd": (_i, [C.POINTER(ConvArgs), _p]),
+    "hpfg_conv_stat_blocks": (_i, [_i, _i, _i]),
+    "hpfg_bn_fwd_finalize": (_i, [_p, _i, _p, _d, _p, _p, _p, _p, _f, _f, _p, _i, _p]),
+    "hpfg_reduce_partials": (_i, [_p, _i, _i, _p, _p]),
+    "hpfg_pack_weights": (_i, [_p, C.POINTER(PackDesc), _i, _p]),
+    "hpfg_act_materialize": (_i, [C.POINTER(Act), C.POINTER(Act), _i, _i, _i, _p, _p]),
+    "hpfg_dropout_mask": (_i, [_p, _l, _f, _u32, _p, _p]),
+    "hpfg_bn_eval_table": (_i, [_p, _p, _p, _p, _f, _p, _i, _p]),
+    "hpfg_bn_bwd_reduce": (_i, [C.POINTER(Act), _i, _i, _i, _p, _p]),
+    "hpfg_bn_bwd_blocks": (_i, [_i, _i, _i, _i]),
+    "hpfg_bn_bwd_finalize": (_i, [_p, _i, _p, _d, _p, _p, _p, _p, _i, _p]),
+    "hpfg_wgrad": (_i, [C.POINTER(WgradArgs), _p]),
+    "hpfg_wgrad_splits": (_i, [_i, _i, _i, _i, _i, _i]),
+    "hpfg_wgrad_slab_floats": (_l, [_i, _i, _i, _i, _i, _i]),
+    "hpfg_channel_sum": (_i, [_p, _i, _l, _i, _p, _p, _p]),
+    "hpfg_pool_scatter_add": (_i, [C.POINTER(Act), _p, _i, _p, _i, _i, _i, _i, _p]),
+    "hpfg_upsample2x_bwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    "hpfg_loss_blocks": (_i, [_i, _i, _i]),
+    "hpfg_seg_loss_partials": (_i, [C.POINTER(LossArgs), _p]),
+    "hpfg_seg_loss_finalize": (_i, [C.POINTER(LossArgs), _p]),
+    "hpfg_seg_loss_bwd": (_i, [C.POINTER(LossArgs), _p, _p]),
+    "hpfg_argmax_labels": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "hpfg_cutmix_blend": (_i, [_p, _p, _p, _p, _l, _p]),
+    "hpfg_sgd_step": (_i, [_p, _p, _p, _l, _p, _f, _f, _f, _p]),
+    "hpfg_ema_update": (_i, [_p, _p, _l, _p, _p]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once) and attach prototypes.  Raises HipLibraryError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C hpfg_amd/csrc`. There is no CPU fallback for the HIP path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.hpfg_version() != VERSION:
+            raise HipLibraryError(f"libhpfg_hip.so version {lib.hpfg_version()} != binding version {VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().hpfg_last_error().decode("utf-8", "replace")
+        raise HipLibraryError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def none_act() -> Act:
+    return Act()

@@ -1,0 +1,204 @@
+// BatchNorm2d (train mode) statistics, forward finalize and backward reduction for the fused conv pipeline.
+// Reference: nn.BatchNorm2d defaults (eps 1e-5, momentum 0.1, affine, running stats with UNBIASED variance) at
+// model/unet.py:19,23; backward = torch's native_batch_norm_backward (train) composed with LeakyReLU / Dropout backward.
+//
+// Forward:  the conv epilogue leaves per-workgroup partial sums  S1 = sum z, S2 = sum z^2  per channel.
+//           finalize (one workgroup per channel, fp64 accumulation) turns them into the table rows
+//           mean, rstd, scale = gamma*rstd, shift = beta - mean*scale  and updates running_mean / running_var.
+// Backward: with g = dL/dy (after LeakyReLU'/Dropout), xhat = (z-mean)*rstd, M = N*H*W:
+//           dz = gamma*rstd * (g - mean(g) - xhat*mean(g*xhat));  dgamma = sum g*xhat;  dbeta = sum g.
+//           The reduce kernel produces partial (sum g, sum g*xhat); finalize writes dgamma/dbeta and the rows
+//           k1 = gamma*rstd, k2 = -gamma*rstd^2*m2, k3 = gamma*rstd*(mean*rstd*m2 - m1)  so that dz = k1*g + k2*z + k3,
+//           which the dgrad / wgrad loaders evaluate on the fly (HPFG_ACT_DZ).
+// Data parallel: hpfg_reduce_partials gives fp64 [2][C] sums to all-reduce; finalize then takes `sums` instead of partials.
+#include "common.h"
+
+namespace {
+
+__device__ inline double block_sum(double v, double* sh) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  if ((tid & 63) == 0) sh[tid >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+  __syncthreads();
+  return t;
+}
+
+// grid = C blocks; partials [nblk][2][C]
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __restrict__ partials, int nblk, const double* __restrict__ sums,
+                                                              double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* running_mean, float* running_var, float momentum, float eps,
+                                                              float* __restrict__ bn, int C) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double s1, s2;
+  if (sums) {
+    s1 = sums[c];
+    s2 = sums[C + c];
+  } else {
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+      a += (double)partials[((long)i * 2 + 0) * C + c];
+      b += (double)partials[((long)i * 2 + 1) * C + c];
+    }
+    s1 = block_sum(a, sh);
+    s2 = block_sum(b, sh);
+  }
+  if (threadIdx.x == 0) {
+    double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    double rstd = 1.0 / sqrt(var + (double)eps);
+    float scale = (float)((double)gamma[c] * rstd);
+    bn[HPFG_BN_MEAN * C + c] = (float)mean;
+    bn[HPFG_BN_RSTD * C + c] = (float)rstd;
+    bn[HPFG_BN_SCALE * C + c] = scale;
+    bn[HPFG_BN_SHIFT * C + c] = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
+    if (running_mean) {
+      double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nblk, int C, double* __restrict__ sums) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x, which = blockIdx.y;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) a += (double)partials[((long)i * 2 + which) * C + c];
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) sums[which * C + c] = a;
+}
+
+// Backward reduction.  Each workgroup walks PIX_PER_BLOCK pixels; thread t owns channel quad (t % Q) and pixel lane t / Q.
+constexpr int BWD_PIX_PER_BLOCK = 512;
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(HpfgAct s, long npix, float* __restrict__ partials) {
+  __shared__ float red[256 * 8];
+  const int C = s.C, Q = C >> 2, tid = threadIdx.x;
+  const ActCtx cx = make_ctx(s);
+  float a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+  const long p0 = (long)blockIdx.x * BWD_PIX_PER_BLOCK;
+  long p1 = p0 + BWD_PIX_PER_BLOCK;
+  if (p1 > npix) p1 = npix;
+  if (Q <= 256) {
+    const int q = tid % Q, pl = tid / Q, PL = 256 / Q;
+    for (long pix = p0 + pl; pix < p1; pix += PL) {
+      f32x4 g, xh;
+      dz_load_g_xhat(s, cx, pix, q * 4, g, xh);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[j] += g[j];
+        b[j] += g[j] * xh[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[tid * 8 + j] = a[j];
+      red[tid * 8 + 4 + j] = b[j];
+    }
+    __syncthreads();
+    // thread (which, c) for c < C sums over pixel lanes
+    for (int o = tid; o < 2 * C; o += 256) {
+      int which = o / C, c = o % C, qq = c >> 2, j = c & 3;
+      float t = 0.f;
+      for (int l = 0; l < PL; ++l) t += red[(l * Q + qq) * 8 + which * 4 + j];
+      partials[((long)blockIdx.x * 2 + which) * C + c] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, const double* __restrict__ sums,
+                                                              double count, const float* __restrict__ gamma, float* __restrict__ bn,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double sg, sgx;
+  if (sums) {
+    sg = sums[c];
+    sgx = sums[C + c];
+  } else {
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+      a += (double)partials[((long)i * 2 + 0) * C + c];
+      b += (double)partials[((long)i * 2 + 1) * C + c];
+    }
+    sg = block_sum(a, sh);
+    sgx = block_sum(b, sh);
+  }
+  if (threadIdx.x == 0) {
+    double m1 = sg / count, m2 = sgx / count;
+    double mean = bn[HPFG_BN_MEAN * C + c], rstd = bn[HPFG_BN_RSTD * C + c], ga = gamma[c];
+    bn[HPFG_BN_K1 * C + c] = (float)(ga * rstd);
+    bn[HPFG_BN_K2 * C + c] = (float)(-ga * rstd * rstd * m2);
+    bn[HPFG_BN_K3 * C + c] = (float)(ga * rstd * (mean * rstd * m2 - m1));
+    if (dgamma) dgamma[c] = (float)sgx;
+    if (dbeta) dbeta[c] = (float)sg;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_eval_table_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                                            float* __restrict__ bn, int C) {
+  int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float rstd = 1.f / sqrtf(rv[c] + eps);
+  float scale = gamma[c] * rstd;
+  bn[HPFG_BN_MEAN * C + c] = rm[c];
+  bn[HPFG_BN_RSTD * C + c] = rstd;
+  bn[HPFG_BN_SCALE * C + c] = scale;
+  bn[HPFG_BN_SHIFT * C + c] = beta[c] - rm[c] * scale;
+}
+
+}  // namespace
+
+extern "C" int hpfg_bn_eval_table(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                                  float* bn, int C, void* stream) {
+  HPFG_ARG_CHECK(gamma && beta && running_mean && running_var && bn && C > 0, "bn_eval_table: bad args");
+  hipLaunchKernelGGL(bn_eval_table_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps,
+                     bn, C);
+  return hpfg_launch_status("bn_eval_table_kernel");
+}
+
+extern "C" int hpfg_bn_fwd_finalize(const float* partials, int nblk, const double* sums, double count, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float eps, float* bn, int C, void* stream) {
+  HPFG_ARG_CHECK((partials && nblk > 0) || sums, "bn_fwd_finalize: need partials or sums");
+  HPFG_ARG_CHECK(gamma && beta && bn && C > 0 && count > 0, "bn_fwd_finalize: bad args");
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nblk, sums, count, gamma, beta, running_mean,
+                     running_var, momentum, eps, bn, C);
+  return hpfg_launch_status("bn_fwd_finalize_kernel");
+}
+
+extern "C" int hpfg_reduce_partials(const float* partials, int nblk, int C, double* sums, void* stream) {
+  HPFG_ARG_CHECK(partials && sums && nblk > 0 && C > 0, "reduce_partials: bad args");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(C, 2), dim3(256), 0, (hipStream_t)stream, partials, nblk, C, sums);
+  return hpfg_launch_status("reduce_partials_kernel");
+}
+
+extern "C" int hpfg_bn_bwd_blocks(int N, int H, int W, int C) {
+  (void)C;
+  long npix = (long)N * H * W;
+  return (int)((npix + BWD_PIX_PER_BLOCK - 1) / BWD_PIX_PER_BLOCK);
+}
+
+extern "C" int hpfg_bn_bwd_reduce(const HpfgAct* g, int N, int H, int W, float* partials, void* stream) {
+  HPFG_ARG_CHECK(g && partials && g->mode == HPFG_ACT_DZ && g->z && g->aux && g->bn, "bn_bwd_reduce: needs a DZ source");
+  HPFG_ARG_CHECK(g->C % 4 == 0 && g->C >= 4 && g->C <= 1024 && 256 % (g->C / 4) == 0, "bn_bwd_reduce: unsupported C=%d", g->C);
+  HPFG_ARG_CHECK(g->Hs == H && g->Ws == W, "bn_bwd_reduce: source size mismatch");
+  long npix = (long)N * H * W;
+  int nblk = hpfg_bn_bwd_blocks(N, H, W, g->C);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *g, npix, partials);
+  return hpfg_launch_status("bn_bwd_reduce_kernel");
+}
+
+extern "C" int hpfg_bn_bwd_finalize(const float* partials, int nblk, const double* sums, double count, const float* gamma, float* bn,
+                                    float* dgamma, float* dbeta, int C, void* stream) {
+  HPFG_ARG_CHECK((partials && nblk > 0) || sums, "bn_bwd_finalize: need partials or sums");
+  HPFG_ARG_CHECK(gamma && bn && C > 0 && count > 0, "bn_bwd_finalize: bad args");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nblk, sums, count, gamma, bn, dgamma, dbeta, C);
+  return hpfg_launch_status("bn_bwd_finalize_kernel");
+}

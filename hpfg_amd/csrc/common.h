@@ -1,0 +1,186 @@
+// Shared device helpers for the HPFG gfx950 kernels: virtual-activation loaders, dropout RNG, error plumbing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/hpfg_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define HPFG_LEAKY 0.01f
+
+extern "C" void hpfg_set_error(const char* fmt, ...);
+#define HPFG_ARG_CHECK(cond, ...)            \
+  do {                                       \
+    if (!(cond)) {                           \
+      hpfg_set_error(__VA_ARGS__);           \
+      return -1;                             \
+    }                                        \
+  } while (0)
+
+static inline int hpfg_launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    hpfg_set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+// ---- counter-based dropout RNG ------------------------------------------------------------------------------
+// keep(i) = fmix32(i * 0x9E3779B1 + seed) >= floor(p * 2^32); i = NHWC element index of the activated tensor.
+// Stateless, so forward consumers and backward loaders regenerate the same mask without storing it.
+__host__ __device__ static inline uint32_t hpfg_hash32(uint32_t i, uint32_t seed) {
+  uint32_t h = i * 0x9E3779B1u + seed;
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+__host__ __device__ static inline uint32_t hpfg_drop_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t >= 4294967295.0) return 0xFFFFFFFFu;
+  return (uint32_t)t;
+}
+
+__device__ static inline float lrelu(float y) { return y > 0.f ? y : HPFG_LEAKY * y; }
+
+// Per-block cache of everything a loader needs that does not depend on the pixel.
+struct ActCtx {
+  uint32_t thresh;
+  uint32_t seed;
+  float inv_keep;
+};
+__device__ static inline ActCtx make_ctx(const HpfgAct& s) {
+  ActCtx c;
+  c.thresh = hpfg_drop_threshold(s.drop_p);
+  c.inv_keep = s.drop_p > 0.f ? 1.f / (1.f - s.drop_p) : 1.f;
+  c.seed = s.drop_seed + ((s.drop_p > 0.f && s.seed_dev) ? *s.seed_dev : 0u);
+  return c;
+}
+
+__device__ static inline bool keep_elem(const HpfgAct& s, const ActCtx& cx, uint32_t e) {
+  return s.drop_mask ? s.drop_mask[e] != 0 : hpfg_hash32(e, cx.seed) >= cx.thresh;
+}
+
+// 4 channels [c, c+4) of the virtual activation `s` at image n, virtual pixel (y, x); caller guarantees the pixel is
+// inside the virtual image (H x W).  Channels >= s.C read as zero.
+__device__ static inline f32x4 act_load4(const HpfgAct& s, const ActCtx& cx, int n, int y, int x, int c) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (c >= s.C) return v;
+  switch (s.mode) {
+    case HPFG_ACT_PLAIN: {
+      const float* p = s.z + ((long)(n * s.Hs + y) * s.Ws + x) * s.pstride + c;
+      v = *reinterpret_cast<const f32x4*>(p);
+      break;
+    }
+    case HPFG_ACT_STRIDED: {
+      const float* p = s.z + (long)n * s.sn + (long)y * s.sy + (long)x * s.sx;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c + j < s.C) v[j] = p[(long)(c + j) * s.sc];
+      break;
+    }
+    case HPFG_ACT_BNACT: {
+      long pix = (long)(n * s.Hs + y) * s.Ws + x;
+      f32x4 z = *reinterpret_cast<const f32x4*>(s.z + pix * s.pstride + c);
+      f32x4 sc = *reinterpret_cast<const f32x4*>(s.bn + HPFG_BN_SCALE * s.bn_stride + s.bn_coff + c);
+      f32x4 sh = *reinterpret_cast<const f32x4*>(s.bn + HPFG_BN_SHIFT * s.bn_stride + s.bn_coff + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = lrelu(z[j] * sc[j] + sh[j]);
+      if (s.drop_p > 0.f) {
+        uint32_t e = (uint32_t)(pix * s.C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = keep_elem(s, cx, e + j) ? v[j] * cx.inv_keep : 0.f;
+      }
+      break;
+    }
+    case HPFG_ACT_BNACT_POOL: {
+      f32x4 sc = *reinterpret_cast<const f32x4*>(s.bn + HPFG_BN_SCALE * s.bn_stride + s.bn_coff + c);
+      f32x4 sh = *reinterpret_cast<const f32x4*>(s.bn + HPFG_BN_SHIFT * s.bn_stride + s.bn_coff + c);
+      const float* base = s.z + ((long)(n * s.Hs + 2 * y) * s.Ws + 2 * x) * s.pstride + c;
+      f32x4 z00 = *reinterpret_cast<const f32x4*>(base);
+      f32x4 z01 = *reinterpret_cast<const f32x4*>(base + s.pstride);
+      f32x4 z10 = *reinterpret_cast<const f32x4*>(base + (long)s.Ws * s.pstride);
+      f32x4 z11 = *reinterpret_cast<const f32x4*>(base + (long)s.Ws * s.pstride + s.pstride);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = lrelu(z00[j] * sc[j] + sh[j]), b = lrelu(z01[j] * sc[j] + sh[j]);
+        float d = lrelu(z10[j] * sc[j] + sh[j]), e = lrelu(z11[j] * sc[j] + sh[j]);
+        v[j] = fmaxf(fmaxf(a, b), fmaxf(d, e));
+      }
+      break;
+    }
+    case HPFG_ACT_UP2X: {
+      // torch upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1)
+      int Ho = 2 * s.Hs, Wo = 2 * s.Ws;
+      float ry = Ho > 1 ? (float)(s.Hs - 1) / (float)(Ho - 1) : 0.f;
+      float rx = Wo > 1 ? (float)(s.Ws - 1) / (float)(Wo - 1) : 0.f;
+      float fy = ry * (float)y, fx = rx * (float)x;
+      int y0 = (int)fy, x0 = (int)fx;
+      int y1 = y0 + (y0 < s.Hs - 1 ? 1 : 0), x1 = x0 + (x0 < s.Ws - 1 ? 1 : 0);
+      float wy1 = fy - (float)y0, wx1 = fx - (float)x0;
+      float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+      const float* b = s.z + (long)n * s.Hs * s.Ws * s.pstride + c;
+      f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((long)y0 * s.Ws + x0) * s.pstride);
+      f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((long)y0 * s.Ws + x1) * s.pstride);
+      f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((long)y1 * s.Ws + x0) * s.pstride);
+      f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((long)y1 * s.Ws + x1) * s.pstride);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = wy0 * (wx0 * v00[j] + wx1 * v01[j]) + wy1 * (wx0 * v10[j] + wx1 * v11[j]);
+      break;
+    }
+    case HPFG_ACT_DZ: {
+      long pix = (long)(n * s.Hs + y) * s.Ws + x;
+      f32x4 z = *reinterpret_cast<const f32x4*>(s.z + pix * s.pstride + c);
+      f32x4 g = *reinterpret_cast<const f32x4*>(s.aux + pix * s.aux_pstride + c);
+      const float* t = s.bn + s.bn_coff + c;
+      f32x4 sc = *reinterpret_cast<const f32x4*>(t + HPFG_BN_SCALE * s.bn_stride);
+      f32x4 sh = *reinterpret_cast<const f32x4*>(t + HPFG_BN_SHIFT * s.bn_stride);
+      f32x4 k1 = *reinterpret_cast<const f32x4*>(t + HPFG_BN_K1 * s.bn_stride);
+      f32x4 k2 = *reinterpret_cast<const f32x4*>(t + HPFG_BN_K2 * s.bn_stride);
+      f32x4 k3 = *reinterpret_cast<const f32x4*>(t + HPFG_BN_K3 * s.bn_stride);
+      uint32_t e = (uint32_t)(pix * s.C + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float gg = g[j];
+        if (s.drop_p > 0.f) gg = keep_elem(s, cx, e + j) ? gg * cx.inv_keep : 0.f;
+        float yv = z[j] * sc[j] + sh[j];
+        gg = yv > 0.f ? gg : HPFG_LEAKY * gg;
+        v[j] = k1[j] * gg + k2[j] * z[j] + k3[j];
+      }
+      break;
+    }
+    default:
+      break;
+  }
+  return v;
+}
+
+// g-only part of the DZ chain (used by the BN-backward reduction): returns g and xhat for 4 channels.
+__device__ static inline void dz_load_g_xhat(const HpfgAct& s, const ActCtx& cx, long pix, int c, f32x4& g_out, f32x4& xh_out) {
+  f32x4 z = *reinterpret_cast<const f32x4*>(s.z + pix * s.pstride + c);
+  f32x4 g = *reinterpret_cast<const f32x4*>(s.aux + pix * s.aux_pstride + c);
+  const float* t = s.bn + s.bn_coff + c;
+  f32x4 mu = *reinterpret_cast<const f32x4*>(t + HPFG_BN_MEAN * s.bn_stride);
+  f32x4 rs = *reinterpret_cast<const f32x4*>(t + HPFG_BN_RSTD * s.bn_stride);
+  f32x4 sc = *reinterpret_cast<const f32x4*>(t + HPFG_BN_SCALE * s.bn_stride);
+  f32x4 sh = *reinterpret_cast<const f32x4*>(t + HPFG_BN_SHIFT * s.bn_stride);
+  uint32_t e = (uint32_t)(pix * s.C + c);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float gg = g[j];
+    if (s.drop_p > 0.f) gg = keep_elem(s, cx, e + j) ? gg * cx.inv_keep : 0.f;
+    float yv = z[j] * sc[j] + sh[j];
+    g_out[j] = yv > 0.f ? gg : HPFG_LEAKY * gg;
+    xh_out[j] = (z[j] - mu[j]) * rs[j];
+  }
+}
+
+// Select the source that owns virtual channel c of the concat [a0 | a1] and load 4 channels from it.
+__device__ static inline f32x4 cat_load4(const HpfgAct& a0, const ActCtx& c0, const HpfgAct& a1, const ActCtx& c1, int n, int y, int x, int c) {
+  if (c < a0.C || a1.mode == HPFG_ACT_NONE) return act_load4(a0, c0, n, y, x, c);
+  return act_load4(a1, c1, n, y, x, c - a0.C);
+}

@@ -1,0 +1,268 @@
+// Small kernels around the conv pipeline: weight packing, virtual-activation materialisation, dropout-mask dump,
+// max-pool / bilinear-upsample backward routing, CutMix blend, arg-max pseudo-labels, SGD and EMA over flat buffers.
+#include <stdarg.h>
+#include <string.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+extern "C" void hpfg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* hpfg_last_error(void) { return g_err; }
+extern "C" int hpfg_version(void) { return HPFG_VERSION; }
+
+namespace {
+
+// ---- weight packing: OIHW -> MFMA B-fragment order (see conv.hip) ------------------------------------------------------
+// fwd  : wpk[tap][ch][nt][lane][ks] = W[co = nt*16 + (lane&15)][ci = ch*16 + ks*4 + (lane>>4)][tap]
+// dgrad: wpk[tap][ch][nt][lane][ks] = W[co = ch*16 + ks*4 + (lane>>4)][ci = nt*16 + (lane&15)][taps-1-tap]
+__global__ __launch_bounds__(256) void pack_weights_kernel(const HpfgPackDesc* __restrict__ table) {
+  const HpfgPackDesc d = table[blockIdx.y];
+  const long total = (long)d.taps * d.CinPad * d.CoutPad;
+  const int nt_f = d.CoutPad / 16, nch_f = d.CinPad / 16;
+  const int nt_d = d.CinPad / 16, nch_d = d.CoutPad / 16;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int ks = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    long r = i >> 8;
+    {
+      int nt = (int)(r % nt_f), ch = (int)((r / nt_f) % nch_f), tap = (int)(r / ((long)nt_f * nch_f));
+      int co = nt * 16 + (lane & 15), ci = ch * 16 + ks * 4 + (lane >> 4);
+      d.wpk_fwd[i] = (co < d.Cout && ci < d.Cin) ? d.w_oihw[((long)co * d.Cin + ci) * d.taps + tap] : 0.f;
+    }
+    if (d.wpk_dgrad) {
+      int nt = (int)(r % nt_d), ch = (int)((r / nt_d) % nch_d), tap = (int)(r / ((long)nt_d * nch_d));
+      int co = ch * 16 + ks * 4 + (lane >> 4), ci = nt * 16 + (lane & 15);
+      d.wpk_dgrad[i] = (co < d.Cout && ci < d.Cin) ? d.w_oihw[((long)co * d.Cin + ci) * d.taps + (d.taps - 1 - tap)] : 0.f;
+    }
+    if (i < d.CoutPad) d.bias_pad[i] = (i < d.Cout && d.b) ? d.b[i] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void materialize_kernel(HpfgAct a0, HpfgAct a1, int N, int H, int W, float* __restrict__ out) {
+  const int Ct = a0.C + a1.C, Q = (Ct + 3) / 4;
+  const ActCtx c0 = make_ctx(a0), c1 = make_ctx(a1);
+  const long total = (long)N * H * W * Q;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int q = (int)(i % Q);
+    long pix = i / Q;
+    int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+    f32x4 v = cat_load4(a0, c0, a1, c1, n, y, x, q * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (q * 4 + j < Ct) out[pix * Ct + q * 4 + j] = v[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ out, long n, uint32_t thresh, uint32_t seed0,
+                                                           const uint32_t* __restrict__ seed_dev) {
+  const uint32_t seed = seed0 + (seed_dev ? *seed_dev : 0u);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = hpfg_hash32((uint32_t)i, seed) >= thresh ? 1 : 0;
+}
+
+// MaxPool2d(2) backward, fused with the skip-gradient accumulation: dA[n, 2yp+dy*, 2xp+dx*, c] += dP[n,yp,xp,c]
+__global__ __launch_bounds__(256) void pool_scatter_kernel(HpfgAct s, const float* __restrict__ dP, int dp_ps, float* __restrict__ dA, int da_ps,
+                                                           int N, int Hp, int Wp) {
+  const int Q = s.C / 4;
+  const long total = (long)N * Hp * Wp * Q;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int q = (int)(i % Q);
+    long pp = i / Q;
+    int xp = (int)(pp % Wp), yp = (int)((pp / Wp) % Hp), n = (int)(pp / ((long)Wp * Hp));
+    int c = q * 4;
+    f32x4 sc = *reinterpret_cast<const f32x4*>(s.bn + HPFG_BN_SCALE * s.bn_stride + s.bn_coff + c);
+    f32x4 sh = *reinterpret_cast<const f32x4*>(s.bn + HPFG_BN_SHIFT * s.bn_stride + s.bn_coff + c);
+    long p00 = (long)(n * s.Hs + 2 * yp) * s.Ws + 2 * xp;
+    long pos[4] = {p00, p00 + 1, p00 + s.Ws, p00 + s.Ws + 1};
+    f32x4 zz[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) zz[k] = *reinterpret_cast<const f32x4*>(s.z + pos[k] * s.pstride + c);
+    f32x4 g = *reinterpret_cast<const f32x4*>(dP + pp * dp_ps + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float best = lrelu(zz[0][j] * sc[j] + sh[j]);
+      int bi = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        float v = lrelu(zz[k][j] * sc[j] + sh[j]);
+        if (v > best) {
+          best = v;
+          bi = k;
+        }
+      }
+      long dst = (bi == 0 ? pos[0] : bi == 1 ? pos[1] : bi == 2 ? pos[2] : pos[3]) * da_ps + c + j;
+      dA[dst] += g[j];
+    }
+  }
+}
+
+// transpose of the align_corners=True bilinear x2: gather form, one thread per (low-res pixel, channel quad)
+__device__ inline void up_taps(int lo, int L, int* idx, float* wgt, int& cnt) {
+  const int O = 2 * L;
+  const float r = O > 1 ? (float)(L - 1) / (float)(O - 1) : 0.f;
+  cnt = 0;
+  int b = 2 * lo - 2, e = 2 * lo + 4;
+  if (b < 0) b = 0;
+  if (e > O - 1) e = O - 1;
+  for (int o = b; o <= e; ++o) {
+    float f = r * (float)o;
+    int i0 = (int)f;
+    int i1 = i0 + (i0 < L - 1 ? 1 : 0);
+    float w1 = f - (float)i0, w0 = 1.f - w1, w = 0.f;
+    if (i0 == lo) w += w0;
+    if (i1 == lo) w += w1;
+    if ((i0 == lo || i1 == lo) && cnt < 8) {
+      idx[cnt] = o;
+      wgt[cnt] = w;
+      ++cnt;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dUp, int dup_ps, float* __restrict__ dU, int N, int Hl, int Wl,
+                                                           int C) {
+  const int Q = C / 4, Ho = 2 * Hl, Wo = 2 * Wl;
+  const long total = (long)N * Hl * Wl * Q;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int q = (int)(i % Q);
+    long pp = i / Q;
+    int xl = (int)(pp % Wl), yl = (int)((pp / Wl) % Hl), n = (int)(pp / ((long)Wl * Hl));
+    int yi[8], xi[8], ny, nx;
+    float yw[8], xw[8];
+    up_taps(yl, Hl, yi, yw, ny);
+    up_taps(xl, Wl, xi, xw, nx);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(dUp + ((long)(n * Ho + yi[a]) * Wo + xi[b]) * dup_ps + q * 4);
+        float w = yw[a] * xw[b];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += w * v[j];
+      }
+    *reinterpret_cast<f32x4*>(dU + pp * C + q * 4) = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void cutmix_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ m,
+                                                     float* __restrict__ out, long n) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a[i] * (1.f - m[i]) + b[i] * m[i];
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, long npix, int C, const uint8_t* __restrict__ mix_labels,
+                                                     const float* __restrict__ mix_mask, uint8_t* __restrict__ out) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+    const float* l = logits + i * C;
+    float best = l[0];
+    int bi = 0;
+    for (int c = 1; c < C; ++c)
+      if (l[c] > best) {
+        best = l[c];
+        bi = c;
+      }
+    if (mix_mask) bi = mix_mask[i] > 0.5f ? bi : (int)mix_labels[i];
+    out[i] = (uint8_t)bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom, long n,
+                                                  const float* __restrict__ lr_dev, float momentum, float wd, float gscale) {
+  const float lr = *lr_dev;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float w = p[i];
+    float d = g[i] * gscale + wd * w;
+    float b = momentum * mom[i] + d;
+    mom[i] = b;
+    p[i] = w - lr * b;
+  }
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const float* __restrict__ s, long n, const float* __restrict__ alpha_dev) {
+  const float a = *alpha_dev;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) t[i] = t[i] * a + s[i] * (1.f - a);
+}
+
+inline int grid_for(long total, int cap = 4096) {
+  long b = (total + 255) / 256;
+  if (b < 1) b = 1;
+  return (int)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+extern "C" int hpfg_pack_weights(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, void* stream) {
+  HPFG_ARG_CHECK(table_dev && table_host && nlayers > 0 && nlayers < 65536, "pack_weights: bad args");
+  long mx = 0;
+  for (int i = 0; i < nlayers; ++i) {
+    const HpfgPackDesc& d = table_host[i];
+    HPFG_ARG_CHECK(d.CinPad % 16 == 0 && d.CoutPad % 16 == 0 && d.Cin <= d.CinPad && d.Cout <= d.CoutPad && (d.taps == 1 || d.taps == 9),
+                   "pack_weights: bad descriptor %d", i);
+    long t = (long)d.taps * d.CinPad * d.CoutPad;
+    if (t > mx) mx = t;
+  }
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(mx, 256), nlayers), dim3(256), 0, (hipStream_t)stream, table_dev);
+  return hpfg_launch_status("pack_weights_kernel");
+}
+
+extern "C" int hpfg_act_materialize(const HpfgAct* a0, const HpfgAct* a1, int N, int H, int W, float* out, void* stream) {
+  HPFG_ARG_CHECK(a0 && out && N > 0 && H > 0 && W > 0, "act_materialize: bad args");
+  HpfgAct none;
+  memset(&none, 0, sizeof(none));
+  const HpfgAct& b = a1 ? *a1 : none;
+  HPFG_ARG_CHECK(b.mode == HPFG_ACT_NONE || a0->C % 4 == 0, "act_materialize: concat needs a0.C %% 4 == 0");
+  long total = (long)N * H * W * ((a0->C + b.C + 3) / 4);
+  hipLaunchKernelGGL(materialize_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *a0, b, N, H, W, out);
+  return hpfg_launch_status("materialize_kernel");
+}
+
+extern "C" int hpfg_dropout_mask(uint8_t* out, long n_elems, float p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
+  HPFG_ARG_CHECK(out && n_elems > 0 && n_elems < (1L << 32) && p >= 0.f && p < 1.f, "dropout_mask: bad args");
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n_elems)), dim3(256), 0, (hipStream_t)stream, out, n_elems, hpfg_drop_threshold(p), seed,
+                     seed_dev);
+  return hpfg_launch_status("dropout_mask_kernel");
+}
+
+extern "C" int hpfg_pool_scatter_add(const HpfgAct* src, const float* dP, int dp_pstride, float* dA, int da_pstride, int N, int Hp, int Wp,
+                                     void* stream) {
+  HPFG_ARG_CHECK(src && dP && dA && src->mode == HPFG_ACT_BNACT && src->C % 4 == 0, "pool_scatter_add: needs a BNACT source with C%%4==0");
+  HPFG_ARG_CHECK(src->Hs == 2 * Hp && src->Ws == 2 * Wp, "pool_scatter_add: source must be 2x the pooled size");
+  long total = (long)N * Hp * Wp * (src->C / 4);
+  hipLaunchKernelGGL(pool_scatter_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *src, dP, dp_pstride, dA, da_pstride, N, Hp, Wp);
+  return hpfg_launch_status("pool_scatter_kernel");
+}
+
+extern "C" int hpfg_upsample2x_bwd(const float* dUp, int dup_pstride, float* dU, int N, int Hl, int Wl, int C, void* stream) {
+  HPFG_ARG_CHECK(dUp && dU && C % 4 == 0 && N > 0 && Hl > 0 && Wl > 0, "upsample2x_bwd: bad args");
+  long total = (long)N * Hl * Wl * (C / 4);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dUp, dup_pstride, dU, N, Hl, Wl, C);
+  return hpfg_launch_status("upsample_bwd_kernel");
+}
+
+extern "C" int hpfg_cutmix_blend(const float* a, const float* b, const float* mask, float* out, long n, void* stream) {
+  HPFG_ARG_CHECK(a && b && mask && out && n > 0, "cutmix_blend: bad args");
+  hipLaunchKernelGGL(cutmix_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, mask, out, n);
+  return hpfg_launch_status("cutmix_kernel");
+}
+
+extern "C" int hpfg_argmax_labels(const float* logits, int N, int H, int W, int C, const uint8_t* mix_labels, const float* mix_mask, uint8_t* out,
+                                  void* stream) {
+  HPFG_ARG_CHECK(logits && out && C >= 1 && C <= 255, "argmax_labels: bad args");
+  HPFG_ARG_CHECK((mix_labels == nullptr) == (mix_mask == nullptr), "argmax_labels: mix_labels and mix_mask go together");
+  long npix = (long)N * H * W;
+  hipLaunchKernelGGL(argmax_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, logits, npix, C, mix_labels, mix_mask, out);
+  return hpfg_launch_status("argmax_kernel");
+}
+
+extern "C" int hpfg_sgd_step(float* p, const float* g, float* mom, long n, const float* lr_dev, float momentum, float weight_decay, float grad_scale,
+                             void* stream) {
+  HPFG_ARG_CHECK(p && g && mom && lr_dev && n > 0, "sgd_step: bad args");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, mom, n, lr_dev, momentum, weight_decay, grad_scale);
+  return hpfg_launch_status("sgd_kernel");
+}
+
+extern "C" int hpfg_ema_update(float* t, const float* s, long n, const float* alpha_dev, void* stream) {
+  HPFG_ARG_CHECK(t && s && alpha_dev && n > 0, "ema_update: bad args");
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, t, s, n, alpha_dev);
+  return hpfg_launch_status("ema_kernel");
+}

@@ -1,0 +1,381 @@
+"""Kernel schedule of one U-Net forward / backward pass on the HIP library.
+
+The engine owns the device workspace for a fixed (N, H, W) problem: the raw (pre-BatchNorm) output of every conv, the
+per-layer BatchNorm tables, packed weights, gradient buffers.  It issues the C-ABI calls of include/hpfg_hip.h in the
+order of the reference graph (model/unet.py:61-117); no tensor op of the network runs in PyTorch.
+
+Layer naming follows the reference's state_dict keys (e.g. ``encoder.down1.maxpool_conv.1.conv_conv.0``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+
+WIDTHS = (16, 32, 64, 128, 256)          # model/unet.py:161
+ENC_DROPOUT = (0.05, 0.1, 0.2, 0.3, 0.5)  # model/unet.py:162
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def _pad16(c: int) -> int:
+    return (c + 15) // 16 * 16
+
+
+@dataclass
+class ConvSpec:
+    name: str            # state_dict prefix of the conv ("….weight", "….bias")
+    bn: Optional[str]    # state_dict prefix of its BatchNorm, or None
+    cin: int
+    cout: int
+    taps: int
+    h: int               # output height / width
+    w: int
+    drop_p: float = 0.0  # dropout applied to this layer's activated output
+    idx: int = 0
+    cin_pad: int = 0
+    cout_pad: int = 0
+
+    def __post_init__(self):
+        self.cin_pad, self.cout_pad = _pad16(self.cin), _pad16(self.cout)
+
+
+def enc_prefix(lvl: int) -> str:
+    return "encoder.in_conv.conv_conv" if lvl == 0 else f"encoder.down{lvl}.maxpool_conv.1.conv_conv"
+
+
+def build_specs(in_ch: int, ncls: int, H: int, W: int) -> Dict[str, ConvSpec]:
+    specs: Dict[str, ConvSpec] = {}
+
+    def add(s: ConvSpec):
+        s.idx = len(specs)
+        specs[s.name] = s
+
+    cprev = in_ch
+    for lvl, c in enumerate(WIDTHS):
+        p, h, w = enc_prefix(lvl), H >> lvl, W >> lvl
+        add(ConvSpec(f"{p}.0", f"{p}.1", cprev, c, 9, h, w, ENC_DROPOUT[lvl]))
+        add(ConvSpec(f"{p}.4", f"{p}.5", c, c, 9, h, w))
+        cprev = c
+    for k in range(1, 5):
+        c1, c2 = WIDTHS[5 - k], WIDTHS[4 - k]
+        hl, wl = H >> (5 - k), W >> (5 - k)
+        add(ConvSpec(f"decoder.up{k}.conv1x1", None, c1, c2, 1, hl, wl))
+        p = f"decoder.up{k}.conv.conv_conv"
+        add(ConvSpec(f"{p}.0", f"{p}.1", 2 * c2, c2, 9, 2 * hl, 2 * wl))
+        add(ConvSpec(f"{p}.4", f"{p}.5", c2, c2, 9, 2 * hl, 2 * wl))
+    add(ConvSpec("decoder.out_conv", None, WIDTHS[0], ncls, 9, H, W))
+    return specs
+
+
+class UNetEngine:
+    """Forward/backward schedule for one (module, N, H, W).  ``params``: name -> tensor views (flat buffers of the module)."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor],
+                 in_ch: int, ncls: int, N: int, H: int, W: int, device: torch.device):
+        assert H % 16 == 0 and W % 16 == 0, "U-Net input must be a multiple of 16 (4 poolings)"
+        self.lib = L.load()
+        self.dev = device
+        self.N, self.H, self.W, self.in_ch, self.ncls = N, H, W, in_ch, ncls
+        self.params, self.buffers, self.grads = params, buffers, grads
+        self.specs = build_specs(in_ch, ncls, H, W)
+        self.order = list(self.specs.values())
+        f32 = dict(dtype=torch.float32, device=device)
+        # raw conv outputs (logits are allocated per forward call)
+        self.z: Dict[str, torch.Tensor] = {s.name: torch.empty(N, s.h, s.w, s.cout, **f32) for s in self.order if s.name != "decoder.out_conv"}
+        self.bn: Dict[str, torch.Tensor] = {s.name: torch.zeros(L.BN_ROWS, s.cout, **f32) for s in self.order if s.bn}
+        nb = max(self.lib.hpfg_conv_stat_blocks(N, s.h, s.w) * 2 * s.cout_pad for s in self.order if s.bn)
+        nb = max(nb, max(self.lib.hpfg_bn_bwd_blocks(N, s.h, s.w, s.cout) * 2 * s.cout for s in self.order if s.bn))
+        self.partials = torch.empty(nb, **f32)
+        self.sums = torch.empty(2 * 256, dtype=torch.float64, device=device)
+        # packed weights (the first conv reads OIHW directly)
+        self.packed = [s for s in self.order if s.idx > 0]
+        self.wpk_f = {s.name: torch.empty(s.taps * s.cin_pad * s.cout_pad, **f32) for s in self.packed}
+        self.wpk_d = {s.name: torch.empty(s.taps * s.cin_pad * s.cout_pad, **f32) for s in self.packed if s.idx > 1 or True}
+        self.bias_pad = {s.name: torch.empty(s.cout_pad, **f32) for s in self.packed}
+        descs = (L.PackDesc * len(self.packed))()
+        for d, s in zip(descs, self.packed):
+            d.w_oihw, d.b = L.ptr(params[f"{s.name}.weight"]), L.ptr(params[f"{s.name}.bias"])
+            d.wpk_fwd, d.wpk_dgrad, d.bias_pad = L.ptr(self.wpk_f[s.name]), L.ptr(self.wpk_d[s.name]), L.ptr(self.bias_pad[s.name])
+            d.Cout, d.Cin, d.CoutPad, d.CinPad, d.taps = s.cout, s.cin, s.cout_pad, s.cin_pad, s.taps
+        self._pack_host = descs
+        raw = bytes(descs)
+        self._pack_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.seed_dev = torch.zeros(1, dtype=torch.int32, device=device)   # run-time dropout seed word
+        self.base_seed = 0x1234567
+        self.train_stats = True
+        self.bwd_ready = False
+        self._bwd_alloc = False
+        self.x: Optional[torch.Tensor] = None
+        self.world = 1
+        self.ext_masks: Dict[str, torch.Tensor] = {}   # conv name -> uint8 NHWC keep-mask (parity tests replaying torch's masks)
+        self.allreduce = None    # callable(tensor) -> in-place sum across ranks (data parallel), set by hpfg_amd.parallel
+
+    # ---------------------------------------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def layer_seed(self, s: ConvSpec) -> int:
+        return (self.base_seed * 0x9E3779B1 + 0x85EBCA6B * (s.idx + 1)) & 0xFFFFFFFF
+
+    def _act_bn(self, name: str, mode=L.ACT_BNACT) -> L.Act:
+        s = self.specs[name]
+        a = L.Act()
+        a.z, a.bn, a.mode, a.C = L.ptr(self.z[name]), L.ptr(self.bn[name]), mode, s.cout
+        a.Hs, a.Ws, a.pstride, a.bn_stride, a.bn_coff = s.h, s.w, s.cout, s.cout, 0
+        if mode == L.ACT_BNACT and s.drop_p > 0 and self.dropout_on:
+            a.drop_p, a.drop_seed, a.seed_dev = s.drop_p, self.layer_seed(s), L.ptr(self.seed_dev)
+            a.drop_mask = L.ptr(self.ext_masks.get(name)) if self.ext_masks else None
+        return a
+
+    def _act_plain(self, t: torch.Tensor, C_: int, h: int, w: int, pstride: Optional[int] = None, mode=L.ACT_PLAIN) -> L.Act:
+        a = L.Act()
+        a.z, a.mode, a.C, a.Hs, a.Ws = L.ptr(t), mode, C_, h, w
+        a.pstride = C_ if pstride is None else pstride
+        if C_ % 4 != 0 and mode == L.ACT_PLAIN:
+            a.mode = L.ACT_STRIDED
+            a.sn, a.sc, a.sy, a.sx = h * w * a.pstride, 1, w * a.pstride, a.pstride
+        return a
+
+    def _act_input(self, x: torch.Tensor) -> L.Act:
+        a = L.Act()
+        a.z, a.mode, a.C, a.Hs, a.Ws = L.ptr(x), L.ACT_STRIDED, self.in_ch, self.H, self.W
+        a.sn, a.sc, a.sy, a.sx = x.stride(0), x.stride(1), x.stride(2), x.stride(3)
+        return a
+
+    def _act_dz(self, name: str, dA: torch.Tensor, da_pstride: int) -> L.Act:
+        s = self.specs[name]
+        a = L.Act()
+        a.z, a.bn, a.aux, a.mode, a.C = L.ptr(self.z[name]), L.ptr(self.bn[name]), L.ptr(dA), L.ACT_DZ, s.cout
+        a.Hs, a.Ws, a.pstride, a.aux_pstride, a.bn_stride = s.h, s.w, s.cout, da_pstride, s.cout
+        if s.drop_p > 0 and self.dropout_on:
+            a.drop_p, a.drop_seed, a.seed_dev = s.drop_p, self.layer_seed(s), L.ptr(self.seed_dev)
+            a.drop_mask = L.ptr(self.ext_masks.get(name)) if self.ext_masks else None
+        return a
+
+    def input_acts(self, name: str):
+        """(a0, a1) virtual input of conv `name` (forward view)."""
+        s = self.specs[name]
+        none = L.Act()
+        if name == "encoder.in_conv.conv_conv.0":
+            return self._act_input(self.x), none
+        if name == "decoder.out_conv":
+            return self._act_bn("decoder.up4.conv.conv_conv.4"), none
+        if name.endswith(".4"):
+            return self._act_bn(name[:-2] + ".0"), none
+        if name.startswith("encoder.down"):
+            lvl = int(name[len("encoder.down")])
+            return self._act_bn(enc_prefix(lvl - 1) + ".4", L.ACT_BNACT_POOL), none
+        k = int(name[len("decoder.up")])
+        prev = enc_prefix(4) + ".4" if k == 1 else f"decoder.up{k - 1}.conv.conv_conv.4"
+        if name.endswith("conv1x1"):
+            return self._act_bn(prev), none
+        # decoder block conv 0: cat([skip, up(conv1x1)])
+        skip = self._act_bn(enc_prefix(4 - k) + ".4")
+        u = self.specs[f"decoder.up{k}.conv1x1"]
+        up = self._act_plain(self.z[u.name], u.cout, u.h, u.w, mode=L.ACT_UP2X)
+        return skip, up
+
+    # ---------------------------------------------------------------------------------------------------------
+    def pack(self):
+        L.check(self.lib.hpfg_pack_weights(self._pack_dev.data_ptr(), self._pack_host, len(self.packed), self._stream()), "pack_weights")
+
+    def _finalize_bn(self, s: ConvSpec, nblk: int, track: bool):
+        st = self._stream()
+        count = float(self.N * s.h * s.w * self.world)
+        g, b = self.params[f"{s.bn}.weight"], self.params[f"{s.bn}.bias"]
+        rm = self.buffers[f"{s.bn}.running_mean"] if track else None
+        rv = self.buffers[f"{s.bn}.running_var"] if track else None
+        if self.world > 1:
+            sums = self.sums[: 2 * s.cout_pad]
+            L.check(self.lib.hpfg_reduce_partials(L.ptr(self.partials), nblk, s.cout_pad, L.ptr(sums), st), "reduce_partials")
+            self.allreduce(sums)
+            L.check(self.lib.hpfg_bn_fwd_finalize(None, 0, L.ptr(sums), count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), BN_MOMENTUM, BN_EPS,
+                                                  L.ptr(self.bn[s.name]), s.cout, st), "bn_fwd_finalize")
+        else:
+            L.check(self.lib.hpfg_bn_fwd_finalize(L.ptr(self.partials), nblk, None, count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), BN_MOMENTUM,
+                                                  BN_EPS, L.ptr(self.bn[s.name]), s.cout, st), "bn_fwd_finalize")
+
+    def forward(self, x: torch.Tensor, train: bool = True, dropout: Optional[bool] = None, track_running: bool = True,
+                seed_step: Optional[int] = None, needs_grad: bool = True) -> torch.Tensor:
+        """x: [N,C,H,W] fp32 on the device (any strides).  Returns logits as an [N,H,W,ncls] tensor (fresh allocation)."""
+        assert x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (self.N, self.in_ch, self.H, self.W), (x.shape, x.dtype, x.device)
+        st = self._stream()
+        self.x = x
+        self.train_mode = train
+        self.dropout_on = train if dropout is None else dropout
+        if seed_step is not None:
+            self.seed_dev.fill_(int(seed_step) & 0x7FFFFFFF)
+        self.pack()
+        logits = torch.empty(self.N, self.H, self.W, self.ncls, dtype=torch.float32, device=self.dev)
+        for s in self.order:
+            a0, a1 = self.input_acts(s.name)
+            out = logits if s.name == "decoder.out_conv" else self.z[s.name]
+            want_stats = bool(s.bn) and train
+            nblk = self.lib.hpfg_conv_stat_blocks(self.N, s.h, s.w)
+            if s.idx == 0:
+                L.check(self.lib.hpfg_conv3x3_first_fwd(C.byref(a0), L.ptr(self.params[f"{s.name}.weight"]), L.ptr(self.params[f"{s.name}.bias"]),
+                                                        L.ptr(out), L.ptr(self.partials) if want_stats else None, self.N, s.h, s.w, s.cin, s.cout, st),
+                        "conv3x3_first_fwd")
+            else:
+                ca = L.ConvArgs()
+                ca.a0, ca.a1 = a0, a1
+                ca.wpk, ca.bias, ca.out = L.ptr(self.wpk_f[s.name]), L.ptr(self.bias_pad[s.name]), L.ptr(out)
+                ca.stat_partials = L.ptr(self.partials) if want_stats else None
+                ca.out_pstride, ca.Cout, ca.CoutPad = s.cout, s.cout, s.cout_pad
+                ca.N, ca.H, ca.W, ca.taps = self.N, s.h, s.w, s.taps
+                L.check(self.lib.hpfg_conv_fwd(C.byref(ca), st), f"conv_fwd[{s.name}]")
+            if s.bn:
+                if train:
+                    self._finalize_bn(s, nblk, track_running)
+                else:
+                    L.check(self.lib.hpfg_bn_eval_table(L.ptr(self.params[f"{s.bn}.weight"]), L.ptr(self.params[f"{s.bn}.bias"]),
+                                                        L.ptr(self.buffers[f"{s.bn}.running_mean"]), L.ptr(self.buffers[f"{s.bn}.running_var"]), BN_EPS,
+                                                        L.ptr(self.bn[s.name]), s.cout, st), "bn_eval_table")
+        self.bwd_ready = bool(train and needs_grad)
+        return logits
+
+    def materialize(self, name: str, mode=L.ACT_BNACT) -> torch.Tensor:
+        """Activated output of conv `name` as a real [N,h,w,C] tensor (projection-neck input, tests)."""
+        s = self.specs[name]
+        a = self._act_bn(name, mode)
+        h, w = (s.h // 2, s.w // 2) if mode == L.ACT_BNACT_POOL else (s.h, s.w)
+        out = torch.empty(self.N, h, w, s.cout, dtype=torch.float32, device=self.dev)
+        L.check(self.lib.hpfg_act_materialize(C.byref(a), None, self.N, h, w, L.ptr(out), self._stream()), "act_materialize")
+        return out
+
+    def materialize_input(self, name: str) -> torch.Tensor:
+        """Virtual input of conv `name` ([N,h,w,Cin]) -- what the conv kernel stages into LDS."""
+        s = self.specs[name]
+        a0, a1 = self.input_acts(name)
+        out = torch.empty(self.N, s.h, s.w, s.cin, dtype=torch.float32, device=self.dev)
+        L.check(self.lib.hpfg_act_materialize(C.byref(a0), C.byref(a1), self.N, s.h, s.w, L.ptr(out), self._stream()), "act_materialize")
+        return out
+
+    # ---------------------------------------------------------------------------------------------------------
+    def _alloc_bwd(self):
+        if self._bwd_alloc:
+            return
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        N = self.N
+        self.dA: Dict[str, torch.Tensor] = {}
+        self.dA_ps: Dict[str, int] = {}
+        # gradient w.r.t. each BN'd conv's activated output.  Skip features alias the first half of the decoder's dCat.
+        self.dcat: Dict[int, torch.Tensor] = {}
+        for k in range(1, 5):
+            s = self.specs[f"decoder.up{k}.conv.conv_conv.0"]
+            self.dcat[k] = torch.empty(N, s.h, s.w, s.cin, **f32)
+            skip = enc_prefix(4 - k) + ".4"
+            self.dA[skip] = self.dcat[k]          # channels [0, C2) with pixel stride 2*C2
+            self.dA_ps[skip] = s.cin
+        for s in self.order:
+            if s.bn and s.name not in self.dA:
+                self.dA[s.name] = torch.empty(N, s.h, s.w, s.cout, **f32)
+                self.dA_ps[s.name] = s.cout
+        self.dU = {k: torch.empty(N, self.specs[f"decoder.up{k}.conv1x1"].h, self.specs[f"decoder.up{k}.conv1x1"].w,
+                                  self.specs[f"decoder.up{k}.conv1x1"].cout, **f32) for k in range(1, 5)}
+        self.dP = {lvl: torch.empty(N, self.specs[enc_prefix(lvl) + ".0"].h, self.specs[enc_prefix(lvl) + ".0"].w,
+                                    self.specs[enc_prefix(lvl) + ".0"].cin, **f32) for lvl in range(1, 5)}
+        slab = max(self.lib.hpfg_wgrad_slab_floats(N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps) for s in self.order)
+        self.slab = torch.empty(slab, **f32)
+        self.csum_scratch = torch.empty(512 * 256, **f32)
+        self._bwd_alloc = True
+
+    def _bn_backward(self, s: ConvSpec):
+        """BatchNorm/LeakyReLU/Dropout backward statistics of layer s -> k1,k2,k3 rows + dgamma/dbeta."""
+        st = self._stream()
+        g = self._act_dz(s.name, self.dA[s.name], self.dA_ps[s.name])
+        nblk = self.lib.hpfg_bn_bwd_blocks(self.N, s.h, s.w, s.cout)
+        L.check(self.lib.hpfg_bn_bwd_reduce(C.byref(g), self.N, s.h, s.w, L.ptr(self.partials), st), f"bn_bwd_reduce[{s.name}]")
+        count = float(self.N * s.h * s.w * self.world)
+        gam = self.params[f"{s.bn}.weight"]
+        dg, db = self.grads[f"{s.bn}.weight"], self.grads[f"{s.bn}.bias"]
+        if self.world > 1:
+            sums = self.sums[: 2 * s.cout]
+            L.check(self.lib.hpfg_reduce_partials(L.ptr(self.partials), nblk, s.cout, L.ptr(sums), st), "reduce_partials")
+            self.allreduce(sums)
+            L.check(self.lib.hpfg_bn_bwd_finalize(None, 0, L.ptr(sums), count, L.ptr(gam), L.ptr(self.bn[s.name]), L.ptr(dg), L.ptr(db), s.cout, st),
+                    "bn_bwd_finalize")
+        else:
+            L.check(self.lib.hpfg_bn_bwd_finalize(L.ptr(self.partials), nblk, None, count, L.ptr(gam), L.ptr(self.bn[s.name]), L.ptr(dg), L.ptr(db),
+                                                  s.cout, st), "bn_bwd_finalize")
+        return g
+
+    def _wgrad(self, s: ConvSpec, g: L.Act):
+        wa = L.WgradArgs()
+        wa.a0, wa.a1 = self.input_acts(s.name)
+        wa.g = g
+        wa.slab, wa.dw_oihw = L.ptr(self.slab), L.ptr(self.grads[f"{s.name}.weight"])
+        wa.Cin, wa.CinPad, wa.Cout, wa.CoutPad = s.cin, s.cin_pad, s.cout, s.cout_pad
+        wa.N, wa.H, wa.W, wa.taps = self.N, s.h, s.w, s.taps
+        wa.S = self.lib.hpfg_wgrad_splits(self.N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps)
+        L.check(self.lib.hpfg_wgrad(C.byref(wa), self._stream()), f"wgrad[{s.name}]")
+
+    def _dgrad(self, s: ConvSpec, g: L.Act, out: torch.Tensor):
+        """out [N,h,w,cin] = conv-transpose of dZ with this layer's weights."""
+        ca = L.ConvArgs()
+        ca.a0, ca.a1 = g, L.Act()
+        ca.wpk, ca.bias, ca.out, ca.stat_partials = L.ptr(self.wpk_d[s.name]), None, L.ptr(out), None
+        ca.out_pstride, ca.Cout, ca.CoutPad = s.cin, s.cin, s.cin_pad
+        ca.N, ca.H, ca.W, ca.taps = self.N, s.h, s.w, s.taps
+        L.check(self.lib.hpfg_conv_fwd(C.byref(ca), self._stream()), f"dgrad[{s.name}]")
+
+    def backward(self, dlogits: torch.Tensor, dfeat4: Optional[torch.Tensor] = None):
+        """dlogits: [N,H,W,ncls] contiguous.  dfeat4: optional gradient w.r.t. the activated bottleneck [N,h,w,256].
+        Writes every parameter gradient of encoder/decoder into self.grads (overwrite).  Biases of convs that feed a
+        train-mode BatchNorm have an exactly zero gradient (the batch mean removes them); their slots are never written and
+        rely on the zero-initialised gradient buffer."""
+        assert self.bwd_ready, "backward() needs a preceding train-mode forward()"
+        assert dlogits.is_contiguous() and tuple(dlogits.shape) == (self.N, self.H, self.W, self.ncls)
+        self._alloc_bwd()
+        st = self._stream()
+        N = self.N
+        sp = self.specs
+        # ---- out_conv
+        s = sp["decoder.out_conv"]
+        g = self._act_plain(dlogits, self.ncls, s.h, s.w)
+        self._wgrad(s, g)
+        L.check(self.lib.hpfg_channel_sum(L.ptr(dlogits), self.ncls, N * s.h * s.w, self.ncls, L.ptr(self.grads[f"{s.name}.bias"]),
+                                          L.ptr(self.csum_scratch), st), "channel_sum")
+        self._dgrad(s, g, self.dA["decoder.up4.conv.conv_conv.4"])
+        # ---- decoder blocks, last to first
+        for k in range(4, 0, -1):
+            p = f"decoder.up{k}.conv.conv_conv"
+            s2, s1, su = sp[f"{p}.4"], sp[f"{p}.0"], sp[f"decoder.up{k}.conv1x1"]
+            g2 = self._bn_backward(s2)
+            self._wgrad(s2, g2)
+            self._dgrad(s2, g2, self.dA[s1.name])
+            g1 = self._bn_backward(s1)
+            self._wgrad(s1, g1)
+            self._dgrad(s1, g1, self.dcat[k])                      # [dSkip | dUp]
+            c2 = su.cout
+            dup = self.dcat[k].view(-1)[c2:]                        # channel offset c2, pixel stride 2*c2
+            L.check(self.lib.hpfg_upsample2x_bwd(L.ptr(dup), 2 * c2, L.ptr(self.dU[k]), N, su.h, su.w, c2, st), "upsample2x_bwd")
+            gu = self._act_plain(self.dU[k], c2, su.h, su.w)
+            self._wgrad(su, gu)
+            L.check(self.lib.hpfg_channel_sum(L.ptr(self.dU[k]), c2, N * su.h * su.w, c2, L.ptr(self.grads[f"{su.name}.bias"]),
+                                              L.ptr(self.csum_scratch), st), "channel_sum")
+            prev = enc_prefix(4) + ".4" if k == 1 else f"decoder.up{k - 1}.conv.conv_conv.4"
+            self._dgrad(su, gu, self.dA[prev])
+        if dfeat4 is not None:
+            self.dA[enc_prefix(4) + ".4"].add_(dfeat4)
+        # ---- encoder blocks, deepest first
+        for lvl in range(4, -1, -1):
+            p = enc_prefix(lvl)
+            s2, s1 = sp[f"{p}.4"], sp[f"{p}.0"]
+            g2 = self._bn_backward(s2)
+            self._wgrad(s2, g2)
+            self._dgrad(s2, g2, self.dA[s1.name])
+            g1 = self._bn_backward(s1)
+            self._wgrad(s1, g1)
+            if lvl > 0:
+                self._dgrad(s1, g1, self.dP[lvl])
+                below = enc_prefix(lvl - 1) + ".4"
+                src = self._act_bn(below)
+                src.drop_p = 0.0
+                L.check(self.lib.hpfg_pool_scatter_add(C.byref(src), L.ptr(self.dP[lvl]), s1.cin, L.ptr(self.dA[below]), self.dA_ps[below],
+                                                       N, s1.h, s1.w, st), "pool_scatter_add")
+        self.bwd_ready = False

@@ -1,0 +1,297 @@
+"""U-Net / U-Net+ modules whose forward and backward run on the gfx950 HIP library.
+
+Drop-in for the reference's ``model/unet.py`` classes ``UNet`` and ``UNet_Plus`` (unet.py:155-206): same constructor
+signature, same ``state_dict()`` keys and shapes (so reference checkpoints load), same ``.encoder`` / ``.decoder`` attributes
+(``main.py:72-76`` iterates their parameters), ``UNet_Plus.val(x)`` and the ``(logits, (g, d), (g, d))`` return value.
+The submodules are parameter containers only: the arithmetic is done by ``hpfg_amd.engine.UNetEngine`` through one
+``torch.autograd.Function`` per network, not by nn.Conv2d / nn.BatchNorm2d forward calls.
+
+All parameters live in one flat fp32 buffer (and all gradients in another), so that EMA, SGD and the data-parallel gradient
+all-reduce are one kernel / one collective each.  There is no CPU path: a non-GPU input raises.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import engine as E
+from .. import heads
+
+WIDTHS = E.WIDTHS
+
+
+def _block(cin: int, cout: int) -> nn.Module:
+    """Parameter container with the key layout of the reference's ConvBlock (unet.py:15-25): conv_conv.{0,1,4,5}."""
+    m = nn.Module()
+    m.conv_conv = nn.ModuleDict(OrderedDict([
+        ("0", nn.Conv2d(cin, cout, 3, padding=1)), ("1", nn.BatchNorm2d(cout)),
+        ("4", nn.Conv2d(cout, cout, 3, padding=1)), ("5", nn.BatchNorm2d(cout))]))
+    return m
+
+
+def _down(cin: int, cout: int) -> nn.Module:
+    m = nn.Module()
+    m.maxpool_conv = nn.ModuleDict(OrderedDict([("1", _block(cin, cout))]))
+    return m
+
+
+def _up(c1: int, c2: int) -> nn.Module:
+    m = nn.Module()
+    m.conv1x1 = nn.Conv2d(c1, c2, 1)
+    m.conv = _block(2 * c2, c2)
+    return m
+
+
+def _neck(cin: int, hid: int, out: int = 128) -> nn.Module:
+    """projection_conv parameters (unet.py:125-138): mlp.{0,2} Linear, mlp_conv.{0,2} 1x1 conv."""
+    m = nn.Module()
+    m.mlp = nn.ModuleDict(OrderedDict([("0", nn.Linear(cin, hid)), ("2", nn.Linear(hid, out))]))
+    m.mlp_conv = nn.ModuleDict(OrderedDict([("0", nn.Conv2d(cin, hid, 1)), ("2", nn.Conv2d(hid, out, 1))]))
+    return m
+
+
+class _UNetFn(torch.autograd.Function):
+    """Whole-network autograd node: forward = engine.forward, backward = engine.backward into the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, anchor: torch.Tensor, x: torch.Tensor, net: "UNet", want_feat: bool, needs_grad: bool):
+        eng = net._acquire_engine(x)
+        logits = eng.forward(x, train=net.training, track_running=True, seed_step=net._next_seed(), needs_grad=needs_grad)
+        ctx.net, ctx.eng, ctx.want_feat = net, eng, want_feat
+        out = logits.permute(0, 3, 1, 2)
+        if want_feat:
+            feat = eng.materialize(E.enc_prefix(4) + ".4").permute(0, 3, 1, 2)
+            return out, feat
+        return out, logits.new_empty(0)
+
+    @staticmethod
+    def backward(ctx, dlogits, dfeat):
+        net, eng = ctx.net, ctx.eng
+        dl = dlogits.permute(0, 2, 3, 1)
+        if not dl.is_contiguous():
+            dl = dl.contiguous()
+        df = None
+        if ctx.want_feat and dfeat is not None:
+            df = dfeat.permute(0, 2, 3, 1).contiguous()
+        eng.backward(dl, df)
+        net._accumulate_grads(eng)
+        return None, None, None, None, None
+
+
+class UNet(nn.Module):
+    def __init__(self, in_channels: int = 1, num_classes: int = 4):
+        super().__init__()
+        self.in_channels, self.num_classes = in_channels, num_classes
+        enc = nn.Module()
+        enc.in_conv = _block(in_channels, WIDTHS[0])
+        for k in range(1, 5):
+            setattr(enc, f"down{k}", _down(WIDTHS[k - 1], WIDTHS[k]))
+        dec = nn.Module()
+        for k in range(1, 5):
+            setattr(dec, f"up{k}", _up(WIDTHS[5 - k], WIDTHS[4 - k]))
+        dec.out_conv = nn.Conv2d(WIDTHS[0], num_classes, 3, padding=1)
+        self.encoder, self.decoder = enc, dec
+        self._init_runtime()
+
+    # ---- flat storage -----------------------------------------------------------------------------------------
+    def _init_runtime(self):
+        self._flat: Optional[torch.Tensor] = None
+        self._flat_grad: Optional[torch.Tensor] = None
+        self._flat_buf: Optional[torch.Tensor] = None
+        self._flat_long: Optional[torch.Tensor] = None
+        self._engines: Dict[Tuple, List[E.UNetEngine]] = {}
+        self._anchor: Optional[torch.Tensor] = None
+        self._seed_counter = 0
+        self.dropout_seed = 0x1234567
+        self.dp = None   # hpfg_amd.parallel.DataParallelContext or None
+        self.external_dropout_masks = None   # optional {conv name: uint8 NHWC keep-mask}: replay masks drawn elsewhere (tests)
+        self._flatten()
+
+    def _float_buffers(self):
+        return [(n, b) for n, b in self.named_buffers() if b.is_floating_point()]
+
+    def _flatten(self):
+        """(Re)pack parameters, their gradients and the float buffers into three flat tensors; tensors become views."""
+        ps = list(self.named_parameters())
+        if not ps:
+            return
+        dev = ps[0][1].device
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1).float() for _, p in ps]).to(dev)
+            flat_grad = torch.zeros_like(flat)
+            off = 0
+            self._offsets: Dict[str, Tuple[int, int]] = {}
+            for n, p in ps:
+                k = p.numel()
+                p.data = flat[off:off + k].view(p.shape)
+                p.grad = None
+                self._offsets[n] = (off, k)
+                off += k
+            bs = self._float_buffers()
+            fb = torch.cat([b.detach().reshape(-1).float() for _, b in bs]).to(dev)
+            off = 0
+            for n, b in bs:
+                k = b.numel()
+                b.data = fb[off:off + k].view(b.shape)
+                off += k
+            ls = [(n, b) for n, b in self.named_buffers() if b.dtype == torch.long]
+            fl = torch.stack([b.detach().reshape(()) for _, b in ls]).to(dev) if ls else torch.zeros(0, dtype=torch.long, device=dev)
+            for i, (n, b) in enumerate(ls):
+                b.data = fl[i]
+        self._flat, self._flat_grad, self._flat_buf, self._flat_long = flat, flat_grad, fb, fl
+        self._engines = {}
+        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        self._backbone_numel = sum(p.numel() for n, p in ps if n.startswith("encoder.") or n.startswith("decoder."))
+
+    def _is_flat(self) -> bool:
+        ps = list(self.parameters())
+        if self._flat is None or not ps:
+            return False
+        first, last = ps[0], ps[-1]
+        return (first.data_ptr() == self._flat.data_ptr() and
+                last.data_ptr() == self._flat.data_ptr() + (self._flat.numel() - last.numel()) * 4)
+
+    def _ensure_flat(self):
+        if not self._is_flat():
+            self._flatten()
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._flatten()
+        return out
+
+    def __deepcopy__(self, memo):
+        cls = self.__class__
+        new = cls.__new__(cls)
+        nn.Module.__init__(new)
+        import copy
+        for k, v in self.__dict__.items():
+            if k in ("_flat", "_flat_grad", "_flat_buf", "_flat_long", "_engines", "_anchor", "dp"):
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new.dp = self.dp
+        new._flat = new._flat_grad = new._flat_buf = new._flat_long = None
+        new._engines, new._anchor = {}, None
+        new._flatten()
+        return new
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self._ensure_flat()
+        return out
+
+    @property
+    def flat_params(self) -> torch.Tensor:
+        self._ensure_flat()
+        return self._flat
+
+    @property
+    def flat_grads(self) -> torch.Tensor:
+        self._ensure_flat()
+        return self._flat_grad
+
+    def backbone_numel(self) -> int:
+        """Number of leading flat elements that belong to encoder+decoder (main.py:68-76 updates only those)."""
+        return self._backbone_numel
+
+    def attach_grad_views(self):
+        """Make every p.grad a view of the flat gradient buffer (so torch optimizers see the HIP-computed gradients)."""
+        for n, p in self.named_parameters():
+            if p.requires_grad:
+                off, k = self._offsets[n]
+                g = self._flat_grad[off:off + k].view(p.shape)
+                if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                    p.grad = g
+
+    def zero_flat_grad(self):
+        self._flat_grad.zero_()
+
+    # ---- engines ----------------------------------------------------------------------------------------------
+    def _next_seed(self) -> int:
+        self._seed_counter += 1
+        return self._seed_counter
+
+    def _acquire_engine(self, x: torch.Tensor) -> E.UNetEngine:
+        if not x.is_cuda:
+            raise RuntimeError("hpfg_amd.UNet runs on the HIP library only: move the input to the GPU (no CPU fallback)")
+        self._ensure_flat()
+        if x.device != self._flat.device:
+            raise RuntimeError(f"input on {x.device} but parameters on {self._flat.device}")
+        key = (tuple(x.shape), x.device.index)
+        pool = self._engines.setdefault(key, [])
+        eng = next((e for e in pool if not e.bwd_ready), None)
+        if eng is None and len(pool) >= 4:
+            eng = pool[0]   # graphs that were never back-propagated are dropped
+        if eng is None:
+            named = dict(self.named_parameters())
+            params = {n: p.data for n, p in named.items()}
+            bufs = {n: b.data for n, b in self.named_buffers()}
+            gtmp = torch.zeros_like(self._flat)
+            grads = {n: gtmp[o:o + k].view(named[n].shape) for n, (o, k) in self._offsets.items()}
+            eng = E.UNetEngine(params, bufs, grads, self.in_channels, self.num_classes, x.shape[0], x.shape[2], x.shape[3], x.device)
+            eng.gtmp = gtmp
+            pool.append(eng)
+        eng.base_seed = self.dropout_seed
+        eng.ext_masks = self.external_dropout_masks or {}
+        if self.dp is not None:
+            eng.world, eng.allreduce = self.dp.world_size, self.dp.allreduce_sum
+        return eng
+
+    def _accumulate_grads(self, eng: E.UNetEngine):
+        n = self._backbone_numel
+        first = next(iter(self.parameters()))
+        if first.grad is None:          # zero_grad(set_to_none=True) semantics: None means zero
+            self._flat_grad[:n].copy_(eng.gtmp[:n])
+        else:
+            self._flat_grad[:n].add_(eng.gtmp[:n])
+        self.attach_grad_views()
+
+    def _prepare_head_grads(self):
+        """Neck parameters get their gradients from torch autograd; make those accumulate into the flat buffer."""
+        n = self._backbone_numel
+        heads_ = [p for nme, p in self.named_parameters() if not (nme.startswith("encoder.") or nme.startswith("decoder."))]
+        if heads_ and heads_[0].requires_grad and (heads_[0].grad is None or heads_[0].grad.data_ptr() != self._flat_grad.data_ptr() + 4 * n):
+            self._flat_grad[n:].zero_()
+            for nme, p in self.named_parameters():
+                if not (nme.startswith("encoder.") or nme.startswith("decoder.")):
+                    off, k = self._offsets[nme]
+                    p.grad = self._flat_grad[off:off + k].view(p.shape)
+
+    def _bump_bn_counters(self):
+        self._flat_long.add_(1)      # num_batches_tracked of all 18 BatchNorm layers, one kernel
+
+    def _run(self, x: torch.Tensor, want_feat: bool):
+        self._ensure_flat()
+        if self.training:
+            self._bump_bn_counters()
+        trainable = next(iter(self.parameters())).requires_grad
+        anchor = self._anchor if trainable else self._anchor.detach()
+        return _UNetFn.apply(anchor, x.float(), self, want_feat, bool(trainable and torch.is_grad_enabled()))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run(x, False)[0]
+
+
+class UNet_Plus(UNet):
+    def __init__(self, in_channels: int = 1, num_classes: int = 4):
+        nn.Module.__init__(self)
+        self.in_channels, self.num_classes = in_channels, num_classes
+        tmp = UNet.__new__(UNet)
+        UNet.__init__(tmp, in_channels, num_classes)       # consumes the RNG exactly like encoder+decoder construction
+        self.encoder, self.decoder = tmp.encoder, tmp.decoder
+        self.dense_projection_high = _neck(WIDTHS[-1], 2048)
+        self.dense_projection_head = _neck(num_classes, 1024)
+        self._init_runtime()
+
+    def val(self, x):
+        return self._run(x, False)[0]
+
+    def forward(self, x):
+        self._prepare_head_grads()
+        logits, feat = self._run(x, True)
+        high = heads.projection_neck(self.dense_projection_high, feat)
+        head = heads.projection_neck(self.dense_projection_head, logits)
+        return logits, high, head

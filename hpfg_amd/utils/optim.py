@@ -1,0 +1,81 @@
+"""Optimizer / scheduler factories with the reference's signatures (utils/__init__.py:13-49).
+
+``build_optimizer(args, model)`` returns ``FusedSGD`` for an hpfg_amd U-Net on the GPU: torch.optim.SGD's law
+(momentum, weight decay on every parameter, no dampening / nesterov) as ONE HIP kernel over the model's flat parameter,
+gradient and momentum buffers, with the learning rate read from device memory so the step can live inside a hipGraph.
+It is a ``torch.optim.Optimizer`` (param_groups, state_dict, zero_grad), so the reference's LR schedulers drive it unchanged.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib as L
+from .scheduler import CosineWarmupLR_Scheduler, Medical_LR, PolyLR
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, model, lr=0.01, momentum=0.0, weight_decay=0.0):
+        self.model = model
+        params = [p for p in model.parameters() if p.requires_grad]
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        flat = model.flat_params
+        self._mom = torch.zeros_like(flat)
+        self._lr_host = torch.zeros(1, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(1)
+        self._lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.model.zero_flat_grad()          # one memset; p.grad views stay attached
+        self.model.attach_grad_views()
+
+    def push_lr(self):
+        """Stage the current lr on the device (async copy from pinned memory; capturable)."""
+        self._lr_host[0] = float(self.param_groups[0]["lr"])
+        self._lr_dev.copy_(self._lr_host, non_blocking=True)
+
+    @torch.no_grad()
+    def step(self, closure=None, push_lr: bool = True):
+        g = self.param_groups[0]
+        flat, grad = self.model.flat_params, self.model.flat_grads
+        if self._mom.data_ptr() == 0 or self._mom.numel() != flat.numel() or self._mom.device != flat.device:
+            self._mom = torch.zeros_like(flat)
+        if push_lr:
+            self.push_lr()
+        st = torch.cuda.current_stream(flat.device).cuda_stream
+        L.check(L.load().hpfg_sgd_step(L.ptr(flat), L.ptr(grad), L.ptr(self._mom), flat.numel(), L.ptr(self._lr_dev), float(g["momentum"]),
+                                       float(g["weight_decay"]), float(self.grad_scale), st), "sgd_step")
+
+    def state_dict(self):
+        d = super().state_dict()
+        d["flat_momentum"] = self._mom
+        return d
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        mom = sd.pop("flat_momentum", None)
+        super().load_state_dict(sd)
+        if mom is not None:
+            self._mom.copy_(mom)
+
+
+def build_optimizer(args, model):
+    if args.opt == "sgd":
+        if hasattr(model, "flat_params") and model.flat_params.is_cuda:
+            return FusedSGD(model, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
+        return torch.optim.SGD(model.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
+    if args.opt == "adamW":
+        return torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    if args.opt == "adam":
+        return torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    raise ValueError("get_optimizer error")
+
+
+def build_lr_scheduler(args, optimizer):
+    if args.sched == "cosine":
+        return CosineWarmupLR_Scheduler(optimizer=optimizer, base_lr=args.lr, warmup_epochs=args.warmup_epochs, warmup_lr=args.warmup_lr,
+                                        final_lr=args.min_lr, iter_per_epoch=args.step_size, num_epochs=args.total_itrs // args.step_size)
+    if args.sched == "poly":
+        return PolyLR(optimizer, max_iters=args.total_itrs, power=0.1, min_lr=args.min_lr)
+    if args.sched == "medical":
+        return Medical_LR(optimizer=optimizer, base_lr=args.lr, max_iterations=args.total_itrs)
+    raise ValueError("get_lr_scheduler error")

@@ -1,0 +1,171 @@
+/*
+ * hpfg_hip.h -- C ABI of libhpfg_hip.so: the MI355X (gfx950) kernels behind HPFG's training hot path.
+ *
+ * The reference (fakerlove1/HPFG) is pure Python/PyTorch: its "FFI" for this path is the set of torch ops its
+ * U-Net and losses issue.  Each entry point below replaces one fused family of those ops
+ * and cites the reference lines whose arithmetic it reproduces.  Conventions:
+ *   - activations are fp32 NHWC on the device; all pointers are device pointers unless marked host;
+ *   - every function only enqueues work on `stream` (a hipStream_t passed as void*): no allocation, no
+ *     synchronisation, no host<->device copies, safe to capture into a hipGraph;
+ *   - return value 0 = ok, <0 = argument error (see hpfg_last_error()), >0 = hipError_t from the launch.
+ *
+ * "Virtual activations": train-mode BatchNorm makes conv -> BN -> LeakyReLU -> Dropout -> (MaxPool | Upsample+concat)
+ * a chain of per-element maps once the batch statistics are known, so consumers apply that chain while they load
+ * the producer's raw (pre-BN) conv output instead of reading a materialised activation.  HpfgAct describes such a
+ * source; the same descriptor describes the backward-side virtual tensor dZ (gradient w.r.t. a raw conv output).
+ */
+#ifndef HPFG_HIP_H
+#define HPFG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPFG_VERSION 100
+
+/* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
+enum { HPFG_BN_MEAN = 0, HPFG_BN_RSTD = 1, HPFG_BN_SCALE = 2, HPFG_BN_SHIFT = 3,
+       HPFG_BN_K1 = 4, HPFG_BN_K2 = 5, HPFG_BN_K3 = 6, HPFG_BN_SPARE = 7, HPFG_BN_ROWS = 8 };
+
+enum {
+  HPFG_ACT_NONE = 0,       /* contributes no channels */
+  HPFG_ACT_PLAIN = 1,      /* v = z[n,y,x,c]                       (NHWC, float4 path, C%4==0)               */
+  HPFG_ACT_STRIDED = 2,    /* v = z[n*sn + c*sc + y*sy + x*sx]     (any layout, scalar path; network input)  */
+  HPFG_ACT_BNACT = 3,      /* v = drop(lrelu(z*scale+shift))       unet.py:19-21,23-24 (BN train, LeakyReLU .01, Dropout) */
+  HPFG_ACT_BNACT_POOL = 4, /* v = max 2x2 of lrelu(z*scale+shift)  unet.py:37 (MaxPool2d(2)) fused on load   */
+  HPFG_ACT_UP2X = 5,       /* v = bilinear x2, align_corners=True  unet.py:51,56 fused on load               */
+  HPFG_ACT_DZ = 6          /* v = k1*g + k2*z + k3, g = aux*dropmask*lrelu'(z*scale+shift): BN/LeakyReLU/Dropout backward */
+};
+
+typedef struct HpfgAct {
+  const float* z;      /* raw tensor */
+  const float* bn;     /* BN table [HPFG_BN_ROWS][bn_stride] for BNACT/BNACT_POOL/DZ, else NULL */
+  const float* aux;    /* DZ: upstream gradient w.r.t. the activated output (dA) */
+  int32_t mode;
+  int32_t C;           /* channels this source provides (virtual channels >= C read as 0) */
+  int32_t Hs, Ws;      /* spatial size of z (POOL: 2x the virtual size, UP2X: half of it) */
+  int32_t pstride;     /* floats between pixels of z (PLAIN/BNACT/POOL/UP2X/DZ) */
+  int32_t aux_pstride; /* floats between pixels of aux (DZ) */
+  int32_t bn_stride;   /* row length of bn (= channel count of the producing layer) */
+  int32_t bn_coff;     /* first channel of this source inside the bn rows (normally 0) */
+  int32_t sn, sc, sy, sx; /* STRIDED element strides */
+  float drop_p;        /* dropout probability applied to this activation (BNACT, DZ); 0 = none */
+  uint32_t drop_seed;  /* counter-based RNG key; keep(i) = hash(i, seed) >= p*2^32, i = NHWC element index */
+  const uint8_t* drop_mask; /* optional explicit keep-mask (bytes, NHWC element order) used instead of the RNG: lets parity
+                               tests replay the masks torch drew in the reference run */
+  const uint32_t* seed_dev; /* optional device word added to drop_seed at run time (lets a captured hipGraph draw new masks per replay) */
+} HpfgAct;
+
+typedef struct HpfgConvArgs {
+  HpfgAct a0, a1;       /* input = channel concat [a0 | a1]  (torch.cat([skip, up]), unet.py:57); (a0.C+a1.C) padded to 16 */
+  const float* wpk;     /* weights in MFMA fragment order, see hpfg_pack_weights */
+  const float* bias;    /* [CoutPad] or NULL */
+  float* out;           /* raw output, NHWC, out_pstride floats per pixel */
+  float* stat_partials; /* NULL or [hpfg_conv_stat_blocks()][2][CoutPad]: per-block sum(z), sum(z*z) for BN (unet.py:19,23) */
+  int32_t out_pstride, Cout, CoutPad;
+  int32_t N, H, W;      /* output (= virtual input) size */
+  int32_t taps;         /* 9 (3x3, pad 1) or 1 (1x1) */
+} HpfgConvArgs;
+
+typedef struct HpfgWgradArgs {
+  HpfgAct a0, a1;       /* conv input (as in forward) */
+  HpfgAct g;            /* dZ: gradient w.r.t. the conv's raw output (DZ or PLAIN) */
+  float* slab;          /* workspace [S][taps][CinPad][CoutPad] */
+  float* dw_oihw;       /* result, PyTorch layout [Cout][Cin][k][k] (written, not accumulated) */
+  int32_t Cin, CinPad, Cout, CoutPad;
+  int32_t N, H, W, taps;
+  int32_t S;            /* number of pixel splits (slabs), from hpfg_wgrad_splits() */
+} HpfgWgradArgs;
+
+typedef struct HpfgPackDesc {   /* one conv layer for hpfg_pack_weights (device array of these) */
+  const float* w_oihw;  /* [Cout][Cin][k][k] (nn.Conv2d.weight, unet.py:18,22,50,99) */
+  const float* b;       /* [Cout] */
+  float* wpk_fwd;       /* [taps][CinPad/16][CoutPad/16][64][4]: B fragments of mfma_f32_16x16x4f32, k = input channel */
+  float* wpk_dgrad;     /* [taps][CoutPad/16][CinPad/16][64][4]: transposed + tap-flipped weights for dgrad; may be NULL */
+  float* bias_pad;      /* [CoutPad] */
+  int32_t Cout, Cin, CoutPad, CinPad, taps;
+} HpfgPackDesc;
+
+int hpfg_version(void);
+const char* hpfg_last_error(void);
+
+/* ---- forward ------------------------------------------------------------------------------------------- */
+/* nn.Conv2d(Cin<=4 -> 16, k3, p1) on the network input + BN partial sums (encoder.in_conv, unet.py:18-19,72). */
+int hpfg_conv3x3_first_fwd(const HpfgAct* x, const float* w_oihw, const float* bias, float* out, float* stat_partials,
+                           int N, int H, int W, int Cin, int Cout, void* stream);
+/* nn.Conv2d k3/k1 (+ fused producer BN/LeakyReLU/Dropout/MaxPool/Upsample/cat on load) + BN partial sums.
+ * Also serves dgrad: a0 = dZ (mode DZ/PLAIN), wpk = wpk_dgrad. */
+int hpfg_conv_fwd(const HpfgConvArgs* args, void* stream);
+int hpfg_conv_stat_blocks(int N, int H, int W);
+/* BatchNorm2d train-mode statistics -> table rows mean/rstd/scale/shift, running stats (momentum .1, unbiased var)
+ * (unet.py:19,23).  Either partials (float [nblk][2][C]) or pre-reduced sums (double [2][C], e.g. after an all-reduce). */
+int hpfg_bn_fwd_finalize(const float* partials, int nblk, const double* sums, double count, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps, float* bn, int C, void* stream);
+int hpfg_reduce_partials(const float* partials, int nblk, int C, double* sums, void* stream);
+/* eval-mode BatchNorm (model.eval(), val.py:268-287): table rows from the running statistics */
+int hpfg_bn_eval_table(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                       float* bn, int C, void* stream);
+int hpfg_pack_weights(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, void* stream);
+/* evaluate a virtual activation into memory (tests, projection-neck inputs): out [N,H,W,a0.C+a1.C] */
+int hpfg_act_materialize(const HpfgAct* a0, const HpfgAct* a1, int N, int H, int W, float* out, void* stream);
+/* the dropout keep-mask the loaders use, as bytes [n_elems] (tests feed it to the oracle) */
+int hpfg_dropout_mask(uint8_t* out, long n_elems, float p, uint32_t seed, const uint32_t* seed_dev, void* stream);
+
+/* ---- backward ------------------------------------------------------------------------------------------ */
+/* per-channel sum(g), sum(g*xhat) with g = dA*dropmask*lrelu'(y): partials [hpfg_bn_bwd_blocks][2][C] */
+int hpfg_bn_bwd_reduce(const HpfgAct* g /* mode DZ; k rows unused */, int N, int H, int W, float* partials, void* stream);
+int hpfg_bn_bwd_blocks(int N, int H, int W, int C);
+/* finalize: dgamma, dbeta (BatchNorm backward) and table rows k1,k2,k3 so that dz = k1*g + k2*z + k3 */
+int hpfg_bn_bwd_finalize(const float* partials, int nblk, const double* sums, double count, const float* gamma,
+                         float* bn, float* dgamma, float* dbeta, int C, void* stream);
+int hpfg_wgrad(const HpfgWgradArgs* args, void* stream);
+int hpfg_wgrad_splits(int N, int H, int W, int CinPad, int CoutPad, int taps);
+long hpfg_wgrad_slab_floats(int N, int H, int W, int CinPad, int CoutPad, int taps);
+/* first-layer wgrad: dW[co][ci][tap] for Cin<=4 from the strided input */
+/* bias gradient of a conv without BN: db[c] = sum over pixels of g[p][c] (conv1x1 / out_conv) */
+int hpfg_channel_sum(const float* g, int pstride, long npix, int C, float* out, float* scratch, void* stream);
+/* MaxPool2d(2) backward: dA[argmax position] += dP, recomputing the arg-max from the producer's raw output */
+int hpfg_pool_scatter_add(const HpfgAct* src /* BNACT view of the pooled tensor's producer */, const float* dP, int dp_pstride,
+                          float* dA, int da_pstride, int N, int Hp, int Wp, void* stream);
+/* bilinear x2 (align_corners) backward: dU[low res] = sum of taps of dUp (dUp has dup_pstride floats per pixel) */
+int hpfg_upsample2x_bwd(const float* dUp, int dup_pstride, float* dU, int N, int Hl, int Wl, int C, void* stream);
+
+/* ---- losses (main.py:164-197, medloss.py:44-56, diceloss.py:155-191, Mean-Teacher :103-106) -------------- */
+typedef struct HpfgLossArgs {
+  const float* logits;      /* [N,H,W,C] student logits (NHWC) */
+  const float* t_logits;    /* teacher logits for the MSE consistency term, or NULL */
+  const uint8_t* labels0;   /* labels for images [0,n_lab) (255 = ignore), group 0 */
+  const uint8_t* labels1;   /* (pseudo-)labels for images [n_lab,N), group 1, or NULL */
+  const float* coef;        /* device [8]: ce0, dice0, ce1, dice1, mse_w, 0,0,0  (per-step weights live on the device) */
+  float* partials;          /* workspace [hpfg_loss_blocks()][HPFG_LOSS_NSUM] */
+  float* sums;              /* out [HPFG_LOSS_NSUM] reduced sums (all-reduce these for data parallel) */
+  float* out;               /* out [8]: total, ce0, dice0, ce1, dice1, mse, 0, 0 */
+  float* dlogits;           /* backward output [N,H,W,C] */
+  int32_t N, n_lab, H, W, C;
+  int32_t world;            /* data-parallel world size (MSE / CE counts are global after the all-reduce) */
+  int32_t input_is_prob;    /* 1: `logits` already holds probabilities (DiceLoss(softmax=False), diceloss.py:178); CE/MSE weights must be 0 */
+} HpfgLossArgs;
+#define HPFG_LOSS_NSUM 32
+int hpfg_loss_blocks(int N, int H, int W);
+int hpfg_seg_loss_partials(const HpfgLossArgs* a, void* stream);   /* softmax + CE/Dice/MSE partial sums */
+int hpfg_seg_loss_finalize(const HpfgLossArgs* a, void* stream);   /* sums -> loss scalars (device) */
+int hpfg_seg_loss_bwd(const HpfgLossArgs* a, const float* grad_scale_dev /* NULL = 1 */, void* stream);   /* dlogits */
+/* pseudo-labels: argmax over classes of teacher logits, optionally CutMix-blended with labels (main.py:177-178) */
+int hpfg_argmax_labels(const float* logits, int N, int H, int W, int C, const uint8_t* mix_labels, const float* mix_mask,
+                       uint8_t* out, void* stream);
+/* CutMix image blend x1*(1-M)+xu*M (main.py:149) */
+int hpfg_cutmix_blend(const float* a, const float* b, const float* mask, float* out, long n, void* stream);
+
+/* ---- parameter updates --------------------------------------------------------------------------------- */
+/* torch.optim.SGD(momentum, weight_decay) over a flat parameter buffer (utils/__init__.py:15-16); lr read from device */
+int hpfg_sgd_step(float* p, const float* g, float* mom, long n, const float* lr_dev, float momentum, float weight_decay,
+                  float grad_scale, void* stream);
+/* EMA teacher: t = alpha*t + (1-alpha)*s over flat buffers (utils/utils.py:82-86); alpha read from device */
+int hpfg_ema_update(float* t, const float* s, long n, const float* alpha_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,53 @@
+"""CPU: the C-ABI library loads and exports every symbol include/hpfg_hip.h declares; the ctypes structs match the header."""
+import ctypes
+import os
+import re
+
+from hpfg_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "hpfg_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hpfg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = L.load()
+    names = _header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+        assert n in L.PROTOTYPES, f"{n} has no ctypes prototype"
+    assert sorted(L.PROTOTYPES) == names
+    assert lib.hpfg_version() == L.VERSION
+
+
+def test_struct_layouts_match_header_field_order():
+    src = open(os.path.join(ROOT, "include", "hpfg_hip.h")).read()
+    for cname, pyt in (("HpfgAct", L.Act), ("HpfgConvArgs", L.ConvArgs), ("HpfgWgradArgs", L.WgradArgs), ("HpfgPackDesc", L.PackDesc),
+                       ("HpfgLossArgs", L.LossArgs)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = decl.split(",")
+            first = names[0].split()[-1].lstrip("*")
+            fields.append(first)
+            fields += [n.strip().lstrip("*") for n in names[1:]]
+        assert fields == [f[0] for f in pyt._fields_], (cname, fields, [f[0] for f in pyt._fields_])
+
+
+def test_argument_errors_are_reported_not_crashed():
+    lib = L.load()
+    assert lib.hpfg_conv_fwd(None, None) == -1
+    assert b"null" in lib.hpfg_last_error()
+    assert lib.hpfg_wgrad(None, None) == -1
+    assert lib.hpfg_conv_stat_blocks(2, 32, 32) == 2 * 4 and lib.hpfg_conv_stat_blocks(1, 24, 24) == 9
+    assert lib.hpfg_wgrad_splits(16, 224, 224, 16, 16, 9) >= 1
+    assert ctypes.sizeof(L.Act) % 8 == 0

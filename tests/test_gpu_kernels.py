@@ -1,0 +1,207 @@
+"""GPU unit parity tests of the individual HIP kernels (through the C ABI) against plain PyTorch fp32 on the CPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hpfg_amd import _lib as L
+from oracle import rng_ref
+from tests.helpers import AdHocConv, maxerr, nchw, plain_act, stream
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def test_dropout_mask_matches_cpu_law():
+    n, p, seed = 100003, 0.3, 0xDEADBEEF
+    out = torch.empty(n, dtype=torch.uint8, device=DEV)
+    L.check(L.load().hpfg_dropout_mask(L.ptr(out), n, p, seed, None, stream(DEV)), "mask")
+    ref = rng_ref.keep_mask_nhwc(n, p, seed)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    assert abs(ref.mean() - 0.7) < 0.01
+
+
+CONV_CASES = [  # N, H, W, cin, cout, taps
+    (2, 32, 32, 16, 16, 9), (1, 32, 48, 32, 32, 9), (2, 16, 16, 16, 64, 9), (1, 16, 16, 64, 128, 9),
+    (2, 24, 24, 32, 64, 9), (2, 8, 8, 64, 128, 9), (3, 12, 12, 16, 32, 9), (2, 4, 4, 128, 256, 9), (2, 2, 2, 256, 256, 9),
+    (2, 6, 6, 32, 16, 9), (2, 32, 32, 16, 4, 9), (2, 32, 32, 16, 2, 9), (2, 32, 32, 4, 16, 9), (2, 16, 16, 2, 16, 9),
+    (2, 14, 14, 256, 128, 1), (2, 16, 16, 32, 16, 1), (1, 8, 8, 64, 32, 1), (2, 28, 28, 128, 64, 1),
+]
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,taps", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad_plain(N, H, W, cin, cout, taps):
+    g = torch.Generator().manual_seed(H * 1000 + cin + cout)
+    x = torch.randn(N, H, W, cin, generator=g)
+    gz = torch.randn(N, H, W, cout, generator=g)
+    layer = AdHocConv(cin, cout, taps, DEV, seed=cin * 7 + cout)
+    xd, gzd = x.to(DEV), gz.to(DEV)
+    out, part = layer.conv(plain_act(xd, cin, H, W), None, N, H, W, stats=True)
+    xr = nchw(x).requires_grad_(True)
+    wr = layer.w.cpu().clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, layer.b.cpu(), padding=layer.k // 2)
+    e = maxerr(nchw(out.cpu()), ref.detach())
+    assert e < 2e-4 * max(1.0, float(ref.abs().max())), f"conv fwd err {e}"
+    # BN partial sums
+    nblk = L.load().hpfg_conv_stat_blocks(N, H, W)
+    ps = part.view(nblk, 2, layer.cout_pad).cpu().double().sum(0)
+    rs = ref.detach().double()
+    assert maxerr(ps[0, :cout], rs.sum((0, 2, 3))) < 1e-2 * max(1.0, float(rs.sum((0, 2, 3)).abs().max()))
+    assert maxerr(ps[1, :cout], (rs * rs).sum((0, 2, 3))) < 1e-3 * float((rs * rs).sum((0, 2, 3)).max())
+    ref.backward(nchw(gz))
+    # dgrad: conv of gz with the transposed / flipped weights
+    dx, _ = layer.conv(plain_act(gzd, cout, H, W), None, N, H, W, dgrad=True)
+    e = maxerr(nchw(dx.cpu()), xr.grad)
+    assert e < 2e-4 * max(1.0, float(xr.grad.abs().max())), f"dgrad err {e}"
+    dw = layer.wgrad(plain_act(xd, cin, H, W), None, plain_act(gzd, cout, H, W), N, H, W)
+    e = maxerr(dw.cpu(), wr.grad)
+    assert e < 3e-4 * max(1.0, float(wr.grad.abs().max())), f"wgrad err {e}"
+
+
+def _bn_table(C_, seed):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.zeros(L.BN_ROWS, C_)
+    t[L.BN_MEAN] = torch.randn(C_, generator=g) * 0.3
+    t[L.BN_RSTD] = torch.rand(C_, generator=g) + 0.5
+    gamma = torch.randn(C_, generator=g)
+    beta = torch.randn(C_, generator=g) * 0.2
+    t[L.BN_SCALE] = gamma * t[L.BN_RSTD]
+    t[L.BN_SHIFT] = beta - t[L.BN_MEAN] * t[L.BN_SCALE]
+    t[L.BN_K1], t[L.BN_K2], t[L.BN_K3] = torch.randn(3, C_, generator=g) * 0.5
+    return t
+
+
+def _materialize(a0, a1, N, H, W, Ct):
+    out = torch.full((N, H, W, Ct), float("nan"), device=DEV)
+    L.check(L.load().hpfg_act_materialize(C.byref(a0), C.byref(a1) if a1 is not None else None, N, H, W, L.ptr(out), stream(DEV)), "mat")
+    return out.cpu()
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_loader_bnact_pool_up_concat_dz(p):
+    N, H, W, C_ = 2, 12, 16, 32
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(N, H, W, C_, generator=g)
+    tab = _bn_table(C_, 5)
+    zd, tabd = z.to(DEV), tab.to(DEV)
+    seed = 12345
+    a = L.Act()
+    a.z, a.bn, a.mode, a.C, a.Hs, a.Ws, a.pstride, a.bn_stride = L.ptr(zd), L.ptr(tabd), L.ACT_BNACT, C_, H, W, C_, C_
+    a.drop_p, a.drop_seed = p, seed
+    y = F.leaky_relu(z * tab[L.BN_SCALE] + tab[L.BN_SHIFT], 0.01)
+    keep = torch.ones_like(y)
+    if p > 0:
+        keep = torch.from_numpy(rng_ref.keep_mask_nhwc(z.numel(), p, seed).astype(np.float32)).view_as(z)
+    assert maxerr(_materialize(a, None, N, H, W, C_), y * keep / (1 - p)) < 1e-5
+    # pool (no dropout on pooled sources)
+    a.mode, a.drop_p = L.ACT_BNACT_POOL, 0.0
+    ref = F.max_pool2d(nchw(y), 2)
+    assert maxerr(nchw(_materialize(a, None, N, H // 2, W // 2, C_)), ref) < 1e-5
+    # concat [bnact | up2x]
+    a.mode = L.ACT_BNACT
+    u = torch.randn(N, H // 2, W // 2, 16, generator=g)
+    ud = u.to(DEV)
+    b = L.Act()
+    b.z, b.mode, b.C, b.Hs, b.Ws, b.pstride = L.ptr(ud), L.ACT_UP2X, 16, H // 2, W // 2, 16
+    up = F.interpolate(nchw(u), scale_factor=2, mode="bilinear", align_corners=True)
+    ref = torch.cat([nchw(y), up], 1)
+    assert maxerr(nchw(_materialize(a, b, N, H, W, C_ + 16)), ref) < 1e-5
+    # dz = k1*g + k2*z + k3 with g = dA*mask/(1-p)*lrelu'
+    dA = torch.randn(N, H, W, C_ + 8, generator=g)     # wider tensor: exercises aux_pstride
+    dAd = dA.to(DEV)
+    d = L.Act()
+    d.z, d.bn, d.aux, d.mode, d.C, d.Hs, d.Ws, d.pstride, d.aux_pstride, d.bn_stride = (L.ptr(zd), L.ptr(tabd), L.ptr(dAd), L.ACT_DZ, C_, H, W, C_,
+                                                                                       C_ + 8, C_)
+    d.drop_p, d.drop_seed = p, seed
+    yv = z * tab[L.BN_SCALE] + tab[L.BN_SHIFT]
+    gg = dA[..., :C_] * keep / (1 - p) * torch.where(yv > 0, torch.ones_like(yv), torch.full_like(yv, 0.01))
+    ref = tab[L.BN_K1] * gg + tab[L.BN_K2] * z + tab[L.BN_K3]
+    assert maxerr(_materialize(d, None, N, H, W, C_), ref) < 1e-5
+    # BN backward reduction: sum g, sum g*xhat
+    lib = L.load()
+    nblk = lib.hpfg_bn_bwd_blocks(N, H, W, C_)
+    part = torch.empty(nblk * 2 * C_, device=DEV)
+    L.check(lib.hpfg_bn_bwd_reduce(C.byref(d), N, H, W, L.ptr(part), stream(DEV)), "bn_bwd_reduce")
+    ps = part.view(nblk, 2, C_).cpu().double().sum(0)
+    xh = (z - tab[L.BN_MEAN]) * tab[L.BN_RSTD]
+    assert maxerr(ps[0], gg.double().sum((0, 1, 2))) < 1e-3
+    assert maxerr(ps[1], (gg * xh).double().sum((0, 1, 2))) < 1e-3
+
+
+def test_bn_finalize_and_running_stats():
+    N, H, W, C_ = 3, 16, 16, 32
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(N, C_, H, W, generator=g) * 2 + 0.5
+    bn = torch.nn.BatchNorm2d(C_)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C_, generator=g))
+        bn.bias.copy_(torch.randn(C_, generator=g))
+    bn.train()
+    y = bn(z)
+    zz = z.permute(0, 2, 3, 1).reshape(-1, C_).double()
+    part = torch.stack([zz.sum(0), (zz * zz).sum(0)]).float().view(1, 2, C_).to(DEV)
+    tab = torch.zeros(L.BN_ROWS, C_, device=DEV)
+    rm, rv = torch.zeros(C_, device=DEV), torch.ones(C_, device=DEV)
+    L.check(L.load().hpfg_bn_fwd_finalize(L.ptr(part), 1, None, float(N * H * W), L.ptr(bn.weight.detach().to(DEV)), L.ptr(bn.bias.detach().to(DEV)),
+                                          L.ptr(rm), L.ptr(rv), 0.1, 1e-5, L.ptr(tab), C_, stream(DEV)), "fin")
+    t = tab.cpu()
+    yk = z * t[L.BN_SCALE].view(1, -1, 1, 1) + t[L.BN_SHIFT].view(1, -1, 1, 1)
+    assert maxerr(yk, y.detach()) < 1e-4
+    assert maxerr(rm.cpu(), bn.running_mean) < 1e-5 and maxerr(rv.cpu(), bn.running_var) < 1e-4
+
+
+def test_pool_scatter_and_upsample_bwd():
+    N, H, W, C_ = 2, 8, 12, 16
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(N, H, W, C_, generator=g)
+    tab = _bn_table(C_, 6)
+    y = F.leaky_relu(z * tab[L.BN_SCALE] + tab[L.BN_SHIFT], 0.01)
+    yr = nchw(y).requires_grad_(True)
+    pooled = F.max_pool2d(yr, 2)
+    dP = torch.randn(N, H // 2, W // 2, C_, generator=g)
+    pooled.backward(nchw(dP))
+    base = torch.randn(N, H, W, C_ + 16, generator=g)          # dA lives inside a wider (concat) buffer
+    zd, tabd, dPd, dAd = z.to(DEV), tab.to(DEV), dP.to(DEV), base.to(DEV)
+    a = L.Act()
+    a.z, a.bn, a.mode, a.C, a.Hs, a.Ws, a.pstride, a.bn_stride = L.ptr(zd), L.ptr(tabd), L.ACT_BNACT, C_, H, W, C_, C_
+    L.check(L.load().hpfg_pool_scatter_add(C.byref(a), L.ptr(dPd), C_, L.ptr(dAd), C_ + 16, N, H // 2, W // 2, stream(DEV)), "scatter")
+    ref = base.clone()
+    ref[..., :C_] += yr.grad.permute(0, 2, 3, 1)
+    assert maxerr(dAd.cpu(), ref) < 1e-6
+    # upsample backward
+    for (hl, wl) in [(4, 6), (1, 1), (2, 2), (7, 7)]:
+        u = torch.randn(N, 8, hl, wl, generator=g, requires_grad=True)
+        up = F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=True)
+        gcat = torch.randn(N, 2 * hl, 2 * wl, 24, generator=g)  # channels [16,24) hold dUp, pixel stride 24
+        up.backward(nchw(gcat[..., 16:]))
+        gd = gcat.to(DEV)
+        dU = torch.empty(N, hl, wl, 8, device=DEV)
+        L.check(L.load().hpfg_upsample2x_bwd(gd.view(-1)[16:].data_ptr(), 24, L.ptr(dU), N, hl, wl, 8, stream(DEV)), "upbwd")
+        assert maxerr(nchw(dU.cpu()), u.grad) < 1e-5, (hl, wl)
+
+
+def test_first_conv_and_channel_sum():
+    lib = L.load()
+    for (N, H, W, cin) in [(2, 32, 32, 1), (2, 16, 48, 3)]:
+        g = torch.Generator().manual_seed(cin)
+        x = torch.randn(N, cin, H, W, generator=g)
+        w = torch.randn(16, cin, 3, 3, generator=g) * 0.3
+        b = torch.randn(16, generator=g)
+        xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+        a = L.Act()
+        a.z, a.mode, a.C, a.Hs, a.Ws = L.ptr(xd), L.ACT_STRIDED, cin, H, W
+        a.sn, a.sc, a.sy, a.sx = xd.stride()
+        out = torch.empty(N, H, W, 16, device=DEV)
+        nblk = lib.hpfg_conv_stat_blocks(N, H, W)
+        part = torch.empty(nblk * 2 * 16, device=DEV)
+        L.check(lib.hpfg_conv3x3_first_fwd(C.byref(a), L.ptr(wd), L.ptr(bd), L.ptr(out), L.ptr(part), N, H, W, cin, 16, stream(DEV)), "first")
+        ref = F.conv2d(x, w, b, padding=1)
+        assert maxerr(nchw(out.cpu()), ref) < 1e-4
+        ps = part.view(nblk, 2, 16).cpu().double().sum(0)
+        assert maxerr(ps[0], ref.double().sum((0, 2, 3))) < 1e-2
+        cs = torch.empty(16, device=DEV)
+        scratch = torch.empty(512 * 256, device=DEV)
+        L.check(lib.hpfg_channel_sum(L.ptr(out), 16, N * H * W, 16, L.ptr(cs), L.ptr(scratch), stream(DEV)), "csum")
+        assert maxerr(cs.cpu(), ref.sum((0, 2, 3))) < 1e-2

@@ -1,0 +1,160 @@
+"""GPU parity of the whole U-Net forward / backward (HIP engine through the nn.Module) against the CPU oracle, with the oracle
+driven by exactly the dropout masks the kernels generated.  Tolerances: fp32, 1e-3 absolute on logits / losses as BASELINE.json
+states; the per-layer and gradient checks below are tighter."""
+import numpy as np
+import pytest
+import torch
+
+from hpfg_amd.datasets.synthetic import synth_batch
+from hpfg_amd.model import UNet, UNet_Plus
+from hpfg_amd.utils import Med_Sup_Loss
+from oracle import losses_ref, steps_ref, unet_ref
+from tests.helpers import engine_masks, maxerr, nchw, state_from_module
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+CASES = [(2, 32, 1, 4, 1), (3, 48, 3, 2, 1337), (2, 64, 1, 4, 5)]
+
+
+def _engine(m):
+    return next(iter(m._engines.values()))[0]
+
+
+@pytest.mark.parametrize("n,hw,in_ch,ncls,seed", CASES)
+def test_forward_train_every_layer(n, hw, in_ch, ncls, seed):
+    torch.manual_seed(seed)
+    m = UNet(in_ch, ncls).to(DEV)
+    m.train()
+    st = state_from_module(m)
+    x, _ = synth_batch(100 + seed, n, hw, hw, in_ch, ncls, cell=8)
+    with torch.no_grad():
+        out = m(x.to(DEV))
+    eng = _engine(m)
+    masks = engine_masks(eng, m._seed_counter, n, hw, hw)
+    taps = {}
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(st, x, True, masks, taps=taps)
+    errs = {k: maxerr(nchw(eng.z[k].cpu()), taps[k]) for k in eng.z}
+    bad = {k: v for k, v in errs.items() if not v < 5e-4}
+    assert not bad, f"raw conv outputs differ: {bad}\nall: {errs}"
+    assert maxerr(out.cpu(), ref) < 1e-3
+    sd = m.state_dict()
+    for k in sd:
+        if "running" in k:
+            assert maxerr(sd[k].cpu(), st[k]) < 1e-4, k
+        if "num_batches" in k:
+            assert int(sd[k]) == int(st[k]) == 1
+
+
+@pytest.mark.parametrize("n,hw,in_ch,ncls,seed", CASES[:2])
+def test_forward_eval_matches_oracle(n, hw, in_ch, ncls, seed):
+    torch.manual_seed(seed)
+    m = UNet(in_ch, ncls).to(DEV)
+    x, _ = synth_batch(7, n, hw, hw, in_ch, ncls, cell=8)
+    m.train()
+    with torch.no_grad():
+        m(x.to(DEV))            # move the running statistics away from their initial values
+    st = state_from_module(m)
+    m.eval()
+    with torch.no_grad():
+        out = m(x.to(DEV))
+        ref = unet_ref.unet_forward(st, x, train=False)
+    assert maxerr(out.cpu(), ref) < 1e-3
+
+
+@pytest.mark.parametrize("n,hw,in_ch,ncls,seed", CASES)
+def test_backward_all_parameter_gradients(n, hw, in_ch, ncls, seed):
+    torch.manual_seed(seed)
+    m = UNet(in_ch, ncls).to(DEV)
+    m.train()
+    st = state_from_module(m)
+    x, lab = synth_batch(100 + seed, n, hw, hw, in_ch, ncls, cell=8)
+    out = m(x.to(DEV))
+    loss = Med_Sup_Loss(ncls)(out, lab.to(DEV))
+    loss.backward()
+    eng = _engine(m)
+    masks = engine_masks(eng, m._seed_counter, n, hw, hw)
+    names = steps_ref._train_state(st)
+    ro = unet_ref.unet_forward(st, x, True, masks)
+    rl = losses_ref.med_sup_loss(ro, lab.long())
+    rg = steps_ref._grads(rl, st, names)
+    assert abs(float(loss) - float(rl)) < 1e-4
+    errs = {}
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        scale = max(1e-3, float(rg[k].abs().max()))
+        errs[k] = maxerr(p.grad.cpu(), rg[k]) / scale
+    bad = {k: v for k, v in errs.items() if not v < 2e-3}
+    assert not bad, f"relative gradient errors too large: {bad}"
+
+
+def _fixture_masks(d, n, hw, prefix="mask"):
+    """Bit-packed NCHW keep-masks of the five dropout sites -> {conv name: uint8 NHWC tensor on the GPU}."""
+    from hpfg_amd import engine as E
+    out = {}
+    for lvl in range(5):
+        c, h = E.WIDTHS[lvl], hw >> lvl
+        bits = np.unpackbits(d[f"{prefix}{lvl}"])[: n * c * h * h].reshape(n, c, h, h)
+        out[E.enc_prefix(lvl) + ".0"] = torch.from_numpy(bits).permute(0, 2, 3, 1).contiguous().to(DEV)
+    return out
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_golden_fixture_forward_backward(golden_dir, tag):
+    """HIP path vs the REFERENCE's own outputs (tests/golden/unet_fwd_bwd_*.npz written by oracle/make_golden.py from
+    /root/reference/model/unet.py + utils/loss/medloss.py): same seed-initialised weights, same inputs, and the dropout masks
+    torch drew in the reference run replayed through HpfgAct.drop_mask."""
+    d = np.load(f"{golden_dir}/unet_fwd_bwd_{tag}.npz")
+    n, hw, in_ch, ncls, seed, _ = [int(v) for v in d["meta"]]
+    torch.manual_seed(seed)
+    m = UNet(in_ch, ncls).to(DEV)
+    m.train()
+    m.external_dropout_masks = _fixture_masks(d, n, hw)
+    x = torch.from_numpy(d["x"]).to(DEV)
+    lab = torch.from_numpy(d["labels"]).to(DEV)
+    out = m(x)
+    loss = Med_Sup_Loss(ncls)(out, lab)
+    loss.backward()
+    assert maxerr(out.detach().cpu(), torch.from_numpy(d["logits"])) < 1e-3
+    assert abs(float(loss) - float(d["loss"])) < 1e-4
+    eng = _engine(m)
+    for k in d.files:
+        if k.startswith("raw/"):
+            assert maxerr(nchw(eng.z[k[4:]].cpu()), torch.from_numpy(d[k])) < 5e-4, k
+        if k.startswith("bn/"):
+            assert maxerr(m.state_dict()[k[3:]].cpu(), torch.from_numpy(d[k])) < 1e-4, k
+    grads = dict(m.named_parameters())
+    for k in d.files:
+        if k.startswith("grad/"):
+            ref = torch.from_numpy(d[k])
+            assert maxerr(grads[k[5:]].grad.cpu(), ref) < 2e-3 * max(1e-3, float(ref.abs().max())), k
+        if k.startswith("grad_sum/"):
+            g = grads[k[9:]].grad.double().cpu()
+            ref = d[k]
+            assert abs(float(g.abs().sum()) - ref[1]) < 2e-3 * max(1e-3, ref[1]) + 1e-6, k
+
+
+def test_unet_plus_heads_and_backbone_grad():
+    torch.manual_seed(1)
+    m = UNet_Plus(1, 4).to(DEV)
+    m.train()
+    st = state_from_module(m)
+    x, lab = synth_batch(3, 2, 64, 64, 1, 4, cell=8)
+    out, (g1, d1), (g2, d2) = m(x.to(DEV))
+    loss = Med_Sup_Loss(4)(out, lab.to(DEV)) + 0.1 * (g1.square().mean() + d1.square().mean() + g2.square().mean() + d2.square().mean())
+    loss.backward()
+    masks = engine_masks(_engine(m), m._seed_counter, 2, 64, 64)
+    names = steps_ref._train_state(st)
+    ro, (rg1, rd1), (rg2, rd2) = unet_ref.unet_forward(st, x, True, masks, plus=True)
+    rl = losses_ref.med_sup_loss(ro, lab.long()) + 0.1 * (rg1.square().mean() + rd1.square().mean() + rg2.square().mean() + rd2.square().mean())
+    rg = steps_ref._grads(rl, st, names)
+    assert maxerr(g1.detach().cpu(), rg1.detach()) < 1e-3 and maxerr(d2.detach().cpu(), rd2.detach()) < 1e-3
+    assert abs(float(loss) - float(rl)) < 1e-4
+    bad = {}
+    for k, p in m.named_parameters():
+        scale = max(1e-3, float(rg[k].abs().max()))
+        e = maxerr(p.grad.cpu(), rg[k]) / scale
+        if not e < 2e-3:
+            bad[k] = e
+    assert not bad, bad
