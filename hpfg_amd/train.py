@@ -1,0 +1,424 @@
+"""Per-iteration step laws of the reference's drivers, composed from the HIP path.
+
+  SupervisedStep    sup_ACDC.py:83-93            (Supervise)
+  MeanTeacherStep   2017_03_NIPS_Mean-Teacher_ACDC.py:82-113   (Mean_Teacher)
+  CPSStep           2021_06_CVPR_CPS_ACDC.py:83-120            (CPS)
+  HPFGStep          main.py:125-212              (HPFG, incl. update_ema_variables_backbone main.py:68-76)
+
+Each step object owns the optimizer(s) / scheduler(s) built by the reference-compatible factories and exposes
+``step(batch..., cur_itrs) -> dict of device scalars``.  Nothing in a step synchronises with the host: losses stay on the
+device (the reference's ``loss.item()`` / per-class ``dice.item()`` calls have no counterpart); per-step scalars (learning rates,
+consistency weight, EMA alpha) are staged through one pinned buffer and read by the kernels from device memory, so a whole
+step can be captured into a hipGraph (``GraphedStep``).
+
+The driver loops at the bottom keep the reference's function names and signatures.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from copy import deepcopy
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .utils import (BoxMaskGenerator, build_lr_scheduler, build_optimizer, ema_alpha, linear_rampup, seg_loss, sigmoid_rampup,
+                    update_ema_variables, update_ema_variables_backbone)
+from .utils.loss import _nhwc
+
+# layout of the per-step scalar block (device fp32 [32])
+S_LR1, S_LR2, S_ALPHA, S_COEF_A, S_COEF_B = 0, 1, 2, 8, 16
+
+
+class StepScalars:
+    """Host-computed per-iteration scalars -> device, one async copy per step (pinned source, graph-capturable)."""
+
+    def __init__(self, dev):
+        self.host = torch.zeros(32, dtype=torch.float32).pin_memory()
+        self.dev = torch.zeros(32, dtype=torch.float32, device=dev)
+
+    def push(self):
+        self.dev.copy_(self.host, non_blocking=True)
+
+    def view(self, off, n=1):
+        return self.dev[off:off + n]
+
+
+def argmax_labels(logits: torch.Tensor, mix_labels: Optional[torch.Tensor] = None, mix_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uint8 [N,H,W] arg-max over classes of logits [N,C,H,W]; with (mix_labels, mix_mask): labels*(1-M) + argmax*M."""
+    x = _nhwc(logits.detach())
+    N, H, W, Cc = x.shape
+    out = torch.empty(N, H, W, dtype=torch.uint8, device=x.device)
+    ml = mix_labels.contiguous() if mix_labels is not None else None
+    mm = mix_mask.contiguous().float() if mix_mask is not None else None
+    L.check(L.load().hpfg_argmax_labels(L.ptr(x), N, H, W, Cc, L.ptr(ml), L.ptr(mm), L.ptr(out), torch.cuda.current_stream(x.device).cuda_stream),
+            "argmax_labels")
+    return out
+
+
+def cutmix_blend(a: torch.Tensor, b: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """a*(1-M) + b*M elementwise (main.py:149); mask broadcast over channels is materialised by the caller if C > 1."""
+    a, b = a.contiguous(), b.contiguous()
+    m = mask.expand_as(a).contiguous()
+    out = torch.empty_like(a)
+    L.check(L.load().hpfg_cutmix_blend(L.ptr(a), L.ptr(b), L.ptr(m), L.ptr(out), a.numel(), torch.cuda.current_stream(a.device).cuda_stream),
+            "cutmix_blend")
+    return out
+
+
+class _StepBase:
+    def __init__(self, dev, dp=None):
+        self.dev, self.dp = dev, dp
+        self.sc = StepScalars(dev)
+
+    def _attach(self, model):
+        model.dp = self.dp
+
+    def _reduce_grads(self, *models):
+        if self.dp is not None and self.dp.world_size > 1:
+            for m in models:
+                self.dp.allreduce_sum(m.flat_grads)
+
+    @staticmethod
+    def _lr(opt):
+        return float(opt.param_groups[0]["lr"])
+
+
+class SupervisedStep(_StepBase):
+    def __init__(self, model, args, dp=None):
+        super().__init__(next(model.parameters()).device, dp)
+        self.model, self.args = model, args
+        self._attach(model)
+        self.optimizer = build_optimizer(args=args, model=model)
+        self.lr_scheduler = build_lr_scheduler(args=args, optimizer=self.optimizer)
+        self.optimizer._lr_dev = self.sc.view(S_LR1)
+        self.sc.host[S_COEF_A:S_COEF_A + 2] = torch.tensor([0.5, 0.5])
+
+    def host_scalars(self, cur_itrs):
+        self.sc.host[S_LR1] = self._lr(self.optimizer)
+
+    def device_step(self, img, label):
+        out = self.model(img)
+        res = seg_loss(out, label, coef=self.sc.view(S_COEF_A, 8), dp=self.dp)
+        self.optimizer.zero_grad()
+        res[0].backward()
+        self._reduce_grads(self.model)
+        self.optimizer.step(push_lr=False)
+        return {"loss": res[0].detach(), "logits": out.detach(), "parts": res.detach()}
+
+    def after(self):
+        self.lr_scheduler.step()
+
+    def step(self, img, label, cur_itrs):
+        self.host_scalars(cur_itrs)
+        self.sc.push()
+        r = self.device_step(img, label)
+        self.after()
+        return r
+
+
+class MeanTeacherStep(_StepBase):
+    def __init__(self, model, ema_model, args, dp=None):
+        super().__init__(next(model.parameters()).device, dp)
+        self.model, self.ema_model, self.args = model, ema_model, args
+        self._attach(model)
+        self._attach(ema_model)
+        self.optimizer = build_optimizer(args=args, model=model)
+        self.lr_scheduler = build_lr_scheduler(args=args, optimizer=self.optimizer)
+        self.optimizer._lr_dev = self.sc.view(S_LR1)
+
+    def host_scalars(self, cur_itrs, cons_w=None):
+        a = self.args
+        w = a.consistency * sigmoid_rampup(cur_itrs // 150, a.consistency_rampup) if cons_w is None else cons_w
+        h = self.sc.host
+        h[S_LR1] = self._lr(self.optimizer)
+        h[S_ALPHA] = ema_alpha(cur_itrs, a.ema_decay)
+        h[S_COEF_A:S_COEF_A + 5] = torch.tensor([0.5, 0.5, 0.0, 0.0, w])
+        return w
+
+    def device_step(self, label_img, target_label, unlabel_img):
+        nl = label_img.shape[0]
+        x = torch.cat([label_img, unlabel_img], 0)
+        out = self.model(x)
+        with torch.no_grad():
+            t_out = self.ema_model(x)
+        res = seg_loss(out, target_label, nl, coef=self.sc.view(S_COEF_A, 8), teacher_logits=t_out, dp=self.dp)
+        self.optimizer.zero_grad()
+        res[0].backward()
+        self._reduce_grads(self.model)
+        self.optimizer.step(push_lr=False)
+        update_ema_variables(self.model, self.ema_model, self.args.ema_decay, 0, alpha_dev=self.sc.view(S_ALPHA))
+        return {"loss": res[0].detach(), "parts": res.detach(), "logits": out.detach(), "t_logits": t_out}
+
+    def after(self):
+        self.lr_scheduler.step()
+
+    def step(self, label_img, target_label, unlabel_img, cur_itrs, cons_w=None):
+        self.host_scalars(cur_itrs, cons_w)
+        self.sc.push()
+        r = self.device_step(label_img, target_label, unlabel_img)
+        self.after()
+        return r
+
+
+class CPSStep(_StepBase):
+    def __init__(self, model1, model2, args, dp=None):
+        super().__init__(next(model1.parameters()).device, dp)
+        self.model1, self.model2, self.args = model1, model2, args
+        self._attach(model1)
+        self._attach(model2)
+        self.optimizer1 = build_optimizer(args=args.model1, model=model1)
+        self.optimizer2 = build_optimizer(args=args.model2, model=model2)
+        self.lr_scheduler1 = build_lr_scheduler(args=args.model1, optimizer=self.optimizer1)
+        self.lr_scheduler2 = build_lr_scheduler(args=args.model2, optimizer=self.optimizer2)
+        self.optimizer1._lr_dev = self.sc.view(S_LR1)
+        self.optimizer2._lr_dev = self.sc.view(S_LR2)
+
+    def host_scalars(self, cur_itrs, cons_w=None):
+        a = self.args
+        w = a.consistency * sigmoid_rampup(cur_itrs // 150, a.consistency_rampup) if cons_w is None else cons_w
+        h = self.sc.host
+        h[S_LR1], h[S_LR2] = self._lr(self.optimizer1), self._lr(self.optimizer2)
+        h[S_COEF_A:S_COEF_A + 5] = torch.tensor([0.5, 0.5, 0.5 * w, 0.5 * w, 0.0])
+        return w
+
+    def device_step(self, label_img, target_label, unlabel_img):
+        nl = label_img.shape[0]
+        x = torch.cat([label_img, unlabel_img], 0)
+        o1 = self.model1(x)
+        o2 = self.model2(x)
+        p1 = argmax_labels(o1[nl:])
+        p2 = argmax_labels(o2[nl:])
+        coef = self.sc.view(S_COEF_A, 8)
+        r1 = seg_loss(o1, target_label, nl, coef=coef, pseudo=p2, dp=self.dp)
+        r2 = seg_loss(o2, target_label, nl, coef=coef, pseudo=p1, dp=self.dp)
+        loss = r1[0] + r2[0]
+        self.optimizer1.zero_grad()
+        self.optimizer2.zero_grad()
+        loss.backward()
+        self._reduce_grads(self.model1, self.model2)
+        self.optimizer1.step(push_lr=False)
+        self.optimizer2.step(push_lr=False)
+        return {"loss": loss.detach(), "parts1": r1.detach(), "parts2": r2.detach(), "logits1": o1.detach(), "logits2": o2.detach()}
+
+    def after(self):
+        self.lr_scheduler1.step()
+        self.lr_scheduler2.step()
+
+    def step(self, label_img, target_label, unlabel_img, cur_itrs, cons_w=None):
+        self.host_scalars(cur_itrs, cons_w)
+        self.sc.push()
+        r = self.device_step(label_img, target_label, unlabel_img)
+        self.after()
+        return r
+
+
+class HPFGStep(_StepBase):
+    def __init__(self, model1, model2, ema_model, args, dp=None):
+        from .utils import Dense_Loss
+        super().__init__(next(model1.parameters()).device, dp)
+        self.model1, self.model2, self.ema_model, self.args = model1, model2, ema_model, args
+        for m in (model1, model2, ema_model):
+            self._attach(m)
+        self.optimizer1 = build_optimizer(args=args.model1, model=model1)
+        self.optimizer2 = build_optimizer(args=args.model2, model=model2)
+        self.lr_scheduler1 = build_lr_scheduler(args=args.model1, optimizer=self.optimizer1)
+        self.lr_scheduler2 = build_lr_scheduler(args=args.model2, optimizer=self.optimizer2)
+        self.optimizer1._lr_dev = self.sc.view(S_LR1)
+        self.optimizer2._lr_dev = self.sc.view(S_LR2)
+        self.dense_loss = Dense_Loss(args.batch_size + args.unlabel_batch_size, self.dev)
+        self.mask_generator = BoxMaskGenerator(prop_range=(0.25, 0.5), n_boxes=4, random_aspect_ratio=True, prop_by_area=True,
+                                               within_bounds=True, invert=True)          # main.py:94-115
+        self._w = 0.0
+
+    def host_scalars(self, cur_itrs):
+        a = self.args
+        w = a.consistency * linear_rampup(cur_itrs // 150, a.consistency_rampup)
+        h = self.sc.host
+        h[S_LR1], h[S_LR2] = self._lr(self.optimizer1), self._lr(self.optimizer2)
+        h[S_ALPHA] = ema_alpha(cur_itrs, a.ema_decay)
+        h[S_COEF_A:S_COEF_A + 5] = torch.tensor([0.5, 0.5, 0.0, 7.0 * w, 0.0])                 # model1: sup + 7w * pseudo Dice
+        h[S_COEF_B:S_COEF_B + 5] = torch.tensor([0.5, 0.5, 0.0, 0.0, 0.0 if cur_itrs < 1000 else w])   # model2: sup + w * MSE
+        h[3] = w
+        self._w = w
+        return w
+
+    def make_cutmix_mask(self, n, shape, rng=None):
+        m = self.mask_generator.generate_params(n_masks=n, mask_shape=shape, rng=rng)
+        return torch.tensor(m, dtype=torch.float)
+
+    def device_step(self, label_img, target_label, label_img1, target_label1, img_unlabel, cutmix_mask):
+        """label_img1/target_label1 are already repeated to the unlabelled batch size (main.py:142-143)."""
+        nl = label_img.shape[0]
+        mix_un = cutmix_blend(label_img1, img_unlabel, cutmix_mask)
+        batch_mix = torch.cat([label_img, mix_un], 0)
+        o1, _, _ = self.model1(batch_mix)
+        volume = torch.cat([label_img, img_unlabel], 0)
+        o2, h1, h2 = self.model2(volume)
+        with torch.no_grad():
+            ot, th1, th2 = self.ema_model(volume)
+        pseudo = argmax_labels(ot[nl:], target_label1, cutmix_mask[:, 0])
+        r1 = seg_loss(o1, target_label, nl, coef=self.sc.view(S_COEF_A, 8), pseudo=pseudo, dp=self.dp)
+        r2 = seg_loss(o2, target_label, nl, coef=self.sc.view(S_COEF_B, 8), teacher_logits=ot, dp=self.dp)
+        contrast = self.dense_loss(h1, th1) + self.dense_loss(h2, th2)
+        loss = r1[0] + r2[0] + self.sc.view(3)[0] * contrast
+        self.optimizer1.zero_grad()
+        self.optimizer2.zero_grad()
+        loss.backward()
+        self._reduce_grads(self.model1, self.model2)
+        self.optimizer1.step(push_lr=False)
+        self.optimizer2.step(push_lr=False)
+        a = self.sc.view(S_ALPHA)
+        update_ema_variables_backbone(self.model1, self.model2, self.args.ema_decay, 0, alpha_dev=a)
+        update_ema_variables(self.model2, self.ema_model, self.args.ema_decay, 0, alpha_dev=a)
+        return {"loss": loss.detach(), "parts1": r1.detach(), "parts2": r2.detach(), "contrast": contrast.detach(),
+                "logits1": o1.detach(), "logits2": o2.detach(), "t_logits": ot}
+
+    def after(self):
+        self.lr_scheduler1.step()
+        self.lr_scheduler2.step()
+
+    def step(self, label_img, target_label, label_img1, target_label1, img_unlabel, cutmix_mask, cur_itrs):
+        self.host_scalars(cur_itrs)
+        self.sc.push()
+        r = self.device_step(label_img, target_label, label_img1, target_label1, img_unlabel, cutmix_mask)
+        self.after()
+        return r
+
+
+class GraphedStep:
+    """Captures ``step_obj.device_step`` on static input buffers into one hipGraph (torch.cuda.CUDAGraph) and replays it.
+    Host scalars keep flowing through the pinned block (the captured copy node re-reads it at every replay); dropout masks
+    change per replay through the engines' device seed word."""
+
+    def __init__(self, step_obj, example_inputs, warmup: int = 3):
+        self.s = step_obj
+        self.static = [t.clone() for t in example_inputs]
+        self.graph = torch.cuda.CUDAGraph()
+        self._seed_words = []
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(warmup):
+                self.s.host_scalars(i + 1)
+                self.s.sc.push()
+                self.s.device_step(*self.static)
+                self.s.after()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._freeze_seed_updates(True)
+        with torch.cuda.graph(self.graph):
+            self.s.sc.push()
+            self.out = self.s.device_step(*self.static)
+        self._freeze_seed_updates(False)
+
+    def _models(self):
+        return [getattr(self.s, n) for n in ("model", "model1", "model2", "ema_model") if hasattr(self.s, n)]
+
+    def _freeze_seed_updates(self, capturing: bool):
+        for m in self._models():
+            m._graph_seed_mode = capturing
+
+    def step(self, inputs, cur_itrs, **kw):
+        for dst, src in zip(self.static, inputs):
+            dst.copy_(src, non_blocking=True)
+        self.s.host_scalars(cur_itrs, **kw)
+        for m in self._models():
+            m.bump_graph_seed()
+        self.graph.replay()
+        self.s.after()
+        return self.out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Driver loops with the reference's names / signatures (logging and checkpointing kept minimal; evaluation via hpfg_amd.val)
+# ------------------------------------------------------------------------------------------------------------------------
+def _cycle(loader):
+    it = iter(loader)
+    while True:
+        try:
+            yield next(it)
+        except StopIteration:
+            it = iter(loader)
+            yield next(it)
+
+
+def Supervise(model, train_loader, test_loader, args):
+    st = SupervisedStep(model, args, getattr(args, "dp", None))
+    model.train()
+    cur_itrs, log = 0, []
+    max_epoch = args.total_itrs // len(train_loader) + 1
+    for epoch in range(max_epoch):
+        for img, label_true in train_loader:
+            cur_itrs += 1
+            r = st.step(img.to(args.device).float(), label_true.to(args.device), cur_itrs)
+            log.append(r["loss"])
+            if cur_itrs % args.step_size == 0 and test_loader is not None:
+                from .val import test_acdc
+                dice, _ = test_acdc(model=model, test_loader=test_loader, args=args, cur_itrs=cur_itrs)
+                args.logger.info("dice: {:.4f}".format(dice))
+                model.train()
+            if cur_itrs >= args.total_itrs:
+                return torch.stack(log)
+    return torch.stack(log)
+
+
+def Mean_Teacher(model, ema_model, label_loader, unlabel_loader, test_loader, args):
+    st = MeanTeacherStep(model, ema_model, args, getattr(args, "dp", None))
+    model.train()
+    ema_model.train()          # the teacher stays in train mode (2017_03...py:70)
+    cur_itrs, log = 0, []
+    labels = _cycle(label_loader)
+    max_epoch = args.total_itrs // len(unlabel_loader) + 1
+    for epoch in range(max_epoch):
+        for unlabel_img, _ in unlabel_loader:
+            cur_itrs += 1
+            label_img, target_label = next(labels)
+            r = st.step(label_img.to(args.device).float(), target_label.to(args.device), unlabel_img.to(args.device).float(), cur_itrs)
+            log.append(r["loss"])
+            if cur_itrs >= args.total_itrs:
+                return torch.stack(log)
+    return torch.stack(log)
+
+
+def CPS(model1, model2, label_loader, unlabel_loader, test_loader, args):
+    st = CPSStep(model1, model2, args, getattr(args, "dp", None))
+    model1.train()
+    model2.train()
+    cur_itrs, log = 0, []
+    labels = _cycle(label_loader)
+    max_epoch = args.total_itrs // len(unlabel_loader) + 1
+    for epoch in range(max_epoch):
+        for unlabel_img, _ in unlabel_loader:
+            cur_itrs += 1
+            label_img, target_label = next(labels)
+            r = st.step(label_img.to(args.device).float(), target_label.to(args.device), unlabel_img.to(args.device).float(), cur_itrs)
+            log.append(r["loss"])
+            if cur_itrs >= args.total_itrs:
+                return torch.stack(log)
+    return torch.stack(log)
+
+
+def HPFG(model1, model2, ema_model, label_loader, unlabel_loader, test_loader, args):
+    st = HPFGStep(model1, model2, ema_model, args, getattr(args, "dp", None))
+    model1.train()
+    model2.train()
+    cur_itrs, log = 0, []
+    it_a, it_b = _cycle(label_loader), _cycle(label_loader)      # two independent labelled iterators (main.py:119-120)
+    max_epoch = args.total_itrs // len(unlabel_loader) + 1
+    for epoch in range(max_epoch):
+        for img_unlabel, _ in unlabel_loader:
+            cur_itrs += 1
+            label_img, target_label = next(it_a)
+            label_img1, target_label1 = next(it_b)
+            nl, nu = label_img.shape[0], img_unlabel.shape[0]
+            rep = nu // nl
+            cm = st.make_cutmix_mask(nu, (args.train_crop_size[0], args.train_crop_size[1]))
+            r = st.step(label_img.to(args.device).float(), target_label.to(args.device),
+                        label_img1.repeat(rep, 1, 1, 1).to(args.device).float(), target_label1.repeat(rep, 1, 1).to(args.device),
+                        img_unlabel.to(args.device).float(), cm.to(args.device), cur_itrs)
+            log.append(r["loss"])
+            if cur_itrs >= args.total_itrs:
+                return torch.stack(log)
+    return torch.stack(log)

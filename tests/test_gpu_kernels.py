@@ -43,7 +43,7 @@ def test_conv_fwd_dgrad_wgrad_plain(N, H, W, cin, cout, taps):
     wr = layer.w.cpu().clone().requires_grad_(True)
     ref = F.conv2d(xr, wr, layer.b.cpu(), padding=layer.k // 2)
     e = maxerr(nchw(out.cpu()), ref.detach())
-    assert e < 2e-4 * max(1.0, float(ref.abs().max())), f"conv fwd err {e}"
+    assert e < 2e-4 * max(1.0, float(ref.detach().abs().max())), f"conv fwd err {e}"
     # BN partial sums
     nblk = L.load().hpfg_conv_stat_blocks(N, H, W)
     ps = part.view(nblk, 2, layer.cout_pad).cpu().double().sum(0)
@@ -144,7 +144,8 @@ def test_bn_finalize_and_running_stats():
     part = torch.stack([zz.sum(0), (zz * zz).sum(0)]).float().view(1, 2, C_).to(DEV)
     tab = torch.zeros(L.BN_ROWS, C_, device=DEV)
     rm, rv = torch.zeros(C_, device=DEV), torch.ones(C_, device=DEV)
-    L.check(L.load().hpfg_bn_fwd_finalize(L.ptr(part), 1, None, float(N * H * W), L.ptr(bn.weight.detach().to(DEV)), L.ptr(bn.bias.detach().to(DEV)),
+    gam, bet = bn.weight.detach().to(DEV), bn.bias.detach().to(DEV)     # keep alive: the call only enqueues work
+    L.check(L.load().hpfg_bn_fwd_finalize(L.ptr(part), 1, None, float(N * H * W), L.ptr(gam), L.ptr(bet),
                                           L.ptr(rm), L.ptr(rv), 0.1, 1e-5, L.ptr(tab), C_, stream(DEV)), "fin")
     t = tab.cpu()
     yk = z * t[L.BN_SCALE].view(1, -1, 1, 1) + t[L.BN_SHIFT].view(1, -1, 1, 1)
