@@ -210,9 +210,18 @@ class UNet(nn.Module):
         self._flat_grad.zero_()
 
     # ---- engines ----------------------------------------------------------------------------------------------
-    def _next_seed(self) -> int:
+    def _next_seed(self):
+        """Per-forward dropout seed word.  While a step is being captured into a hipGraph the engines keep their device seed
+        word untouched (None): GraphedStep bumps it on the device before every replay instead."""
+        if getattr(self, "_graph_seed_mode", False):
+            return None
         self._seed_counter += 1
         return self._seed_counter
+
+    def bump_graph_seed(self):
+        for pool in self._engines.values():
+            for e in pool:
+                e.seed_dev.add_(1)
 
     def _acquire_engine(self, x: torch.Tensor) -> E.UNetEngine:
         if not x.is_cuda:

@@ -1,0 +1,67 @@
+"""Data parallelism for the hot path: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
+
+The reference is single-process / single-device (main.py:44 says so); sharding is new functionality whose contract is
+"R ranks on per-rank batches == one process on the concatenated global batch".  Three exchanges make that exact:
+  1. BatchNorm statistics: every BN layer's [sum z, sum z^2] (forward) and [sum g, sum g*xhat] (backward), 2*C fp64 values,
+     all-reduced between the partial-sum kernel and the finalize kernel (engine.py) -- train-mode teacher included;
+  2. loss sums: the CE/Dice/MSE partial sums (32 floats) all-reduced before the scalar finalize (utils/loss.py);
+  3. gradients: ONE all-reduce (SUM, the loss is already normalised by the global counts) of the flat fp32 gradient buffer
+     per trainable model (7.26 MB U-Net / 14.65 MB U-Net+), issued right after backward.
+EMA, SGD and the LR/ramp-up scalars stay per rank (parameters are bit-identical after the reduced step).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallelContext:
+    def __init__(self, group=None, device: Optional[torch.device] = None):
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = device
+
+    def allreduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world_size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def barrier(self):
+        if self.device is not None and self.device.type == "cuda":
+            dist.barrier(group=self.group, device_ids=[self.device.index])
+        else:
+            dist.barrier(group=self.group)
+
+    def max_float(self, v: float) -> float:
+        t = torch.tensor([v], dtype=torch.float64, device=self.device if self.device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def shutdown(self):
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def init_from_env(device: torch.device, backend: Optional[str] = None) -> DataParallelContext:
+    """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from torch.distributed.run."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = backend or ("nccl" if device.type == "cuda" else "gloo")
+    if not dist.is_initialized():
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = device
+        dist.init_process_group(backend=backend, **kw)
+    return DataParallelContext(None, device)
+
+
+def shard_batch(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Rank r's contiguous share of a global batch (parity runs split one global batch R ways)."""
+    n = t.shape[0]
+    assert n % world == 0, f"global batch {n} not divisible by world size {world}"
+    k = n // world
+    return t[rank * k:(rank + 1) * k]

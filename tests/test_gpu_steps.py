@@ -1,0 +1,135 @@
+"""GPU parity of the step laws (supervised, Mean-Teacher, CPS, HPFG) against loss traces produced by the REFERENCE's own
+modules (tests/golden/trace_*.npz, written by oracle/make_golden.py): same seeds, inputs, schedulers, and the dropout masks of
+the reference run replayed through HpfgAct.drop_mask.  Tolerance 1e-3 on losses / logits (BASELINE.json north_star)."""
+from copy import deepcopy
+
+import numpy as np
+import pytest
+import torch
+
+from hpfg_amd import engine as E
+from hpfg_amd.model import UNet, UNet_Plus
+from hpfg_amd.train import CPSStep, HPFGStep, MeanTeacherStep, SupervisedStep
+from hpfg_amd.utils import AttrDict
+from oracle import losses_ref
+from tests.helpers import maxerr
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+TOL = 1e-3
+
+
+def _masks(d, key, n, hw):
+    out = {}
+    for lvl in range(5):
+        c, h = E.WIDTHS[lvl], hw >> lvl
+        bits = np.unpackbits(d[f"{key}{lvl}"])[: n * c * h * h].reshape(n, c, h, h)
+        out[E.enc_prefix(lvl) + ".0"] = torch.from_numpy(bits).permute(0, 2, 3, 1).contiguous().to(DEV)
+    return out
+
+
+def _opt_args(**kw):
+    base = dict(opt="sgd", lr=0.01, momentum=0.9, weight_decay=1e-4, sched="medical", total_itrs=30000, step_size=200, warmup_epochs=0,
+                warmup_lr=1e-4, min_lr=1e-6, consistency=0.1, consistency_rampup=200.0, ema_decay=0.99)
+    base.update(kw)
+    return AttrDict(base)
+
+
+def test_supervised_trace(golden_dir):
+    d = np.load(f"{golden_dir}/trace_sup.npz")
+    torch.manual_seed(1)
+    m = UNet(1, 4).to(DEV)
+    m.train()
+    st = SupervisedStep(m, _opt_args(weight_decay=5e-4, sched="cosine"))
+    x, lab = torch.from_numpy(d["x"]).to(DEV), torch.from_numpy(d["labels"]).to(DEV)
+    losses = []
+    for k in range(4):
+        m.external_dropout_masks = _masks(d, f"it{k}_mask", 4, 32)
+        losses.append(st.step(x, lab, k + 1)["loss"])
+    losses = torch.stack(losses).cpu().numpy()
+    assert np.abs(losses - d["losses"]).max() < TOL, (losses, d["losses"])
+    m.eval()
+    with torch.no_grad():
+        fin = m(x).cpu()
+    assert maxerr(fin, torch.from_numpy(d["final_eval_logits"])) < TOL
+    dice = losses_ref.mean_foreground_dice(fin.argmax(1).numpy(), d["labels"], 4)
+    assert abs(dice - float(d["final_dice"])) < TOL
+
+
+def test_mean_teacher_trace(golden_dir):
+    d = np.load(f"{golden_dir}/trace_mt.npz")
+    torch.manual_seed(1337)
+    m = UNet(1, 4).to(DEV)
+    ema = deepcopy(m)
+    for p in ema.parameters():
+        p.requires_grad = False
+    m.train()
+    ema.train()
+    st = MeanTeacherStep(m, ema, _opt_args())
+    xl, yl, xu = (torch.from_numpy(d[k]).to(DEV) for k in ("xl", "yl", "xu"))
+    rows = []
+    for k in range(3):
+        m.external_dropout_masks = _masks(d, f"it{k}_s", 4, 32)
+        ema.external_dropout_masks = _masks(d, f"it{k}_t", 4, 32)
+        r = st.step(xl, yl, xu, k + 1, cons_w=float(d["cons_w"]))
+        p = r["parts"].cpu()
+        rows.append([float(r["loss"]), 0.5 * float(p[1]) + 0.5 * float(p[2]), float(p[5])])
+    assert np.abs(np.array(rows) - d["losses"]).max() < TOL, (rows, d["losses"])
+    assert maxerr(r["logits"].cpu(), torch.from_numpy(d["student_logits_last"])) < TOL
+    assert maxerr(r["t_logits"].cpu(), torch.from_numpy(d["teacher_logits_last"])) < TOL
+
+
+def test_cps_trace(golden_dir):
+    d = np.load(f"{golden_dir}/trace_cps.npz")
+    torch.manual_seed(1337)
+    m1 = UNet(3, 2).to(DEV)
+    m2 = UNet(3, 2).to(DEV)
+    m1.train()
+    m2.train()
+    args = _opt_args()
+    args.model1, args.model2 = _opt_args(), _opt_args()
+    st = CPSStep(m1, m2, args)
+    xl, yl, xu = (torch.from_numpy(d[k]).to(DEV) for k in ("xl", "yl", "xu"))
+    rows = []
+    for k in range(2):
+        m1.external_dropout_masks = _masks(d, f"it{k}_a", 4, 48)
+        m2.external_dropout_masks = _masks(d, f"it{k}_b", 4, 48)
+        r = st.step(xl, yl, xu, k + 1, cons_w=float(d["cons_w"]))
+        rows.append(float(r["loss"]))
+    assert np.abs(np.array(rows) - d["losses"][:, 0]).max() < TOL, (rows, d["losses"])
+    assert maxerr(r["logits1"].cpu(), torch.from_numpy(d["logits1_last"])) < TOL
+    assert maxerr(r["logits2"].cpu(), torch.from_numpy(d["logits2_last"])) < TOL
+
+
+def test_hpfg_trace(golden_dir):
+    d = np.load(f"{golden_dir}/trace_hpfg.npz")
+    torch.manual_seed(1)
+    m1 = UNet_Plus(1, 4).to(DEV)
+    m2 = UNet_Plus(1, 4).to(DEV)
+    ema = deepcopy(m2)
+    for p in ema.parameters():
+        p.requires_grad = False
+    m1.train()
+    m2.train()
+    args = _opt_args(batch_size=2, unlabel_batch_size=2)
+    args.model1 = _opt_args(weight_decay=5e-4)
+    args.model2 = _opt_args(weight_decay=5e-4)
+    st = HPFGStep(m1, m2, ema, args)
+    # the fixture was produced with a constant lr of 0.01 (no scheduler stepping): pin the schedulers' effect
+    xl, yl, xl1, yl1, xu = (torch.from_numpy(d[k]).to(DEV) for k in ("xl", "yl", "xl1", "yl1", "xu"))
+    rows = []
+    for j, cur in enumerate(d["cur_itrs"]):
+        for o in (st.optimizer1, st.optimizer2):
+            o.param_groups[0]["lr"] = 0.01
+        m1.external_dropout_masks = _masks(d, f"it{j}_a", 4, 64)
+        m2.external_dropout_masks = _masks(d, f"it{j}_b", 4, 64)
+        ema.external_dropout_masks = _masks(d, f"it{j}_t", 4, 64)
+        cm = torch.from_numpy(d["cutmix"][j]).to(DEV)
+        r = st.step(xl, yl, xl1, yl1, xu, cm, int(cur))
+        rows.append([float(r["loss"]), float(r["contrast"])])
+    ref = d["losses"]
+    assert np.abs(np.array(rows)[:, 0] - ref[:, 0]).max() < TOL, (rows, ref)
+    assert np.abs(np.array(rows)[:, 1] - ref[:, 4]).max() < TOL, (rows, ref)
+    assert maxerr(r["logits1"].cpu(), torch.from_numpy(d["logits1_last"])) < TOL
+    assert maxerr(r["logits2"].cpu(), torch.from_numpy(d["logits2_last"])) < TOL
+    assert maxerr(r["t_logits"].cpu(), torch.from_numpy(d["t_logits_last"])) < TOL
