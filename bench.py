@@ -183,7 +183,11 @@ def cpu_baseline(n_lab, n_unlab, size):
     """CPU oracle (plain PyTorch restatement of the reference step, oracle/steps_ref.py) on this host's cores: bounded sample."""
     from hpfg_amd.datasets.synthetic import synth_batch
     from oracle import laws_ref, steps_ref, unet_ref
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))      # a 1-GPU box shares its host: 16 cores is this job's CPU share
     torch.set_num_threads(cores)
     st = unet_ref.init_state(1337, 1, 4)
     ema = unet_ref.clone_state(st)
