@@ -184,3 +184,40 @@ __device__ static inline f32x4 cat_load4(const HpfgAct& a0, const ActCtx& c0, co
   if (c < a0.C || a1.mode == HPFG_ACT_NONE) return act_load4(a0, c0, n, y, x, c);
   return act_load4(a1, c1, n, y, x, c - a0.C);
 }
+
+
+// ---- single-mode loaders (compile-time mode): keep the conv kernels' staging code small and register-light -------------
+enum { HPFG_KIND_PLAIN = 0, HPFG_KIND_BNACT = 1, HPFG_KIND_POOL = 2, HPFG_KIND_CAT = 3, HPFG_KIND_DZ = 4 };
+
+template <int MODE>
+__device__ static inline f32x4 act_load4_mode(const HpfgAct& s, const ActCtx& cx, int n, int y, int x, int c) {
+  HpfgAct t = s;
+  t.mode = MODE;          // constant-folds the switch in act_load4
+  return act_load4(t, cx, n, y, x, c);
+}
+
+template <int KIND>
+__device__ static inline f32x4 kind_load4(const HpfgAct& a0, const ActCtx& c0, const HpfgAct& a1, const ActCtx& c1, int n, int y, int x, int c) {
+  if (KIND == HPFG_KIND_PLAIN) {
+    if (a0.mode == HPFG_ACT_STRIDED) return act_load4_mode<HPFG_ACT_STRIDED>(a0, c0, n, y, x, c);
+    return act_load4_mode<HPFG_ACT_PLAIN>(a0, c0, n, y, x, c);
+  }
+  if (KIND == HPFG_KIND_BNACT) return act_load4_mode<HPFG_ACT_BNACT>(a0, c0, n, y, x, c);
+  if (KIND == HPFG_KIND_POOL) return act_load4_mode<HPFG_ACT_BNACT_POOL>(a0, c0, n, y, x, c);
+  if (KIND == HPFG_KIND_DZ) return act_load4_mode<HPFG_ACT_DZ>(a0, c0, n, y, x, c);
+  // CAT: [BNACT skip | bilinear-upsampled plain]
+  if (c < a0.C) return act_load4_mode<HPFG_ACT_BNACT>(a0, c0, n, y, x, c);
+  return act_load4_mode<HPFG_ACT_UP2X>(a1, c1, n, y, x, c - a0.C);
+}
+
+static inline int hpfg_kind_of(const HpfgAct& a0, const HpfgAct& a1) {
+  if (a1.mode == HPFG_ACT_UP2X && a0.mode == HPFG_ACT_BNACT) return HPFG_KIND_CAT;
+  if (a1.mode != HPFG_ACT_NONE) return -1;
+  switch (a0.mode) {
+    case HPFG_ACT_PLAIN: case HPFG_ACT_STRIDED: return HPFG_KIND_PLAIN;
+    case HPFG_ACT_BNACT: return HPFG_KIND_BNACT;
+    case HPFG_ACT_BNACT_POOL: return HPFG_KIND_POOL;
+    case HPFG_ACT_DZ: return HPFG_KIND_DZ;
+    default: return -1;
+  }
+}

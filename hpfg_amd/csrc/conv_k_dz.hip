@@ -1,0 +1,9 @@
+#include "conv_kernel.h"
+
+int hpfg_conv_launch_dz(const HpfgConvArgs& a, hipStream_t st) {
+  if (a.taps != 9) {
+    hpfg_set_error("conv_fwd: 1x1 convolution with a dz loader is not instantiated");
+    return -1;
+  }
+  return hpfg_conv::conv_dispatch_kind<HPFG_KIND_DZ, 9>(a, st);
+}

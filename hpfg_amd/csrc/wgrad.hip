@@ -11,113 +11,36 @@
 // private slab; a second kernel sums the slabs in a fixed order (bitwise reproducible, no float atomics) and emits the
 // gradient in PyTorch's [Cout][Cin][k][k] layout.  3x3: three waves, wave w owns kernel row ky = w.  1x1: wave w owns
 // n-tile w.
-#include "common.h"
+#include "wgrad_kernel.h"
 
 namespace {
 
-constexpr int T = 16;          // pixel tile edge
-constexpr int PSA = 17;        // LDS pixel stride of the A tile (16 channels + 1)
-
-template <int TAPS, int NJ>
-struct WCfg {
-  static constexpr int NW = TAPS == 9 ? 3 : NJ;           // waves per workgroup
-  static constexpr int HALO = TAPS == 9 ? 1 : 0;
-  static constexpr int TP = T + 2 * HALO;
-  static constexpr int PSB = 16 * NJ + 1;                  // LDS pixel stride of the dZ tile
-  static constexpr int LDS_A = TP * TP * PSA;
-  static constexpr int LDS_B = T * T * PSB;
-  static constexpr int NT = TAPS == 9 ? 3 : 1;             // taps per wave
-  static constexpr int NA = TAPS == 9 ? NJ : 1;            // n-tiles per wave
-};
-
-template <int TAPS, int NJ>
-__global__ __launch_bounds__((TAPS == 9 ? 192 : 64 * NJ)) void wgrad_kernel(HpfgWgradArgs p, int tiles_x, int tiles_y) {
-  using C = WCfg<TAPS, NJ>;
-  __shared__ float ldsA[C::LDS_A];
-  __shared__ float ldsB[C::LDS_B];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = 64 * C::NW;
-  const int ci0 = blockIdx.y * 16, co0 = blockIdx.z * 16 * NJ;
-  const int H = p.H, W = p.W;
-  const ActCtx cxa0 = make_ctx(p.a0), cxa1 = make_ctx(p.a1), cxg = make_ctx(p.g);
-
-  f32x4 acc[C::NT][C::NA];
-#pragma unroll
-  for (int t = 0; t < C::NT; ++t)
-#pragma unroll
-    for (int j = 0; j < C::NA; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int ntiles = tiles_x * tiles_y;
-  const int nwork = p.N * ntiles;
-  for (int wk = blockIdx.x; wk < nwork; wk += gridDim.x) {
-    const int n = wk / ntiles, tile = wk % ntiles;
-    const int ty0 = (tile / tiles_x) * T, tx0 = (tile % tiles_x) * T;
-    __syncthreads();
-    for (int idx = tid; idx < C::TP * C::TP * 4; idx += nthr) {
-      int pix = idx >> 2, cq = idx & 3;
-      int gy = ty0 + pix / C::TP - C::HALO, gx = tx0 + pix % C::TP - C::HALO;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = cat_load4(p.a0, cxa0, p.a1, cxa1, n, gy, gx, ci0 + cq * 4);
-      float* d = ldsA + pix * PSA + cq * 4;
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-    }
-    for (int idx = tid; idx < T * T * 4 * NJ; idx += nthr) {
-      int pix = idx / (4 * NJ), cq = idx % (4 * NJ);
-      int gy = ty0 + pix / T, gx = tx0 + pix % T;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy < H && gx < W) v = act_load4(p.g, cxg, n, gy, gx, co0 + cq * 4);
-      float* d = ldsB + pix * C::PSB + cq * 4;
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int ks = 0; ks < T * T / 4; ++ks) {
-      const int pix = ks * 4 + (lane >> 4);            // k index = pixel
-      const int r = pix / T, c = pix % T;
-      if (TAPS == 9) {
-        float b[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) b[j] = ldsB[pix * C::PSB + j * 16 + (lane & 15)];
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          float a = ldsA[((r + wave) * C::TP + c + kx) * PSA + (lane & 15)];
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[kx][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[kx][j], 0, 0, 0);
-        }
-      } else {
-        float b = ldsB[pix * C::PSB + wave * 16 + (lane & 15)];
-        float a = ldsA[pix * PSA + (lane & 15)];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[0][0], 0, 0, 0);
-      }
-    }
-  }
-  // slab[s][tap][ci][co]; C/D layout: row (ci) = (lane>>4)*4 + r, col (co) = lane & 15
-  float* slab = p.slab + (long)blockIdx.x * p.taps * p.CinPad * p.CoutPad;
-#pragma unroll
-  for (int t = 0; t < C::NT; ++t)
-#pragma unroll
-    for (int j = 0; j < C::NA; ++j) {
-      const int tap = TAPS == 9 ? wave * 3 + t : 0;
-      const int nt = TAPS == 9 ? j : wave;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int ci = ci0 + (lane >> 4) * 4 + r, co = co0 + nt * 16 + (lane & 15);
-        slab[((long)tap * p.CinPad + ci) * p.CoutPad + co] = acc[t][j][r];
-      }
-    }
-}
-
-// dw[co][ci][tap] = sum_s slab[s][tap][ci][co]
+// dw[co][ci][tap] = sum_s slab[s][tap][ci][co].  Workgroup = 16 elements x 16 slab lanes; fixed summation order (reproducible).
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int taps, int Cin,
                                                           int CinPad, int Cout, int CoutPad) {
+  __shared__ float red[16][17];
   const long per = (long)taps * CinPad * CoutPad;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+  const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + il;
+  float t0 = 0.f, t1 = 0.f;
+  if (i < per) {
+    int s = sl;
+    for (; s + 16 < S; s += 32) {
+      t0 += slab[s * per + i];
+      t1 += slab[(s + 16) * per + i];
+    }
+    if (s < S) t0 += slab[s * per + i];
+  }
+  red[sl][il] = t0 + t1;
+  __syncthreads();
+  if (sl == 0 && i < per) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][il];
     int co = (int)(i % CoutPad);
     int ci = (int)((i / CoutPad) % CinPad);
     int tap = (int)(i / ((long)CoutPad * CinPad));
-    if (co >= Cout || ci >= Cin) continue;
-    float t = 0.f;
-    for (int s = 0; s < S; ++s) t += slab[s * per + i];
-    dw[((long)co * Cin + ci) * taps + tap] = t;
+    if (co < Cout && ci < Cin) dw[((long)co * Cin + ci) * taps + tap] = t;
   }
 }
 
@@ -146,19 +69,19 @@ __global__ __launch_bounds__(64) void channel_sum_stage2(const float* __restrict
   if (threadIdx.x == 0) out[c] = (float)a;
 }
 
-int pick_nj(int CoutPad) { return CoutPad % 64 == 0 ? 4 : (CoutPad % 32 == 0 ? 2 : 1); }
-
 }  // namespace
 
 extern "C" int hpfg_wgrad_splits(int N, int H, int W, int CinPad, int CoutPad, int taps) {
   (void)taps;
+  using namespace hpfg_wg;
   int nj = pick_nj(CoutPad);
   long pairs = (long)(CinPad / 16) * (CoutPad / (16 * nj));
-  long nwork = (long)N * ((H + T - 1) / T) * ((W + T - 1) / T);
-  long s = 1536 / pairs;
-  if (s < 1) s = 1;
-  if (s > nwork) s = nwork;
-  return (int)s;
+  long nwork = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  long target = 1024 / pairs;               // aim at ~1k workgroups per launch
+  if (target < 1) target = 1;
+  if (target > nwork) target = nwork;
+  long per_block = (nwork + target - 1) / target;   // work items per workgroup
+  return (int)((nwork + per_block - 1) / per_block);
 }
 
 extern "C" long hpfg_wgrad_slab_floats(int N, int H, int W, int CinPad, int CoutPad, int taps) {
@@ -172,22 +95,19 @@ extern "C" int hpfg_wgrad(const HpfgWgradArgs* a, void* stream) {
   HPFG_ARG_CHECK(a->S >= 1, "wgrad: S < 1");
   HPFG_ARG_CHECK(a->a1.mode == HPFG_ACT_NONE || a->a0.C % 16 == 0, "wgrad: concat needs a0.C %% 16 == 0");
   hipStream_t st = (hipStream_t)stream;
-  const int nj = pick_nj(a->CoutPad);
-  const int tx = (a->W + T - 1) / T, ty = (a->H + T - 1) / T;
-  dim3 grid(a->S, a->CinPad / 16, a->CoutPad / (16 * nj));
-#define HPFG_WG(TAPS, NJ) hipLaunchKernelGGL((wgrad_kernel<TAPS, NJ>), grid, dim3(64 * WCfg<TAPS, NJ>::NW), 0, st, *a, tx, ty)
-  if (a->taps == 9) {
-    if (nj == 4) HPFG_WG(9, 4); else if (nj == 2) HPFG_WG(9, 2); else HPFG_WG(9, 1);
-  } else {
-    if (nj == 4) HPFG_WG(1, 4); else if (nj == 2) HPFG_WG(1, 2); else HPFG_WG(1, 1);
+  const int akind = hpfg_kind_of(a->a0, a->a1);
+  HPFG_ARG_CHECK(akind >= 0 && akind != HPFG_KIND_DZ, "wgrad: unsupported input source (a0.mode=%d, a1.mode=%d)", a->a0.mode, a->a1.mode);
+  int rc;
+  if (a->g.mode == HPFG_ACT_DZ) rc = hpfg_wgrad_launch_dz(*a, akind, st);
+  else if (a->g.mode == HPFG_ACT_PLAIN || a->g.mode == HPFG_ACT_STRIDED) rc = hpfg_wgrad_launch_plain(*a, akind, st);
+  else {
+    hpfg_set_error("wgrad: unsupported gradient source mode %d", a->g.mode);
+    return -1;
   }
-#undef HPFG_WG
-  int rc = hpfg_launch_status("wgrad_kernel");
   if (rc) return rc;
   long per = (long)a->taps * a->CinPad * a->CoutPad;
-  int rb = (int)((per + 255) / 256);
-  if (rb > 2048) rb = 2048;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, st, a->slab, a->dw_oihw, a->S, a->taps, a->Cin, a->CinPad, a->Cout, a->CoutPad);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((per + 15) / 16)), dim3(256), 0, st, a->slab, a->dw_oihw, a->S, a->taps, a->Cin, a->CinPad,
+                     a->Cout, a->CoutPad);
   return hpfg_launch_status("slab_reduce_kernel");
 }
 
