@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ = range(7)
 LOSS_NSUM = 32
-VERSION = 100
+VERSION = 101
+MATH_F32, MATH_BF16X3 = 0, 1
 
 
 class HipLibraryError(RuntimeError):
@@ -33,7 +34,7 @@ class Act(C.Structure):
 class ConvArgs(C.Structure):
     _fields_ = [("a0", Act), ("a1", Act), ("wpk", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
                 ("stat_partials", C.c_void_p), ("out_pstride", C.c_int32), ("Cout", C.c_int32), ("CoutPad", C.c_int32),
-                ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("taps", C.c_int32)]
+                ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("taps", C.c_int32), ("math", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -44,8 +45,8 @@ class WgradArgs(C.Structure):
 
 class PackDesc(C.Structure):
     _fields_ = [("w_oihw", C.c_void_p), ("b", C.c_void_p), ("wpk_fwd", C.c_void_p), ("wpk_dgrad", C.c_void_p),
-                ("bias_pad", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32), ("CoutPad", C.c_int32),
-                ("CinPad", C.c_int32), ("taps", C.c_int32)]
+                ("bias_pad", C.c_void_p), ("wpk16_fwd", C.c_void_p), ("wpk16_dgrad", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32),
+                ("CoutPad", C.c_int32), ("CinPad", C.c_int32), ("taps", C.c_int32), ("kc", C.c_int32)]
 
 
 class LossArgs(C.Structure):
@@ -66,6 +67,8 @@ PROTOTYPES = {
     "hpfg_conv_stat_blocks": (_i, [_i, _i, _i]),
     "hpfg_bn_fwd_finalize": (_i, [_p, _i, _p, _d, _p, _p, _p, _p, _f, _f, _p, _i, _p]),
     "hpfg_reduce_partials": (_i, [_p, _i, _i, _p, _p]),
+    "hpfg_conv_kc": (_i, [_i, _i, _i]),
+    "hpfg_wpk16_elems": (_l, [_i, _i, _i, _i]),
     "hpfg_pack_weights": (_i, [_p, C.POINTER(PackDesc), _i, _p]),
     "hpfg_act_materialize": (_i, [C.POINTER(Act), C.POINTER(Act), _i, _i, _i, _p, _p]),
     "hpfg_dropout_mask": (_i, [_p, _l, _f, _u32, _p, _p]),

@@ -13,6 +13,7 @@
 // pixel-major with stride 17 floats (conflict-free ds_read_b32 for the A operand: 16 pixels x 4 channels per MFMA);
 // B operands come straight from global memory in pre-packed fragment order (one float4 per lane covers 4 k-steps).
 #include "conv_kernel.h"
+#include "conv_bf16_kernel.h"
 
 namespace {
 
@@ -100,6 +101,18 @@ extern "C" int hpfg_conv_fwd(const HpfgConvArgs* a, void* stream) {
   HPFG_ARG_CHECK(a->a1.mode == HPFG_ACT_NONE || a->a0.C % 16 == 0, "conv_fwd: concat needs a0.C %% 16 == 0");
   HPFG_ARG_CHECK(a->out_pstride >= a->Cout, "conv_fwd: out_pstride < Cout");
   hipStream_t st = (hipStream_t)stream;
+  if (a->math == HPFG_MATH_BF16X3) {
+    switch (hpfg_kind_of(a->a0, a->a1)) {
+      case HPFG_KIND_PLAIN: return hpfg_conv16_launch_plain(*a, st);
+      case HPFG_KIND_BNACT: return hpfg_conv16_launch_bnact(*a, st);
+      case HPFG_KIND_POOL: return hpfg_conv16_launch_pool(*a, st);
+      case HPFG_KIND_CAT: return hpfg_conv16_launch_cat(*a, st);
+      case HPFG_KIND_DZ: return hpfg_conv16_launch_dz(*a, st);
+      default: break;
+    }
+    hpfg_set_error("conv_fwd(bf16x3): unsupported source combination (a0.mode=%d, a1.mode=%d)", a->a0.mode, a->a1.mode);
+    return -1;
+  }
   switch (hpfg_kind_of(a->a0, a->a1)) {
     case HPFG_KIND_PLAIN: return hpfg_conv_launch_plain(*a, st);
     case HPFG_KIND_BNACT: return hpfg_conv_launch_bnact(*a, st);

@@ -39,6 +39,38 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const HpfgPackDesc* _
     }
     if (i < d.CoutPad) d.bias_pad[i] = (i < d.Cout && d.b) ? d.b[i] : 0.f;
   }
+  // ---- bf16x3 fragments: [ks][ntile][hi|lo][64 lanes][8], k-local = 8*(lane>>4)+j, column = lane&15 (conv_bf16_kernel.h) ----
+  const int ksteps = d.taps == 1 ? 1 : (d.kc == 32 ? 9 : 5);
+  for (int dir = 0; dir < 2; ++dir) {
+    __bf16* out = reinterpret_cast<__bf16*>(dir == 0 ? d.wpk16_fwd : d.wpk16_dgrad);
+    if (!out) continue;
+    const int Kch = dir == 0 ? d.Cin : d.Cout;                  // contraction channels
+    const int ntn = (dir == 0 ? d.CoutPad : d.CinPad) / 16;     // output-channel tiles
+    const int nchunks = (Kch + d.kc - 1) / d.kc;
+    const long tot = (long)nchunks * ksteps * ntn * 512;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+      const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+      const long r = i >> 9;
+      const int nt = (int)(r % ntn), ks = (int)(r / ntn);
+      const int chunk = ks / ksteps, s = ks % ksteps;
+      const int kl = 8 * (lane >> 4) + j;
+      int tap, kch;
+      if (d.taps == 1) { tap = 0; kch = chunk * 32 + kl; }
+      else if (d.kc == 32) { tap = s; kch = chunk * 32 + kl; }
+      else { tap = 2 * s + (kl >> 4); kch = chunk * 16 + (kl & 15); }
+      const int nch = nt * 16 + (lane & 15);
+      float w = 0.f;
+      if (tap < d.taps && kch < Kch) {
+        if (dir == 0) { if (nch < d.Cout) w = d.w_oihw[((long)nch * d.Cin + kch) * d.taps + tap]; }
+        else { if (nch < d.Cin) w = d.w_oihw[((long)kch * d.Cin + nch) * d.taps + (d.taps - 1 - tap)]; }
+      }
+      const __bf16 hi = (__bf16)w;
+      const __bf16 lo = (__bf16)(w - (float)hi);
+      const long base = ((long)ks * ntn + nt) * 2;
+      out[(base + 0) * 512 + lane * 8 + j] = hi;
+      out[(base + 1) * 512 + lane * 8 + j] = lo;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void materialize_kernel(HpfgAct a0, HpfgAct a1, int N, int H, int W, float* __restrict__ out) {
@@ -191,6 +223,13 @@ inline int grid_for(long total, int cap = 4096) {
 
 }  // namespace
 
+extern "C" int hpfg_conv_kc(int H, int W, int taps) { return (taps == 9 && H % 16 == 0 && W % 16 == 0) ? 16 : 32; }
+
+extern "C" long hpfg_wpk16_elems(int Kchannels, int NchannelsPad, int taps, int kc) {
+  const int ksteps = taps == 1 ? 1 : (kc == 32 ? 9 : 5);
+  return (long)((Kchannels + kc - 1) / kc) * ksteps * (NchannelsPad / 16) * 2 * 64 * 8;
+}
+
 extern "C" int hpfg_pack_weights(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, void* stream) {
   HPFG_ARG_CHECK(table_dev && table_host && nlayers > 0 && nlayers < 65536, "pack_weights: bad args");
   long mx = 0;
@@ -198,6 +237,7 @@ extern "C" int hpfg_pack_weights(const HpfgPackDesc* table_dev, const HpfgPackDe
     const HpfgPackDesc& d = table_host[i];
     HPFG_ARG_CHECK(d.CinPad % 16 == 0 && d.CoutPad % 16 == 0 && d.Cin <= d.CinPad && d.Cout <= d.CoutPad && (d.taps == 1 || d.taps == 9),
                    "pack_weights: bad descriptor %d", i);
+    HPFG_ARG_CHECK((!d.wpk16_fwd && !d.wpk16_dgrad) || d.kc == 32 || (d.kc == 16 && d.taps == 9), "pack_weights: bad kc in descriptor %d", i);
     long t = (long)d.taps * d.CinPad * d.CoutPad;
     if (t > mx) mx = t;
   }

@@ -96,10 +96,17 @@ class UNetEngine:
         self.wpk_f = {s.name: torch.empty(s.taps * s.cin_pad * s.cout_pad, **f32) for s in self.packed}
         self.wpk_d = {s.name: torch.empty(s.taps * s.cin_pad * s.cout_pad, **f32) for s in self.packed if s.idx > 1 or True}
         self.bias_pad = {s.name: torch.empty(s.cout_pad, **f32) for s in self.packed}
+        # bf16x3 fragments (hi/lo split weights) for the split-precision matrix-core path
+        self.kc = {s.name: self.lib.hpfg_conv_kc(s.h, s.w, s.taps) for s in self.packed}
+        self.wpk16_f = {s.name: torch.empty(self.lib.hpfg_wpk16_elems(s.cin, s.cout_pad, s.taps, self.kc[s.name]), dtype=torch.bfloat16, device=device)
+                        for s in self.packed}
+        self.wpk16_d = {s.name: torch.empty(self.lib.hpfg_wpk16_elems(s.cout, s.cin_pad, s.taps, self.kc[s.name]), dtype=torch.bfloat16, device=device)
+                        for s in self.packed}
         descs = (L.PackDesc * len(self.packed))()
         for d, s in zip(descs, self.packed):
             d.w_oihw, d.b = L.ptr(params[f"{s.name}.weight"]), L.ptr(params[f"{s.name}.bias"])
             d.wpk_fwd, d.wpk_dgrad, d.bias_pad = L.ptr(self.wpk_f[s.name]), L.ptr(self.wpk_d[s.name]), L.ptr(self.bias_pad[s.name])
+            d.wpk16_fwd, d.wpk16_dgrad, d.kc = L.ptr(self.wpk16_f[s.name]), L.ptr(self.wpk16_d[s.name]), self.kc[s.name]
             d.Cout, d.Cin, d.CoutPad, d.CinPad, d.taps = s.cout, s.cin, s.cout_pad, s.cin_pad, s.taps
         self._pack_host = descs
         raw = bytes(descs)
@@ -111,6 +118,7 @@ class UNetEngine:
         self._bwd_alloc = False
         self.x: Optional[torch.Tensor] = None
         self.world = 1
+        self.math = L.MATH_F32      # L.MATH_BF16X3 selects the split-bf16 matrix-core kernels for conv forward / dgrad
         self.ext_masks: Dict[str, torch.Tensor] = {}   # conv name -> uint8 NHWC keep-mask (parity tests replaying torch's masks)
         self.allreduce = None    # callable(tensor) -> in-place sum across ranks (data parallel), set by hpfg_amd.parallel
 
@@ -223,7 +231,9 @@ class UNetEngine:
             else:
                 ca = L.ConvArgs()
                 ca.a0, ca.a1 = a0, a1
-                ca.wpk, ca.bias, ca.out = L.ptr(self.wpk_f[s.name]), L.ptr(self.bias_pad[s.name]), L.ptr(out)
+                ca.math = self.math
+                ca.wpk = L.ptr(self.wpk16_f[s.name]) if self.math == L.MATH_BF16X3 else L.ptr(self.wpk_f[s.name])
+                ca.bias, ca.out = L.ptr(self.bias_pad[s.name]), L.ptr(out)
                 ca.stat_partials = L.ptr(self.partials) if want_stats else None
                 ca.out_pstride, ca.Cout, ca.CoutPad = s.cout, s.cout, s.cout_pad
                 ca.N, ca.H, ca.W, ca.taps = self.N, s.h, s.w, s.taps
@@ -318,7 +328,9 @@ class UNetEngine:
         """out [N,h,w,cin] = conv-transpose of dZ with this layer's weights."""
         ca = L.ConvArgs()
         ca.a0, ca.a1 = g, L.Act()
-        ca.wpk, ca.bias, ca.out, ca.stat_partials = L.ptr(self.wpk_d[s.name]), None, L.ptr(out), None
+        ca.math = self.math
+        ca.wpk = L.ptr(self.wpk16_d[s.name]) if self.math == L.MATH_BF16X3 else L.ptr(self.wpk_d[s.name])
+        ca.bias, ca.out, ca.stat_partials = None, L.ptr(out), None
         ca.out_pstride, ca.Cout, ca.CoutPad = s.cin, s.cin, s.cin_pad
         ca.N, ca.H, ca.W, ca.taps = self.N, s.h, s.w, s.taps
         L.check(self.lib.hpfg_conv_fwd(C.byref(ca), self._stream()), f"dgrad[{s.name}]")

@@ -17,6 +17,9 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+import os
+
+from .. import _lib as L
 from .. import engine as E
 from .. import heads
 
@@ -107,6 +110,7 @@ class UNet(nn.Module):
         self._seed_counter = 0
         self.dropout_seed = 0x1234567
         self.dp = None   # hpfg_amd.parallel.DataParallelContext or None
+        self.math = os.environ.get("HPFG_MATH", "f32")   # "f32": exact fp32 MFMA; "bf16x3": split-bf16 MFMA (fp32-class accuracy)
         self.external_dropout_masks = None   # optional {conv name: uint8 NHWC keep-mask}: replay masks drawn elsewhere (tests)
         self._flatten()
 
@@ -244,6 +248,7 @@ class UNet(nn.Module):
             eng.gtmp = gtmp
             pool.append(eng)
         eng.base_seed = self.dropout_seed
+        eng.math = L.MATH_BF16X3 if self.math == "bf16x3" else L.MATH_F32
         eng.ext_masks = self.external_dropout_masks or {}
         if self.dp is not None:
             eng.world, eng.allreduce = self.dp.world_size, self.dp.allreduce_sum

@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 100
+#define HPFG_VERSION 101
+enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
 enum { HPFG_BN_MEAN = 0, HPFG_BN_RSTD = 1, HPFG_BN_SCALE = 2, HPFG_BN_SHIFT = 3,
@@ -67,6 +68,8 @@ typedef struct HpfgConvArgs {
   int32_t out_pstride, Cout, CoutPad;
   int32_t N, H, W;      /* output (= virtual input) size */
   int32_t taps;         /* 9 (3x3, pad 1) or 1 (1x1) */
+  int32_t math;         /* HPFG_MATH_F32: exact fp32 MFMA, wpk = fp32 fragments; HPFG_MATH_BF16X3: split-bf16 MFMA (hi*hi+hi*lo+lo*hi,
+                           fp32 accumulate), wpk = the wpk16_* buffer of hpfg_pack_weights */
 } HpfgConvArgs;
 
 typedef struct HpfgWgradArgs {
@@ -85,7 +88,11 @@ typedef struct HpfgPackDesc {   /* one conv layer for hpfg_pack_weights (device 
   float* wpk_fwd;       /* [taps][CinPad/16][CoutPad/16][64][4]: B fragments of mfma_f32_16x16x4f32, k = input channel */
   float* wpk_dgrad;     /* [taps][CoutPad/16][CinPad/16][64][4]: transposed + tap-flipped weights for dgrad; may be NULL */
   float* bias_pad;      /* [CoutPad] */
+  void* wpk16_fwd;      /* bf16x3 B fragments [k-step][CoutPad/16][hi|lo][64][8] (hpfg_wpk16_elems() bf16 values), or NULL */
+  void* wpk16_dgrad;    /* same for dgrad (k = output channel, taps flipped), or NULL */
   int32_t Cout, Cin, CoutPad, CinPad, taps;
+  int32_t kc;           /* K packing of the bf16 buffers: 32 = one tap x 32 channels, 16 = two taps x 16 channels (3x3 on 16x16 tiles);
+                           use hpfg_conv_kc(H, W, taps) */
 } HpfgPackDesc;
 
 int hpfg_version(void);
@@ -107,6 +114,8 @@ int hpfg_reduce_partials(const float* partials, int nblk, int C, double* sums, v
 /* eval-mode BatchNorm (model.eval(), val.py:268-287): table rows from the running statistics */
 int hpfg_bn_eval_table(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                        float* bn, int C, void* stream);
+int hpfg_conv_kc(int H, int W, int taps);
+long hpfg_wpk16_elems(int Kchannels, int NchannelsPad, int taps, int kc);   /* bf16 elements of one wpk16 buffer */
 int hpfg_pack_weights(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, void* stream);
 /* evaluate a virtual activation into memory (tests, projection-neck inputs): out [N,H,W,a0.C+a1.C] */
 int hpfg_act_materialize(const HpfgAct* a0, const HpfgAct* a1, int N, int H, int W, float* out, void* stream);

@@ -40,7 +40,7 @@ def pad16(c):
 
 
 class AdHocConv:
-    def __init__(self, cin, cout, taps, device, seed=0):
+    def __init__(self, cin, cout, taps, device, seed=0, hw=(16, 16)):
         g = torch.Generator().manual_seed(seed)
         k = 3 if taps == 9 else 1
         self.cin, self.cout, self.taps, self.k, self.dev = cin, cout, taps, k, device
@@ -51,7 +51,12 @@ class AdHocConv:
         self.wpk_f = torch.empty(n, device=device)
         self.wpk_d = torch.empty(n, device=device)
         self.bias_pad = torch.empty(self.cout_pad, device=device)
+        lib = L.load()
+        self.kc = lib.hpfg_conv_kc(hw[0], hw[1], taps)
+        self.wpk16_f = torch.empty(lib.hpfg_wpk16_elems(cin, self.cout_pad, taps, self.kc), dtype=torch.bfloat16, device=device)
+        self.wpk16_d = torch.empty(lib.hpfg_wpk16_elems(cout, self.cin_pad, taps, self.kc), dtype=torch.bfloat16, device=device)
         d = (L.PackDesc * 1)()
+        d[0].wpk16_fwd, d[0].wpk16_dgrad, d[0].kc = L.ptr(self.wpk16_f), L.ptr(self.wpk16_d), self.kc
         d[0].w_oihw, d[0].b, d[0].wpk_fwd, d[0].wpk_dgrad, d[0].bias_pad = (L.ptr(self.w), L.ptr(self.b), L.ptr(self.wpk_f), L.ptr(self.wpk_d),
                                                                           L.ptr(self.bias_pad))
         d[0].Cout, d[0].Cin, d[0].CoutPad, d[0].CinPad, d[0].taps = cout, cin, self.cout_pad, self.cin_pad, taps
@@ -59,14 +64,19 @@ class AdHocConv:
         self._keep = (d, dev_tab)
         L.check(L.load().hpfg_pack_weights(dev_tab.data_ptr(), d, 1, stream(device)), "pack")
 
-    def conv(self, a0, a1, N, H, W, stats=False, dgrad=False):
+    def conv(self, a0, a1, N, H, W, stats=False, dgrad=False, math=0):
         lib = L.load()
         cout = self.cin if dgrad else self.cout
         cpad = self.cin_pad if dgrad else self.cout_pad
         out = torch.full((N, H, W, cout), float("nan"), device=self.dev)
         ca = L.ConvArgs()
         ca.a0, ca.a1 = a0, (a1 if a1 is not None else L.Act())
-        ca.wpk = L.ptr(self.wpk_d if dgrad else self.wpk_f)
+        ca.math = math
+        if math == L.MATH_BF16X3:
+            assert lib.hpfg_conv_kc(H, W, self.taps) == self.kc, "AdHocConv was packed for a different tile class"
+            ca.wpk = L.ptr(self.wpk16_d if dgrad else self.wpk16_f)
+        else:
+            ca.wpk = L.ptr(self.wpk_d if dgrad else self.wpk_f)
         ca.bias = None if dgrad else L.ptr(self.bias_pad)
         ca.out = L.ptr(out)
         part = None

@@ -36,7 +36,7 @@ def test_conv_fwd_dgrad_wgrad_plain(N, H, W, cin, cout, taps):
     g = torch.Generator().manual_seed(H * 1000 + cin + cout)
     x = torch.randn(N, H, W, cin, generator=g)
     gz = torch.randn(N, H, W, cout, generator=g)
-    layer = AdHocConv(cin, cout, taps, DEV, seed=cin * 7 + cout)
+    layer = AdHocConv(cin, cout, taps, DEV, seed=cin * 7 + cout, hw=(H, W))
     xd, gzd = x.to(DEV), gz.to(DEV)
     out, part = layer.conv(plain_act(xd, cin, H, W), None, N, H, W, stats=True)
     xr = nchw(x).requires_grad_(True)
@@ -55,6 +55,13 @@ def test_conv_fwd_dgrad_wgrad_plain(N, H, W, cin, cout, taps):
     dx, _ = layer.conv(plain_act(gzd, cout, H, W), None, N, H, W, dgrad=True)
     e = maxerr(nchw(dx.cpu()), xr.grad)
     assert e < 2e-4 * max(1.0, float(xr.grad.abs().max())), f"dgrad err {e}"
+    # split-bf16 matrix-core path: fp32-class accuracy (~1e-5 relative), same packing entry point
+    o16, p16 = layer.conv(plain_act(xd, cin, H, W), None, N, H, W, stats=True, math=L.MATH_BF16X3)
+    e = maxerr(nchw(o16.cpu()), ref.detach())
+    assert e < 3e-4 * max(1.0, float(ref.detach().abs().max())), f"bf16x3 conv fwd err {e}"
+    d16, _ = layer.conv(plain_act(gzd, cout, H, W), None, N, H, W, dgrad=True, math=L.MATH_BF16X3)
+    e = maxerr(nchw(d16.cpu()), xr.grad)
+    assert e < 3e-4 * max(1.0, float(xr.grad.abs().max())), f"bf16x3 dgrad err {e}"
     dw = layer.wgrad(plain_act(xd, cin, H, W), None, plain_act(gzd, cout, H, W), N, H, W)
     e = maxerr(dw.cpu(), wr.grad)
     assert e < 3e-4 * max(1.0, float(wr.grad.abs().max())), f"wgrad err {e}"
