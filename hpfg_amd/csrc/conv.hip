@@ -101,7 +101,7 @@ extern "C" int hpfg_conv_fwd(const HpfgConvArgs* a, void* stream) {
   HPFG_ARG_CHECK(a->a1.mode == HPFG_ACT_NONE || a->a0.C % 16 == 0, "conv_fwd: concat needs a0.C %% 16 == 0");
   HPFG_ARG_CHECK(a->out_pstride >= a->Cout, "conv_fwd: out_pstride < Cout");
   hipStream_t st = (hipStream_t)stream;
-  if (a->math == HPFG_MATH_BF16X3) {
+  if ((a->math & 0xff) == HPFG_MATH_BF16X3) {
     switch (hpfg_kind_of(a->a0, a->a1)) {
       case HPFG_KIND_PLAIN: return hpfg_conv16_launch_plain(*a, st);
       case HPFG_KIND_BNACT: return hpfg_conv16_launch_bnact(*a, st);

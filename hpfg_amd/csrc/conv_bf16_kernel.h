@@ -51,17 +51,17 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
   }
 }
 
-#define HPFG16_STAGE_LOAD(I, CH, V0, V1)                                                                                 \
+#define HPFG16_STAGE_LOAD(I, CH, NN, TY, TX, V0, V1)                                                                     \
   {                                                                                                                      \
     const int idx_ = tid + (I) * 256;                                                                                    \
     V0 = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                      \
     V1 = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                      \
     if (idx_ < C::NPIECE) {                                                                                              \
       const int pix_ = idx_ / C::NG, g_ = idx_ % C::NG;                                                                  \
-      const int gy_ = ty0 + pix_ / C::WP - C::HALO, gx_ = tx0 + pix_ % C::WP - C::HALO;                                  \
-      if (gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W) {                                                                  \
-        V0 = kind_load4<KIND>(p.a0, cx0, p.a1, cx1, n, gy_, gx_, (CH) * C::KC + g_ * 8);                                 \
-        V1 = kind_load4<KIND>(p.a0, cx0, p.a1, cx1, n, gy_, gx_, (CH) * C::KC + g_ * 8 + 4);                             \
+      const int gy_ = (TY) + pix_ / C::WP - C::HALO, gx_ = (TX) + pix_ % C::WP - C::HALO;                                \
+      if (gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W && !(p.math & 0x400)) {                                             \
+        V0 = kind_load4<KIND>(p.a0, cx0, p.a1, cx1, NN, gy_, gx_, (CH) * C::KC + g_ * 8);                                \
+        V1 = kind_load4<KIND>(p.a0, cx0, p.a1, cx1, NN, gy_, gx_, (CH) * C::KC + g_ * 8 + 4);                            \
       }                                                                                                                  \
     }                                                                                                                    \
   }
@@ -85,15 +85,78 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
     BL[j] = q_[64];                                                                                                      \
   }
 
+// Epilogue shared by both kernels: + bias, store the raw output tile, per-channel partial sums for BatchNorm.
+template <class C>
+__device__ __forceinline__ void conv16_epilogue(const HpfgConvArgs& p, f32x4 (&acc)[C::MI][C::NI], float* ldsf, int tid, int lane, int wm, int wn,
+                                                int nt0, int cb, int n, int ty0, int tx0, long blk) {
+  const int H = p.H, W = p.W;
+  float s1[C::NI], s2[C::NI];
+#pragma unroll
+  for (int j = 0; j < C::NI; ++j) {
+    s1[j] = 0.f;
+    s2[j] = 0.f;
+    const int co = (nt0 + j) * 16 + (lane & 15);
+    const float b = (p.bias && co < p.CoutPad) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int m = 0; m < C::MI; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int pxl = (wm * C::MI + m) * 16 + (lane >> 4) * 4 + r;
+        int gy = ty0 + pxl / C::TW, gx = tx0 + pxl % C::TW;
+        float v = acc[m][j][r] + b;
+        if (gy < H && gx < W && co < p.Cout) {
+          if (!(p.math & 0x100)) p.out[((long)(n * H + gy) * W + gx) * p.out_pstride + co] = v;
+          s1[j] += v;
+          s2[j] += v * v;
+        }
+      }
+    }
+  }
+  if (p.stat_partials) {
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j) {
+      s1[j] += __shfl_xor(s1[j], 16);
+      s2[j] += __shfl_xor(s2[j], 16);
+      s1[j] += __shfl_xor(s1[j], 32);
+      s2[j] += __shfl_xor(s2[j], 32);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int j = 0; j < C::NI; ++j) {
+        int cl = (wn * C::NI + j) * 16 + lane;
+        ldsf[(0 * C::WM + wm) * C::BN + cl] = s1[j];
+        ldsf[(1 * C::WM + wm) * C::BN + cl] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * C::BN) {
+      int which = tid / C::BN, cl = tid % C::BN;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < C::WM; ++w) t += ldsf[(which * C::WM + w) * C::BN + cl];
+      int co = cb * C::BN + cl;
+      if (co < p.CoutPad) p.stat_partials[(blk * 2 + which) * p.CoutPad + co] = t;
+    }
+    __syncthreads();
+  }
+}
+
+// 3x3: persistent workgroups.  A workgroup walks tiles w = blockIdx.x, blockIdx.x + gridDim.x, ... (tile-major inside an image,
+// so consecutive tiles share halos in L2) and streams (tile, input-channel chunk) items through a double-buffered LDS tile:
+// while the MFMAs of item i run, the activated tile of item i+1 -- the next chunk, or chunk 0 of the workgroup's NEXT tile --
+// is fetched piecewise into the other buffer, so the load latency of a tile is hidden behind the previous tile's MFMAs and
+// output stores even for single-chunk (16-channel) layers.  One barrier per item.
 template <class C, int KIND>
 __global__ __launch_bounds__(256) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
-  constexpr int NBUF = C::TAPS == 9 ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * C::BUF_BYTES > 2 * 4 * C::BN * 4 ? NBUF * C::BUF_BYTES : 2 * 4 * C::BN * 4];
+  static_assert(C::TAPS == 9, "persistent kernel is the 3x3 path");
+  constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * C::BUF_BYTES + STAT_BYTES];
+  float* ldsf = reinterpret_cast<float*>(lds + 2 * C::BUF_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % C::WM, wn = wave / C::WM;
-  const int tile = blockIdx.x, n = blockIdx.y, cb = blockIdx.z;
-  const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+  const int cb = blockIdx.y;
   const int H = p.H, W = p.W;
+  const int ntiles = tiles_x * tiles_y, nwork = ntiles * p.N;
   const ActCtx cx0 = make_ctx(p.a0), cx1 = make_ctx(p.a1);
 
   f32x4 acc[C::MI][C::NI];
@@ -102,9 +165,8 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(HpfgConvArgs p, int ti
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // per-lane byte offset of this lane's A fragment inside a buffer, for tap (0,0): pixel slot + channel-group plane
-  const int kg = lane >> 4;                                   // k group of 8 inside the MFMA's K = 32
-  const int gl = C::KC == 32 ? kg : (kg & 1);                 // LDS channel group
+  const int kg = lane >> 4;
+  const int gl = C::KC == 32 ? kg : (kg & 1);
   int aoff[C::MI];
 #pragma unroll
   for (int m = 0; m < C::MI; ++m) {
@@ -118,19 +180,35 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(HpfgConvArgs p, int ti
   const int nt0 = (cb * C::WN + wn) * C::NI;
   const bf16x8* wpk = reinterpret_cast<const bf16x8*>(p.wpk);
 
-  if (C::TAPS == 9) {
-    for (int i = 0; i < C::NLD; ++i) {
-      f32x4 v0, v1;
-      HPFG16_STAGE_LOAD(i, 0, v0, v1)
-      HPFG16_STAGE_STORE(i, lds, v0, v1)
-    }
-    bf16x8 bh[C::NI], bl[C::NI], nh[C::NI], nl[C::NI];
-    HPFG16_LOAD_B(0, bh, bl)
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-      const unsigned char* cur = lds + (ch & 1) * C::BUF_BYTES;
-      unsigned char* nxt = lds + ((ch + 1) & 1) * C::BUF_BYTES;
-      const bool more = ch + 1 < nchunks;
+  int w = blockIdx.x;
+  if (w >= nwork) return;
+  int n = w / ntiles, tl = w % ntiles;
+  int ty0 = (tl / tiles_x) * C::TH, tx0 = (tl % tiles_x) * C::TW;
+  for (int i = 0; i < C::NLD; ++i) {
+    f32x4 v0, v1;
+    HPFG16_STAGE_LOAD(i, 0, n, ty0, tx0, v0, v1)
+    HPFG16_STAGE_STORE(i, lds, v0, v1)
+  }
+  bf16x8 bh[C::NI], bl[C::NI], nh[C::NI], nl[C::NI];
+  HPFG16_LOAD_B(0, bh, bl)
+  __syncthreads();
+  int item = 0;
+  while (true) {
+    for (int ch = 0; ch < nchunks; ++ch, ++item) {
+      const unsigned char* cur = lds + (item & 1) * C::BUF_BYTES;
+      unsigned char* nxt = lds + ((item + 1) & 1) * C::BUF_BYTES;
+      // the item after this one: next chunk of this tile, or chunk 0 of this workgroup's next tile
+      const bool last_chunk = ch + 1 == nchunks;
+      const int wn_ = w + (int)gridDim.x;
+      const bool more = !last_chunk || wn_ < nwork;
+      const int nch = last_chunk ? 0 : ch + 1;
+      int nn = n, nty = ty0, ntx = tx0;
+      if (last_chunk && more) {
+        nn = wn_ / ntiles;
+        const int t2 = wn_ % ntiles;
+        nty = (t2 / tiles_x) * C::TH;
+        ntx = (t2 % tiles_x) * C::TW;
+      }
       f32x4 s0a = {0.f, 0.f, 0.f, 0.f}, s0b = s0a, s1a = s0a, s1b = s0a;
 #pragma unroll 1
       for (int s = 0; s < C::KSTEPS; ++s) {
@@ -139,18 +217,20 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(HpfgConvArgs p, int ti
             if ((s & 1) == 0) HPFG16_STAGE_STORE(s - 2, nxt, s0a, s0b) else HPFG16_STAGE_STORE(s - 2, nxt, s1a, s1b)
           }
           if (s < C::NLD) {
-            if ((s & 1) == 0) HPFG16_STAGE_LOAD(s, ch + 1, s0a, s0b) else HPFG16_STAGE_LOAD(s, ch + 1, s1a, s1b)
+            if ((s & 1) == 0) HPFG16_STAGE_LOAD(s, nch, nn, nty, ntx, s0a, s0b) else HPFG16_STAGE_LOAD(s, nch, nn, nty, ntx, s1a, s1b)
           }
         }
-        if (s + 1 < C::KSTEPS) {
-          HPFG16_LOAD_B(ch * C::KSTEPS + s + 1, nh, nl)
-        } else if (more) {
-          HPFG16_LOAD_B((ch + 1) * C::KSTEPS, nh, nl)
+        if (!(p.math & 0x800)) {
+          if (s + 1 < C::KSTEPS) {
+            HPFG16_LOAD_B(ch * C::KSTEPS + s + 1, nh, nl)
+          } else if (more) {
+            HPFG16_LOAD_B(nch * C::KSTEPS, nh, nl)
+          }
         }
-        // tap of this lane's k group: KC=32 -> tap s for all lanes; KC=16 -> taps 2s, 2s+1 (tap 9 = zero weights: re-read tap 8)
         int tap = C::KC == 32 ? s : 2 * s + (kg >> 1);
         tap = tap > 8 ? 8 : tap;
         const int toff = ((tap / 3) * C::RS + (tap % 3)) * 16;
+        if (!(p.math & 0x200))
 #pragma unroll
         for (int m = 0; m < C::MI; ++m) {
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(cur + aoff[m] + toff);
@@ -170,83 +250,74 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(HpfgConvArgs p, int ti
       }
       __syncthreads();
     }
-  } else {
-    for (int ch = 0; ch < nchunks; ++ch) {
-      __syncthreads();
-      for (int i = 0; i < C::NLD; ++i) {
-        f32x4 v0, v1;
-        HPFG16_STAGE_LOAD(i, ch, v0, v1)
-        HPFG16_STAGE_STORE(i, lds, v0, v1)
-      }
-      bf16x8 bh[C::NI], bl[C::NI];
-      HPFG16_LOAD_B(ch, bh, bl)
-      __syncthreads();
+    conv16_epilogue<C>(p, acc, ldsf, tid, lane, wm, wn, nt0, cb, n, ty0, tx0, (long)w);
 #pragma unroll
-      for (int m = 0; m < C::MI; ++m) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds + aoff[m]);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds + aoff[m] + C::PLANE);
+    for (int m = 0; m < C::MI; ++m)
 #pragma unroll
-        for (int j = 0; j < C::NI; ++j) {
-          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[m][j], 0, 0, 0);
-          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[m][j], 0, 0, 0);
-          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[m][j], 0, 0, 0);
-        }
-      }
-    }
+      for (int j = 0; j < C::NI; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    w += gridDim.x;
+    if (w >= nwork) break;
+    n = w / ntiles;
+    tl = w % ntiles;
+    ty0 = (tl / tiles_x) * C::TH;
+    tx0 = (tl % tiles_x) * C::TW;
   }
+}
 
-  // ---- epilogue (identical to conv_kernel.h): + bias, store raw output, per-channel partial sums for BatchNorm ----
-  float* ldsf = reinterpret_cast<float*>(lds);
-  float s1[C::NI], s2[C::NI];
+// 1x1: one tile per workgroup, K = 32 input channels per MFMA step, no halo.
+template <class C, int KIND>
+__global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
+  static_assert(C::TAPS == 1, "1x1 path");
+  constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[C::BUF_BYTES + STAT_BYTES];
+  float* ldsf = reinterpret_cast<float*>(lds + C::BUF_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % C::WM, wn = wave / C::WM;
+  const int tile = blockIdx.x, n = blockIdx.y, cb = blockIdx.z;
+  const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+  const int H = p.H, W = p.W;
+  const ActCtx cx0 = make_ctx(p.a0), cx1 = make_ctx(p.a1);
+  f32x4 acc[C::MI][C::NI];
 #pragma unroll
-  for (int j = 0; j < C::NI; ++j) {
-    s1[j] = 0.f;
-    s2[j] = 0.f;
-    const int co = (nt0 + j) * 16 + (lane & 15);
-    const float b = (p.bias && co < p.CoutPad) ? p.bias[co] : 0.f;
+  for (int m = 0; m < C::MI; ++m)
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int kg = lane >> 4;
+  int aoff[C::MI];
+#pragma unroll
+  for (int m = 0; m < C::MI; ++m) {
+    int pxl = (wm * C::MI + m) * 16 + (lane & 15);
+    aoff[m] = (kg * 2) * C::PLANE + ((pxl / C::TW) * C::RS + (pxl % C::TW)) * 16;
+  }
+  const int cin_total = p.a0.C + p.a1.C;
+  const int nchunks = (cin_total + C::KC - 1) / C::KC;
+  const int ntn = p.CoutPad / 16;
+  const int nt0 = (cb * C::WN + wn) * C::NI;
+  const bf16x8* wpk = reinterpret_cast<const bf16x8*>(p.wpk);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();
+    for (int i = 0; i < C::NLD; ++i) {
+      f32x4 v0, v1;
+      HPFG16_STAGE_LOAD(i, ch, n, ty0, tx0, v0, v1)
+      HPFG16_STAGE_STORE(i, lds, v0, v1)
+    }
+    bf16x8 bh[C::NI], bl[C::NI];
+    HPFG16_LOAD_B(ch, bh, bl)
+    __syncthreads();
 #pragma unroll
     for (int m = 0; m < C::MI; ++m) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int pxl = (wm * C::MI + m) * 16 + (lane >> 4) * 4 + r;
-        int gy = ty0 + pxl / C::TW, gx = tx0 + pxl % C::TW;
-        float v = acc[m][j][r] + b;
-        if (gy < H && gx < W && co < p.Cout) {
-          p.out[((long)(n * H + gy) * W + gx) * p.out_pstride + co] = v;
-          s1[j] += v;
-          s2[j] += v * v;
-        }
-      }
-    }
-  }
-  if (p.stat_partials) {
-#pragma unroll
-    for (int j = 0; j < C::NI; ++j) {
-      s1[j] += __shfl_xor(s1[j], 16);
-      s2[j] += __shfl_xor(s2[j], 16);
-      s1[j] += __shfl_xor(s1[j], 32);
-      s2[j] += __shfl_xor(s2[j], 32);
-    }
-    __syncthreads();
-    if (lane < 16) {
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds + aoff[m]);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds + aoff[m] + C::PLANE);
 #pragma unroll
       for (int j = 0; j < C::NI; ++j) {
-        int cl = (wn * C::NI + j) * 16 + lane;
-        ldsf[(0 * C::WM + wm) * C::BN + cl] = s1[j];
-        ldsf[(1 * C::WM + wm) * C::BN + cl] = s2[j];
+        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[m][j], 0, 0, 0);
+        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[m][j], 0, 0, 0);
+        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[m][j], 0, 0, 0);
       }
     }
-    __syncthreads();
-    if (tid < 2 * C::BN) {
-      int which = tid / C::BN, cl = tid % C::BN;
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < C::WM; ++w) t += ldsf[(which * C::WM + w) * C::BN + cl];
-      int co = cb * C::BN + cl;
-      long blk = (long)n * (tiles_x * tiles_y) + tile;
-      if (co < p.CoutPad) p.stat_partials[(blk * 2 + which) * p.CoutPad + co] = t;
-    }
   }
+  __syncthreads();
+  conv16_epilogue<C>(p, acc, ldsf, tid, lane, wm, wn, nt0, cb, n, ty0, tx0, (long)n * (tiles_x * tiles_y) + tile);
 }
 
 #undef HPFG16_STAGE_LOAD
@@ -256,8 +327,21 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(HpfgConvArgs p, int ti
 template <class C, int KIND>
 int launch_cfg(const HpfgConvArgs& a, hipStream_t st) {
   int tx = (a.W + C::TW - 1) / C::TW, ty = (a.H + C::TH - 1) / C::TH;
-  dim3 grid(tx * ty, a.N, a.CoutPad / C::BN);
-  hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND>), grid, dim3(256), 0, st, a, tx, ty);
+  if constexpr (C::TAPS == 9) {
+    // persistent grid: as many workgroups as stay resident (LDS-limited), never more than there are tiles
+    const int lds_bytes = 2 * C::BUF_BYTES + 2 * 4 * C::BN * 4;
+    int per_cu = 160 * 1024 / lds_bytes;
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    long nwork = (long)tx * ty * a.N;
+    long gx = 256L * per_cu;
+    if (gx > nwork) gx = nwork;
+    dim3 grid((unsigned)gx, a.CoutPad / C::BN);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND>), grid, dim3(256), 0, st, a, tx, ty);
+  } else {
+    dim3 grid(tx * ty, a.N, a.CoutPad / C::BN);
+    hipLaunchKernelGGL((conv1x1_bf16x3_kernel<C, KIND>), grid, dim3(256), 0, st, a, tx, ty);
+  }
   return hpfg_launch_status("conv_bf16x3_kernel");
 }
 
