@@ -28,7 +28,8 @@ static inline int hpfg_launch_status(const char* what) {
 }
 
 // ---- counter-based dropout RNG ------------------------------------------------------------------------------
-// keep(i) = fmix32(i * 0x9E3779B1 + seed) >= floor(p * 2^32); i = NHWC element index of the activated tensor.
+// One 32-bit hash serves two neighbouring elements: h = fmix32((i >> 1) * 0x9E3779B1 + seed), r16 = (i & 1) ? h >> 16 : h & 0xFFFF,
+// keep(i) = r16 >= floor(p * 65536); i = NHWC element index of the activated tensor (p is resolved to 1.5e-5).
 // Stateless, so forward consumers and backward loaders regenerate the same mask without storing it.
 __host__ __device__ static inline uint32_t hpfg_hash32(uint32_t i, uint32_t seed) {
   uint32_t h = i * 0x9E3779B1u + seed;
@@ -40,12 +41,16 @@ __host__ __device__ static inline uint32_t hpfg_hash32(uint32_t i, uint32_t seed
   return h;
 }
 __host__ __device__ static inline uint32_t hpfg_drop_threshold(float p) {
-  double t = (double)p * 4294967296.0;
-  if (t >= 4294967295.0) return 0xFFFFFFFFu;
+  double t = (double)p * 65536.0;
+  if (t >= 65535.0) return 0xFFFFu;
   return (uint32_t)t;
 }
+__host__ __device__ static inline bool hpfg_keep(uint32_t i, uint32_t seed, uint32_t thresh16) {
+  const uint32_t h = hpfg_hash32(i >> 1, seed);
+  return ((i & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= thresh16;
+}
 
-__device__ static inline float lrelu(float y) { return y > 0.f ? y : HPFG_LEAKY * y; }
+__device__ static inline float lrelu(float y) { return fmaxf(y, HPFG_LEAKY * y); }   // == y > 0 ? y : 0.01*y
 
 // Per-block cache of everything a loader needs that does not depend on the pixel.
 struct ActCtx {
@@ -62,7 +67,18 @@ __device__ static inline ActCtx make_ctx(const HpfgAct& s) {
 }
 
 __device__ static inline bool keep_elem(const HpfgAct& s, const ActCtx& cx, uint32_t e) {
-  return s.drop_mask ? s.drop_mask[e] != 0 : hpfg_hash32(e, cx.seed) >= cx.thresh;
+  return s.drop_mask ? s.drop_mask[e] != 0 : hpfg_keep(e, cx.seed, cx.thresh);
+}
+
+// keep flags of the 4 elements e..e+3 (e % 4 == 0) as a 4-bit mask: two hashes, or one 32-bit load of an explicit mask.
+__device__ static inline uint32_t keep4(const HpfgAct& s, const ActCtx& cx, uint32_t e) {
+  if (s.drop_mask) {
+    const uint32_t m = *reinterpret_cast<const uint32_t*>(s.drop_mask + e);
+    return ((m & 0xFFu) ? 1u : 0u) | ((m & 0xFF00u) ? 2u : 0u) | ((m & 0xFF0000u) ? 4u : 0u) | ((m & 0xFF000000u) ? 8u : 0u);
+  }
+  const uint32_t h0 = hpfg_hash32(e >> 1, cx.seed), h1 = hpfg_hash32((e >> 1) + 1, cx.seed);
+  return ((h0 & 0xFFFFu) >= cx.thresh ? 1u : 0u) | ((h0 >> 16) >= cx.thresh ? 2u : 0u) | ((h1 & 0xFFFFu) >= cx.thresh ? 4u : 0u) |
+         ((h1 >> 16) >= cx.thresh ? 8u : 0u);
 }
 
 // 4 channels [c, c+4) of the virtual activation `s` at image n, virtual pixel (y, x); caller guarantees the pixel is
@@ -91,9 +107,9 @@ __device__ static inline f32x4 act_load4(const HpfgAct& s, const ActCtx& cx, int
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = lrelu(z[j] * sc[j] + sh[j]);
       if (s.drop_p > 0.f) {
-        uint32_t e = (uint32_t)(pix * s.C + c);
+        const uint32_t km = keep4(s, cx, (uint32_t)(pix * s.C + c));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = keep_elem(s, cx, e + j) ? v[j] * cx.inv_keep : 0.f;
+        for (int j = 0; j < 4; ++j) v[j] = (km >> j) & 1u ? v[j] * cx.inv_keep : 0.f;
       }
       break;
     }
@@ -142,11 +158,10 @@ __device__ static inline f32x4 act_load4(const HpfgAct& s, const ActCtx& cx, int
       f32x4 k1 = *reinterpret_cast<const f32x4*>(t + HPFG_BN_K1 * s.bn_stride);
       f32x4 k2 = *reinterpret_cast<const f32x4*>(t + HPFG_BN_K2 * s.bn_stride);
       f32x4 k3 = *reinterpret_cast<const f32x4*>(t + HPFG_BN_K3 * s.bn_stride);
-      uint32_t e = (uint32_t)(pix * s.C + c);
+      const uint32_t km = s.drop_p > 0.f ? keep4(s, cx, (uint32_t)(pix * s.C + c)) : 0xFu;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float gg = g[j];
-        if (s.drop_p > 0.f) gg = keep_elem(s, cx, e + j) ? gg * cx.inv_keep : 0.f;
+        float gg = (km >> j) & 1u ? g[j] * cx.inv_keep : 0.f;
         float yv = z[j] * sc[j] + sh[j];
         gg = yv > 0.f ? gg : HPFG_LEAKY * gg;
         v[j] = k1[j] * gg + k2[j] * z[j] + k3[j];
@@ -168,11 +183,10 @@ __device__ static inline void dz_load_g_xhat(const HpfgAct& s, const ActCtx& cx,
   f32x4 rs = *reinterpret_cast<const f32x4*>(t + HPFG_BN_RSTD * s.bn_stride);
   f32x4 sc = *reinterpret_cast<const f32x4*>(t + HPFG_BN_SCALE * s.bn_stride);
   f32x4 sh = *reinterpret_cast<const f32x4*>(t + HPFG_BN_SHIFT * s.bn_stride);
-  uint32_t e = (uint32_t)(pix * s.C + c);
+  const uint32_t km = s.drop_p > 0.f ? keep4(s, cx, (uint32_t)(pix * s.C + c)) : 0xFu;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    float gg = g[j];
-    if (s.drop_p > 0.f) gg = keep_elem(s, cx, e + j) ? gg * cx.inv_keep : 0.f;
+    float gg = (km >> j) & 1u ? g[j] * cx.inv_keep : 0.f;
     float yv = z[j] * sc[j] + sh[j];
     g_out[j] = yv > 0.f ? gg : HPFG_LEAKY * gg;
     xh_out[j] = (z[j] - mu[j]) * rs[j];

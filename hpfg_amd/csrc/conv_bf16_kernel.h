@@ -2,16 +2,19 @@
 //
 // Every fp32 operand is split as x = hi + lo with hi = bf16(x), lo = bf16(x - hi); a product is evaluated as
 // hi*hi + hi*lo + lo*hi with fp32 accumulation inside v_mfma_f32_16x16x32_bf16 (the dropped lo*lo term is 2^-16 relative).
-// Three bf16 MFMAs replace sixteen fp32-input MFMAs' worth of cycles (MI355X_MICROARCH.md: f32-in MFMA = 1/16 of the bf16 rate),
-// a 5.3x higher contraction roof at ~1e-5 relative error per layer -- inside the 1e-3 parity budget (tests/test_gpu_bf16x3.py).
+// Three bf16 MFMAs replace sixteen fp32-input MFMAs' worth of cycles (MI355X_MICROARCH.md: f32-in MFMA = 1/16 of the bf16 rate).
 //
-// Same mapping, loaders, epilogue and BN partial sums as conv_kernel.h; what differs:
-//   * LDS tile: bf16 planes [channel group of 8][hi|lo][pixel slot][8 ch], 16 B per (pixel, group) so an A fragment is one
-//     ds_read_b128; the plane size is a multiple of 256 B and the 16 pixels of an MFMA row tile map to distinct 16-B slots
-//     mod 16, so every ds_read_b128 lane group is bank-conflict free;
-//   * K packing of one MFMA (K = 32): KC = 32 -> one tap x 32 input channels (small tiles, channel-rich layers);
-//     KC = 16 -> two taps x 16 input channels (16x16 tiles of the 16/32-channel layers; taps padded 9 -> 10 with zero weights);
-//   * B fragments come pre-split (hi, lo) in fragment order from hpfg_pack_weights.
+// Structure (3x3): persistent workgroups stream (tile, input-channel chunk) items through a double-buffered LDS tile.
+//   * LDS tile: bf16 planes [channel group of 8][hi|lo][pixel slot][8 ch]; one A fragment = one ds_read_b128; plane size is a
+//     multiple of 256 B and the 16 pixels of an MFMA tile map to distinct 16-B slots mod 16 -> conflict-free reads.
+//   * K packing of one MFMA (K = 32): KC = 32 -> one tap x 32 input channels; KC = 16 -> two taps x 16 input channels
+//     (16x16 tiles of the 16/32-channel layers; taps padded 9 -> 10 with zero weights).
+//   * The MFMA is issued as D = W^T-fragment x pixel-fragment, so a lane ends up with 4 consecutive output channels of one
+//     pixel: the epilogue is one 16-B store per lane per tile pair, 1 KB contiguous per wave instruction.
+//   * Staging is the instruction-count hot spot of the thin (16/32-channel, 224^2/112^2) layers -- they are VALU-issue bound,
+//     not MFMA bound -- so everything pixel-invariant (piece coordinates, LDS offsets, BatchNorm tables of the chunk) is
+//     hoisted into registers, addresses are 32-bit, and the producer chain (BN + LeakyReLU + Dropout | MaxPool | bilinear)
+//     is specialised per loader kind at compile time.
 #pragma once
 #include "common.h"
 
@@ -26,16 +29,16 @@ struct Cfg {
   static constexpr int BN = 16 * NI * WN;
   static constexpr int HALO = TAPS == 9 ? 1 : 0;
   static constexpr int HP = TH + 2 * HALO, WP = TW + 2 * HALO;
-  // row stride in 16-B slots: an MFMA row tile's 16 pixels must hit 16 distinct slots mod 16
-  static constexpr int RS = TW == 16 ? WP : (TAPS == 9 ? 24 : 8);
+  static constexpr int RS = TW == 16 ? WP : (TAPS == 9 ? 24 : 8);   // row stride in 16-B slots
   static constexpr int NSLOT = (HP * RS + 15) / 16 * 16;
-  static constexpr int NG = KC / 8;                      // channel groups of 8
-  static constexpr int PLANE = NSLOT * 16;               // bytes
+  static constexpr int NG = KC / 8;
+  static constexpr int PLANE = NSLOT * 16;
   static constexpr int BUF_BYTES = NG * 2 * PLANE;
-  static constexpr int KSTEPS = TAPS == 1 ? 1 : (KC == 32 ? 9 : 5);   // MFMA k-steps per input-channel chunk
-  static constexpr int NPIECE = HP * WP * NG;            // (pixel, group) staging pieces per chunk
+  static constexpr int KSTEPS = TAPS == 1 ? 1 : (KC == 32 ? 9 : 5);
+  static constexpr int NPIECE = HP * WP * NG;
   static constexpr int NLD = (NPIECE + 255) / 256;
   static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(256 % NG == 0, "a thread must keep one channel group");
   static_assert(KC == 32 || (KC == 16 && TAPS == 9), "two-tap K packing only for 3x3");
   static_assert(TAPS == 1 || NLD + 2 <= KSTEPS, "stage pipeline must fit into the k-steps of a chunk");
 };
@@ -51,105 +54,285 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
   }
 }
 
-#define HPFG16_STAGE_LOAD(I, CH, NN, TY, TX, V0, V1)                                                                     \
-  {                                                                                                                      \
-    const int idx_ = tid + (I) * 256;                                                                                    \
-    V0 = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                      \
-    V1 = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                      \
-    if (idx_ < C::NPIECE) {                                                                                              \
-      const int pix_ = idx_ / C::NG, g_ = idx_ % C::NG;                                                                  \
-      const int gy_ = (TY) + pix_ / C::WP - C::HALO, gx_ = (TX) + pix_ % C::WP - C::HALO;                                \
-      if (gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W && !(p.math & 0x400)) {                                             \
-        V0 = kind_load4<KIND>(p.a0, cx0, p.a1, cx1, NN, gy_, gx_, (CH) * C::KC + g_ * 8);                                \
-        V1 = kind_load4<KIND>(p.a0, cx0, p.a1, cx1, NN, gy_, gx_, (CH) * C::KC + g_ * 8 + 4);                            \
-      }                                                                                                                  \
-    }                                                                                                                    \
-  }
-#define HPFG16_STAGE_STORE(I, BUF, V0, V1)                                                                               \
-  {                                                                                                                      \
-    const int idx_ = tid + (I) * 256;                                                                                    \
-    if (idx_ < C::NPIECE) {                                                                                              \
-      const int pix_ = idx_ / C::NG, g_ = idx_ % C::NG;                                                                  \
-      const int slot_ = (pix_ / C::WP) * C::RS + pix_ % C::WP;                                                           \
-      bf16x8 hi_, lo_;                                                                                                   \
-      split8(V0, V1, hi_, lo_);                                                                                          \
-      *reinterpret_cast<bf16x8*>((BUF) + (g_ * 2 + 0) * C::PLANE + slot_ * 16) = hi_;                                    \
-      *reinterpret_cast<bf16x8*>((BUF) + (g_ * 2 + 1) * C::PLANE + slot_ * 16) = lo_;                                    \
-    }                                                                                                                    \
-  }
-// B fragments of global k-step KS (= chunk * KSTEPS + step): [ks][ntile][hi|lo][64 lanes] x 16 B
-#define HPFG16_LOAD_B(KS, BH, BL)                                                                                        \
-  _Pragma("unroll") for (int j = 0; j < C::NI; ++j) {                                                                    \
-    const bf16x8* q_ = wpk + (((long)(KS) * ntn + nt0 + j) * 2) * 64 + lane;                                             \
-    BH[j] = q_[0];                                                                                                       \
-    BL[j] = q_[64];                                                                                                      \
-  }
+__device__ __forceinline__ f32x4 ld4(const float* base, int off) { return *reinterpret_cast<const f32x4*>(base + off); }
 
-// Epilogue shared by both kernels: + bias, store the raw output tile, per-channel partial sums for BatchNorm.
+// ---- per-kind staging: issue_piece() puts the raw global loads of one 8-channel piece in flight, finish_piece() applies the
+// ---- producer chain.  Raw loads per piece: PLAIN/BNACT 2, DZ 4 (z + dA), POOL 8 (2x2 pixels), CAT 8 (4 bilinear taps).
+template <int KIND>
+struct RawCount { static constexpr int N = KIND == HPFG_KIND_POOL || KIND == HPFG_KIND_CAT ? 8 : (KIND == HPFG_KIND_DZ ? 4 : 2); };
+
+struct Tab {   // per-chunk per-channel tables of this thread's 8 channels
+  f32x4 sc[2], sh[2], k1[2], k2[2], k3[2];
+};
+
+template <int KIND>
+__device__ __forceinline__ void load_tables(Tab& t, const HpfgConvArgs& p, int c0, bool chvalid) {
+  if (KIND == HPFG_KIND_PLAIN || !chvalid) return;
+  if (KIND == HPFG_KIND_CAT && c0 >= p.a0.C) return;
+  const float* b = p.a0.bn + p.a0.bn_coff + c0;
+  const int st = p.a0.bn_stride;
+  t.sc[0] = ld4(b, HPFG_BN_SCALE * st);
+  t.sc[1] = ld4(b, HPFG_BN_SCALE * st + 4);
+  t.sh[0] = ld4(b, HPFG_BN_SHIFT * st);
+  t.sh[1] = ld4(b, HPFG_BN_SHIFT * st + 4);
+  if (KIND == HPFG_KIND_DZ) {
+    t.k1[0] = ld4(b, HPFG_BN_K1 * st);
+    t.k1[1] = ld4(b, HPFG_BN_K1 * st + 4);
+    t.k2[0] = ld4(b, HPFG_BN_K2 * st);
+    t.k2[1] = ld4(b, HPFG_BN_K2 * st + 4);
+    t.k3[0] = ld4(b, HPFG_BN_K3 * st);
+    t.k3[1] = ld4(b, HPFG_BN_K3 * st + 4);
+  }
+}
+
+// bilinear x2 (align_corners=True) source taps of output coordinate o for a low-res extent L
+__device__ __forceinline__ void up_coord(int o, int L, int& i0, int& i1, float& w1) {
+  const float r = L > 1 ? (float)(L - 1) / (float)(2 * L - 1) : 0.f;
+  const float f = r * (float)o;
+  i0 = (int)f;
+  i1 = i0 + (i0 < L - 1 ? 1 : 0);
+  w1 = f - (float)i0;
+}
+
+template <int KIND>
+__device__ __forceinline__ void issue_piece(f32x4 (&raw)[RawCount<KIND>::N], const HpfgConvArgs& p, const ActCtx& cx0, int n, int gy, int gx, int c0,
+                                            bool ok) {
+#pragma unroll
+  for (int i = 0; i < RawCount<KIND>::N; ++i) raw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!ok) return;
+  const HpfgAct& a = p.a0;
+  if (KIND == HPFG_KIND_PLAIN) {
+    if (a.mode == HPFG_ACT_STRIDED) {
+      raw[0] = act_load4_mode<HPFG_ACT_STRIDED>(a, cx0, n, gy, gx, c0);
+      raw[1] = act_load4_mode<HPFG_ACT_STRIDED>(a, cx0, n, gy, gx, c0 + 4);
+    } else {
+      const int off = ((n * a.Hs + gy) * a.Ws + gx) * a.pstride + c0;
+      raw[0] = ld4(a.z, off);
+      if (c0 + 4 < a.C) raw[1] = ld4(a.z, off + 4);
+    }
+  } else if (KIND == HPFG_KIND_BNACT || (KIND == HPFG_KIND_CAT && c0 < a.C)) {
+    const int off = ((n * a.Hs + gy) * a.Ws + gx) * a.pstride + c0;
+    raw[0] = ld4(a.z, off);
+    raw[1] = ld4(a.z, off + 4);
+  } else if (KIND == HPFG_KIND_POOL) {
+    const int off = ((n * a.Hs + 2 * gy) * a.Ws + 2 * gx) * a.pstride + c0;
+    const int ro = a.Ws * a.pstride;
+    raw[0] = ld4(a.z, off);
+    raw[1] = ld4(a.z, off + 4);
+    raw[2] = ld4(a.z, off + a.pstride);
+    raw[3] = ld4(a.z, off + a.pstride + 4);
+    raw[4] = ld4(a.z, off + ro);
+    raw[5] = ld4(a.z, off + ro + 4);
+    raw[6] = ld4(a.z, off + ro + a.pstride);
+    raw[7] = ld4(a.z, off + ro + a.pstride + 4);
+  } else if (KIND == HPFG_KIND_CAT) {   // upsampled half
+    const HpfgAct& u = p.a1;
+    int y0, y1, x0, x1;
+    float wy, wx;
+    up_coord(gy, u.Hs, y0, y1, wy);
+    up_coord(gx, u.Ws, x0, x1, wx);
+    const int cb = n * u.Hs * u.Ws * u.pstride + (c0 - a.C);
+    const int o00 = cb + (y0 * u.Ws + x0) * u.pstride, o01 = cb + (y0 * u.Ws + x1) * u.pstride;
+    const int o10 = cb + (y1 * u.Ws + x0) * u.pstride, o11 = cb + (y1 * u.Ws + x1) * u.pstride;
+    raw[0] = ld4(u.z, o00);
+    raw[1] = ld4(u.z, o00 + 4);
+    raw[2] = ld4(u.z, o01);
+    raw[3] = ld4(u.z, o01 + 4);
+    raw[4] = ld4(u.z, o10);
+    raw[5] = ld4(u.z, o10 + 4);
+    raw[6] = ld4(u.z, o11);
+    raw[7] = ld4(u.z, o11 + 4);
+  } else {   // DZ
+    const int pix = (n * a.Hs + gy) * a.Ws + gx;
+    raw[0] = ld4(a.z, pix * a.pstride + c0);
+    raw[1] = ld4(a.z, pix * a.pstride + c0 + 4);
+    raw[2] = ld4(a.aux, pix * a.aux_pstride + c0);
+    raw[3] = ld4(a.aux, pix * a.aux_pstride + c0 + 4);
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ void finish_piece(f32x4& v0, f32x4& v1, const f32x4 (&raw)[RawCount<KIND>::N], const Tab& t, const HpfgConvArgs& p,
+                                             const ActCtx& cx0, int n, int gy, int gx, int c0, bool ok) {
+  v0 = f32x4{0.f, 0.f, 0.f, 0.f};
+  v1 = v0;
+  if (!ok) return;
+  const HpfgAct& a = p.a0;
+  if (KIND == HPFG_KIND_PLAIN) {
+    v0 = raw[0];
+    v1 = raw[1];
+  } else if (KIND == HPFG_KIND_BNACT || (KIND == HPFG_KIND_CAT && c0 < a.C)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v0[j] = lrelu(raw[0][j] * t.sc[0][j] + t.sh[0][j]);
+      v1[j] = lrelu(raw[1][j] * t.sc[1][j] + t.sh[1][j]);
+    }
+    if (KIND == HPFG_KIND_BNACT && a.drop_p > 0.f) {
+      const uint32_t e = (uint32_t)(((n * a.Hs + gy) * a.Ws + gx) * a.C + c0);
+      const uint32_t k0 = keep4(a, cx0, e), k1 = keep4(a, cx0, e + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v0[j] = (k0 >> j) & 1u ? v0[j] * cx0.inv_keep : 0.f;
+        v1[j] = (k1 >> j) & 1u ? v1[j] * cx0.inv_keep : 0.f;
+      }
+    }
+  } else if (KIND == HPFG_KIND_POOL) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float m0 = lrelu(raw[0][j] * t.sc[0][j] + t.sh[0][j]), m1 = lrelu(raw[1][j] * t.sc[1][j] + t.sh[1][j]);
+#pragma unroll
+      for (int q = 1; q < 4; ++q) {
+        m0 = fmaxf(m0, lrelu(raw[2 * q][j] * t.sc[0][j] + t.sh[0][j]));
+        m1 = fmaxf(m1, lrelu(raw[2 * q + 1][j] * t.sc[1][j] + t.sh[1][j]));
+      }
+      v0[j] = m0;
+      v1[j] = m1;
+    }
+  } else if (KIND == HPFG_KIND_CAT) {
+    const HpfgAct& u = p.a1;
+    int i0, i1;
+    float wy1, wx1;
+    up_coord(gy, u.Hs, i0, i1, wy1);
+    up_coord(gx, u.Ws, i0, i1, wx1);
+    const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v0[j] = wy0 * (wx0 * raw[0][j] + wx1 * raw[2][j]) + wy1 * (wx0 * raw[4][j] + wx1 * raw[6][j]);
+      v1[j] = wy0 * (wx0 * raw[1][j] + wx1 * raw[3][j]) + wy1 * (wx0 * raw[5][j] + wx1 * raw[7][j]);
+    }
+  } else {   // DZ: k1*g + k2*z + k3, g = dA * dropmask/(1-p) * lrelu'(scale*z+shift)
+    uint32_t k0 = 0xFu, k1 = 0xFu;
+    if (a.drop_p > 0.f) {
+      const uint32_t e = (uint32_t)(((n * a.Hs + gy) * a.Ws + gx) * a.C + c0);
+      k0 = keep4(a, cx0, e);
+      k1 = keep4(a, cx0, e + 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float g0 = (k0 >> j) & 1u ? raw[2][j] * cx0.inv_keep : 0.f, g1 = (k1 >> j) & 1u ? raw[3][j] * cx0.inv_keep : 0.f;
+      g0 = raw[0][j] * t.sc[0][j] + t.sh[0][j] > 0.f ? g0 : HPFG_LEAKY * g0;
+      g1 = raw[1][j] * t.sc[1][j] + t.sh[1][j] > 0.f ? g1 : HPFG_LEAKY * g1;
+      v0[j] = t.k1[0][j] * g0 + t.k2[0][j] * raw[0][j] + t.k3[0][j];
+      v1[j] = t.k1[1][j] * g1 + t.k2[1][j] * raw[1][j] + t.k3[1][j];
+    }
+  }
+}
+
+// per-thread, tile-invariant description of staging piece i: local pixel (ly, lx) and LDS byte offset
+struct Piece {
+  int ly, lx, lds, ok;
+};
 template <class C>
-__device__ __forceinline__ void conv16_epilogue(const HpfgConvArgs& p, f32x4 (&acc)[C::MI][C::NI], float* ldsf, int tid, int lane, int wm, int wn,
-                                                int nt0, int cb, int n, int ty0, int tx0, long blk) {
-  const int H = p.H, W = p.W;
-  float s1[C::NI], s2[C::NI];
+__device__ __forceinline__ Piece make_piece(int tid, int i) {
+  Piece q;
+  const int idx = tid + i * 256;
+  const int pix = idx / C::NG, g = idx % C::NG;
+  q.ok = idx < C::NPIECE;
+  q.ly = pix / C::WP - C::HALO;
+  q.lx = pix % C::WP - C::HALO;
+  q.lds = (g * 2) * C::PLANE + ((pix / C::WP) * C::RS + pix % C::WP) * 16;
+  return q;
+}
+
+template <class C>
+__device__ __forceinline__ void store_piece(unsigned char* buf, const Piece& q, const f32x4& v0, const f32x4& v1) {
+  if (!q.ok) return;
+  bf16x8 hi, lo;
+  split8(v0, v1, hi, lo);
+  *reinterpret_cast<bf16x8*>(buf + q.lds) = hi;
+  *reinterpret_cast<bf16x8*>(buf + q.lds + C::PLANE) = lo;
+}
+
+template <class C>
+__device__ __forceinline__ void load_b(bf16x8 (&bh)[C::NI], bf16x8 (&bl)[C::NI], const bf16x8* wpk, int ks, int ntn, int nt0, int lane) {
 #pragma unroll
   for (int j = 0; j < C::NI; ++j) {
-    s1[j] = 0.f;
-    s2[j] = 0.f;
-    const int co = (nt0 + j) * 16 + (lane & 15);
-    const float b = (p.bias && co < p.CoutPad) ? p.bias[co] : 0.f;
+    const bf16x8* q = wpk + ((ks * ntn + nt0 + j) * 2) * 64 + lane;
+    bh[j] = q[0];
+    bl[j] = q[64];
+  }
+}
+
+// Epilogue: acc holds D[cout = (lane>>4)*4 + r][pixel = lane & 15] per (m, j) tile -> one 16-B store per lane; BN partial sums.
+template <class C>
+__device__ __forceinline__ void conv16_epilogue(const HpfgConvArgs& p, f32x4 (&acc)[C::MI][C::NI], float* ldsf, int tid, int lane, int wm, int wn,
+                                                int nt0, int cb, int n, int ty0, int tx0, int blk) {
+  const int H = p.H, W = p.W;
+  const bool vec = (p.Cout & 3) == 0 && (p.out_pstride & 3) == 0;
+  f32x4 s1[C::NI], s2[C::NI];
+#pragma unroll
+  for (int j = 0; j < C::NI; ++j) {
+    s1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s2[j] = s1[j];
+    const int co = (nt0 + j) * 16 + (lane >> 4) * 4;
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && co < p.CoutPad) b = ld4(p.bias, co);
 #pragma unroll
     for (int m = 0; m < C::MI; ++m) {
+      const int pxl = (wm * C::MI + m) * 16 + (lane & 15);
+      const int gy = ty0 + pxl / C::TW, gx = tx0 + pxl % C::TW;
+      if (gy < H && gx < W && co < p.Cout) {
+        f32x4 v = acc[m][j] + b;
+        float* o = p.out + ((n * H + gy) * W + gx) * p.out_pstride + co;
+        if (vec) {
+          *reinterpret_cast<f32x4*>(o) = v;
+        } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int pxl = (wm * C::MI + m) * 16 + (lane >> 4) * 4 + r;
-        int gy = ty0 + pxl / C::TW, gx = tx0 + pxl % C::TW;
-        float v = acc[m][j][r] + b;
-        if (gy < H && gx < W && co < p.Cout) {
-          if (!(p.math & 0x100)) p.out[((long)(n * H + gy) * W + gx) * p.out_pstride + co] = v;
-          s1[j] += v;
-          s2[j] += v * v;
+          for (int r = 0; r < 4; ++r) {
+            if (co + r < p.Cout) o[r] = v[r];
+            else v[r] = 0.f;
+          }
         }
+        s1[j] += v;
+        s2[j] += v * v;
       }
     }
   }
   if (p.stat_partials) {
 #pragma unroll
-    for (int j = 0; j < C::NI; ++j) {
-      s1[j] += __shfl_xor(s1[j], 16);
-      s2[j] += __shfl_xor(s2[j], 16);
-      s1[j] += __shfl_xor(s1[j], 32);
-      s2[j] += __shfl_xor(s2[j], 32);
-    }
-    if (lane < 16) {
+    for (int j = 0; j < C::NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = s1[j][r], b = s2[j][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o);
+          b += __shfl_xor(b, o);
+        }
+        s1[j][r] = a;
+        s2[j][r] = b;
+      }
+    if ((lane & 15) == 0) {
 #pragma unroll
       for (int j = 0; j < C::NI; ++j) {
-        int cl = (wn * C::NI + j) * 16 + lane;
-        ldsf[(0 * C::WM + wm) * C::BN + cl] = s1[j];
-        ldsf[(1 * C::WM + wm) * C::BN + cl] = s2[j];
+        const int cl = (wn * C::NI + j) * 16 + (lane >> 4) * 4;
+        *reinterpret_cast<f32x4*>(ldsf + (0 * C::WM + wm) * C::BN + cl) = s1[j];
+        *reinterpret_cast<f32x4*>(ldsf + (1 * C::WM + wm) * C::BN + cl) = s2[j];
       }
     }
     __syncthreads();
     if (tid < 2 * C::BN) {
-      int which = tid / C::BN, cl = tid % C::BN;
+      const int which = tid / C::BN, cl = tid % C::BN;
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < C::WM; ++w) t += ldsf[(which * C::WM + w) * C::BN + cl];
-      int co = cb * C::BN + cl;
-      if (co < p.CoutPad) p.stat_partials[(blk * 2 + which) * p.CoutPad + co] = t;
+      const int co = cb * C::BN + cl;
+      if (co < p.CoutPad) p.stat_partials[((long)blk * 2 + which) * p.CoutPad + co] = t;
     }
     __syncthreads();
   }
 }
 
-// 3x3: persistent workgroups.  A workgroup walks tiles w = blockIdx.x, blockIdx.x + gridDim.x, ... (tile-major inside an image,
-// so consecutive tiles share halos in L2) and streams (tile, input-channel chunk) items through a double-buffered LDS tile:
-// while the MFMAs of item i run, the activated tile of item i+1 -- the next chunk, or chunk 0 of the workgroup's NEXT tile --
-// is fetched piecewise into the other buffer, so the load latency of a tile is hidden behind the previous tile's MFMAs and
-// output stores even for single-chunk (16-channel) layers.  One barrier per item.
+#define HPFG16_MFMA3(ACC, AH, AL, BH, BL)                              \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BH, AH, ACC, 0, 0, 0); \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BL, AH, ACC, 0, 0, 0); \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BH, AL, ACC, 0, 0, 0);
+
 template <class C, int KIND>
-__global__ __launch_bounds__(256) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, (C::NI >= 4 || (C::NI >= 2 && RawCount<KIND>::N >= 4)) ? 2 : 3) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   static_assert(C::TAPS == 9, "persistent kernel is the 3x3 path");
   constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
+  constexpr int NR = RawCount<KIND>::N;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * C::BUF_BYTES + STAT_BYTES];
   float* ldsf = reinterpret_cast<float*>(lds + 2 * C::BUF_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -157,7 +340,7 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(HpfgConvArgs p, int ti
   const int cb = blockIdx.y;
   const int H = p.H, W = p.W;
   const int ntiles = tiles_x * tiles_y, nwork = ntiles * p.N;
-  const ActCtx cx0 = make_ctx(p.a0), cx1 = make_ctx(p.a1);
+  const ActCtx cx0 = make_ctx(p.a0);
 
   f32x4 acc[C::MI][C::NI];
 #pragma unroll
@@ -170,9 +353,21 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(HpfgConvArgs p, int ti
   int aoff[C::MI];
 #pragma unroll
   for (int m = 0; m < C::MI; ++m) {
-    int pxl = (wm * C::MI + m) * 16 + (lane & 15);
+    const int pxl = (wm * C::MI + m) * 16 + (lane & 15);
     aoff[m] = (gl * 2) * C::PLANE + ((pxl / C::TW) * C::RS + (pxl % C::TW)) * 16;
   }
+  // byte offsets of the k-steps' taps for this lane (KC=16 packs taps 2s, 2s+1 into one MFMA; tap 9 re-reads tap 8: zero weights)
+  int toff[C::KSTEPS];
+#pragma unroll
+  for (int s = 0; s < C::KSTEPS; ++s) {
+    int tap = C::KC == 32 ? s : 2 * s + (kg >> 1);
+    tap = tap > 8 ? 8 : tap;
+    toff[s] = ((tap / 3) * C::RS + (tap % 3)) * 16;
+  }
+  Piece pc[C::NLD];
+#pragma unroll
+  for (int i = 0; i < C::NLD; ++i) pc[i] = make_piece<C>(tid, i);
+  const int g8 = (tid % C::NG) * 8;          // this thread's channel group inside a chunk
 
   const int cin_total = p.a0.C + p.a1.C;
   const int nchunks = (cin_total + C::KC - 1) / C::KC;
@@ -184,63 +379,70 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(HpfgConvArgs p, int ti
   if (w >= nwork) return;
   int n = w / ntiles, tl = w % ntiles;
   int ty0 = (tl / tiles_x) * C::TH, tx0 = (tl % tiles_x) * C::TW;
-  for (int i = 0; i < C::NLD; ++i) {
-    f32x4 v0, v1;
-    HPFG16_STAGE_LOAD(i, 0, n, ty0, tx0, v0, v1)
-    HPFG16_STAGE_STORE(i, lds, v0, v1)
+  Tab tab;
+  {
+    const int c0 = g8;
+    const bool chv = c0 < cin_total;
+    load_tables<KIND>(tab, p, c0, chv);
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) {
+      const int gy = ty0 + pc[i].ly, gx = tx0 + pc[i].lx;
+      const bool ok = pc[i].ok && chv && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      f32x4 raw[NR], v0, v1;
+      issue_piece<KIND>(raw, p, cx0, n, gy, gx, c0, ok);
+      finish_piece<KIND>(v0, v1, raw, tab, p, cx0, n, gy, gx, c0, ok);
+      store_piece<C>(lds, pc[i], v0, v1);
+    }
   }
   bf16x8 bh[C::NI], bl[C::NI], nh[C::NI], nl[C::NI];
-  HPFG16_LOAD_B(0, bh, bl)
+  load_b<C>(bh, bl, wpk, 0, ntn, nt0, lane);
   __syncthreads();
   int item = 0;
   while (true) {
     for (int ch = 0; ch < nchunks; ++ch, ++item) {
       const unsigned char* cur = lds + (item & 1) * C::BUF_BYTES;
       unsigned char* nxt = lds + ((item + 1) & 1) * C::BUF_BYTES;
-      // the item after this one: next chunk of this tile, or chunk 0 of this workgroup's next tile
       const bool last_chunk = ch + 1 == nchunks;
-      const int wn_ = w + (int)gridDim.x;
-      const bool more = !last_chunk || wn_ < nwork;
+      const int w2 = w + (int)gridDim.x;
+      const bool more = !last_chunk || w2 < nwork;
       const int nch = last_chunk ? 0 : ch + 1;
       int nn = n, nty = ty0, ntx = tx0;
       if (last_chunk && more) {
-        nn = wn_ / ntiles;
-        const int t2 = wn_ % ntiles;
+        nn = w2 / ntiles;
+        const int t2 = w2 % ntiles;
         nty = (t2 / tiles_x) * C::TH;
         ntx = (t2 % tiles_x) * C::TW;
       }
-      f32x4 s0a = {0.f, 0.f, 0.f, 0.f}, s0b = s0a, s1a = s0a, s1b = s0a;
-#pragma unroll 1
+      const int c0n = nch * C::KC + g8;
+      const bool chvn = more && c0n < cin_total;
+      if (more && nchunks > 1) load_tables<KIND>(tab, p, c0n, chvn);
+      f32x4 raw[2][NR];
+#pragma unroll
       for (int s = 0; s < C::KSTEPS; ++s) {
-        if (more) {
-          if (s >= 2 && s - 2 < C::NLD) {
-            if ((s & 1) == 0) HPFG16_STAGE_STORE(s - 2, nxt, s0a, s0b) else HPFG16_STAGE_STORE(s - 2, nxt, s1a, s1b)
-          }
-          if (s < C::NLD) {
-            if ((s & 1) == 0) HPFG16_STAGE_LOAD(s, nch, nn, nty, ntx, s0a, s0b) else HPFG16_STAGE_LOAD(s, nch, nn, nty, ntx, s1a, s1b)
-          }
-        }
-        if (!(p.math & 0x800)) {
-          if (s + 1 < C::KSTEPS) {
-            HPFG16_LOAD_B(ch * C::KSTEPS + s + 1, nh, nl)
-          } else if (more) {
-            HPFG16_LOAD_B(nch * C::KSTEPS, nh, nl)
+        if (s >= 2 && s - 2 < C::NLD) {        // finish the piece issued two k-steps ago and park it in the other LDS buffer
+          const int i = s - 2 < C::NLD ? s - 2 : 0;
+          const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
+          const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
+          if (more) {
+            f32x4 v0, v1;
+            finish_piece<KIND>(v0, v1, raw[i & 1], tab, p, cx0, nn, gy, gx, c0n, ok);
+            store_piece<C>(nxt, pc[i], v0, v1);
           }
         }
-        int tap = C::KC == 32 ? s : 2 * s + (kg >> 1);
-        tap = tap > 8 ? 8 : tap;
-        const int toff = ((tap / 3) * C::RS + (tap % 3)) * 16;
-        if (!(p.math & 0x200))
+        if (s < C::NLD) {
+          const int i = s < C::NLD ? s : 0;
+          const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
+          const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
+          issue_piece<KIND>(raw[i & 1], p, cx0, nn, gy, gx, c0n, ok);
+        }
+        if (s + 1 < C::KSTEPS) load_b<C>(nh, nl, wpk, ch * C::KSTEPS + s + 1, ntn, nt0, lane);
+        else if (more) load_b<C>(nh, nl, wpk, nch * C::KSTEPS, ntn, nt0, lane);
 #pragma unroll
         for (int m = 0; m < C::MI; ++m) {
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(cur + aoff[m] + toff);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(cur + aoff[m] + toff + C::PLANE);
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(cur + aoff[m] + toff[s]);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(cur + aoff[m] + toff[s] + C::PLANE);
 #pragma unroll
-          for (int j = 0; j < C::NI; ++j) {
-            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[m][j], 0, 0, 0);
-            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[m][j], 0, 0, 0);
-            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[m][j], 0, 0, 0);
-          }
+          for (int j = 0; j < C::NI; ++j) { HPFG16_MFMA3(acc[m][j], ah, al, bh[j], bl[j]) }
         }
 #pragma unroll
         for (int j = 0; j < C::NI; ++j) {
@@ -250,7 +452,7 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(HpfgConvArgs p, int ti
       }
       __syncthreads();
     }
-    conv16_epilogue<C>(p, acc, ldsf, tid, lane, wm, wn, nt0, cb, n, ty0, tx0, (long)w);
+    conv16_epilogue<C>(p, acc, ldsf, tid, lane, wm, wn, nt0, cb, n, ty0, tx0, w);
 #pragma unroll
     for (int m = 0; m < C::MI; ++m)
 #pragma unroll
@@ -269,6 +471,7 @@ template <class C, int KIND>
 __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   static_assert(C::TAPS == 1, "1x1 path");
   constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
+  constexpr int NR = RawCount<KIND>::N;
   __shared__ __attribute__((aligned(16))) unsigned char lds[C::BUF_BYTES + STAT_BYTES];
   float* ldsf = reinterpret_cast<float*>(lds + C::BUF_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -276,7 +479,7 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int
   const int tile = blockIdx.x, n = blockIdx.y, cb = blockIdx.z;
   const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
   const int H = p.H, W = p.W;
-  const ActCtx cx0 = make_ctx(p.a0), cx1 = make_ctx(p.a1);
+  const ActCtx cx0 = make_ctx(p.a0);
   f32x4 acc[C::MI][C::NI];
 #pragma unroll
   for (int m = 0; m < C::MI; ++m)
@@ -286,52 +489,54 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int
   int aoff[C::MI];
 #pragma unroll
   for (int m = 0; m < C::MI; ++m) {
-    int pxl = (wm * C::MI + m) * 16 + (lane & 15);
+    const int pxl = (wm * C::MI + m) * 16 + (lane & 15);
     aoff[m] = (kg * 2) * C::PLANE + ((pxl / C::TW) * C::RS + (pxl % C::TW)) * 16;
   }
+  const int g8 = (tid % C::NG) * 8;
   const int cin_total = p.a0.C + p.a1.C;
   const int nchunks = (cin_total + C::KC - 1) / C::KC;
   const int ntn = p.CoutPad / 16;
   const int nt0 = (cb * C::WN + wn) * C::NI;
   const bf16x8* wpk = reinterpret_cast<const bf16x8*>(p.wpk);
+  Tab tab;
   for (int ch = 0; ch < nchunks; ++ch) {
+    const int c0 = ch * C::KC + g8;
+    const bool chv = c0 < cin_total;
+    load_tables<KIND>(tab, p, c0, chv);
     __syncthreads();
+#pragma unroll
     for (int i = 0; i < C::NLD; ++i) {
-      f32x4 v0, v1;
-      HPFG16_STAGE_LOAD(i, ch, n, ty0, tx0, v0, v1)
-      HPFG16_STAGE_STORE(i, lds, v0, v1)
+      const Piece q = make_piece<C>(tid, i);
+      const int gy = ty0 + q.ly, gx = tx0 + q.lx;
+      const bool ok = q.ok && chv && gy < H && gx < W;
+      f32x4 raw[NR], v0, v1;
+      issue_piece<KIND>(raw, p, cx0, n, gy, gx, c0, ok);
+      finish_piece<KIND>(v0, v1, raw, tab, p, cx0, n, gy, gx, c0, ok);
+      store_piece<C>(lds, q, v0, v1);
     }
     bf16x8 bh[C::NI], bl[C::NI];
-    HPFG16_LOAD_B(ch, bh, bl)
+    load_b<C>(bh, bl, wpk, ch, ntn, nt0, lane);
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < C::MI; ++m) {
       const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds + aoff[m]);
       const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds + aoff[m] + C::PLANE);
 #pragma unroll
-      for (int j = 0; j < C::NI; ++j) {
-        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[m][j], 0, 0, 0);
-        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[m][j], 0, 0, 0);
-        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[m][j], 0, 0, 0);
-      }
+      for (int j = 0; j < C::NI; ++j) { HPFG16_MFMA3(acc[m][j], ah, al, bh[j], bl[j]) }
     }
   }
   __syncthreads();
-  conv16_epilogue<C>(p, acc, ldsf, tid, lane, wm, wn, nt0, cb, n, ty0, tx0, (long)n * (tiles_x * tiles_y) + tile);
+  conv16_epilogue<C>(p, acc, ldsf, tid, lane, wm, wn, nt0, cb, n, ty0, tx0, n * (tiles_x * tiles_y) + tile);
 }
-
-#undef HPFG16_STAGE_LOAD
-#undef HPFG16_STAGE_STORE
-#undef HPFG16_LOAD_B
 
 template <class C, int KIND>
 int launch_cfg(const HpfgConvArgs& a, hipStream_t st) {
   int tx = (a.W + C::TW - 1) / C::TW, ty = (a.H + C::TH - 1) / C::TH;
   if constexpr (C::TAPS == 9) {
-    // persistent grid: as many workgroups as stay resident (LDS-limited), never more than there are tiles
     const int lds_bytes = 2 * C::BUF_BYTES + 2 * 4 * C::BN * 4;
     int per_cu = 160 * 1024 / lds_bytes;
-    if (per_cu > 4) per_cu = 4;
+    const int reg_cap = (C::NI >= 4 || (C::NI >= 2 && RawCount<KIND>::N >= 4)) ? 2 : 3;   // matches __launch_bounds__
+    if (per_cu > reg_cap) per_cu = reg_cap;
     if (per_cu < 1) per_cu = 1;
     long nwork = (long)tx * ty * a.N;
     long gx = 256L * per_cu;
@@ -349,7 +554,7 @@ template <int KIND, int TAPS>
 int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st) {
   const bool big = (a.H % 16 == 0) && (a.W % 16 == 0);
   const int cp = a.CoutPad;
-  constexpr int KCB = TAPS == 9 ? 16 : 32;     // 16x16 tiles of 3x3 convs use the two-tap K packing
+  constexpr int KCB = TAPS == 9 ? 16 : 32;
   if (big) {
     if (cp % 64 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 4, TAPS, KCB>, KIND>(a, st);
     if (cp % 32 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 2, TAPS, KCB>, KIND>(a, st);

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void materialize_kernel(HpfgAct a0, HpfgAct a1
 __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ out, long n, uint32_t thresh, uint32_t seed0,
                                                            const uint32_t* __restrict__ seed_dev) {
   const uint32_t seed = seed0 + (seed_dev ? *seed_dev : 0u);
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = hpfg_hash32((uint32_t)i, seed) >= thresh ? 1 : 0;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = hpfg_keep((uint32_t)i, seed, thresh) ? 1 : 0;
 }
 
 // MaxPool2d(2) backward, fused with the skip-gradient accumulation: dA[n, 2yp+dy*, 2xp+dx*, c] += dP[n,yp,xp,c]

@@ -1,7 +1,8 @@
 """Oracle (test infrastructure): numpy restatement of the HIP path's counter-based dropout RNG.
 
 The reference draws dropout masks from torch's Philox/MT streams (nn.Dropout, model/unet.py:21), which cannot be reproduced
-on the device; the HIP path instead uses  keep(i) = fmix32(i*0x9E3779B1 + seed) >= floor(p*2^32)  over the NHWC element index
+on the device; the HIP path instead uses  h = fmix32((i>>1)*0x9E3779B1 + seed), r16 = (i&1) ? h>>16 : h&0xFFFF,
+keep(i) = r16 >= floor(p*65536)  over the NHWC element index
 (hpfg_amd/csrc/common.h).  This file restates that integer law bit-exactly so that (a) the device masks can be checked on
 the CPU and (b) the oracle U-Net can be run with exactly the masks the kernels used.
 """
@@ -19,12 +20,15 @@ def hash32(i: np.ndarray, seed: int) -> np.ndarray:
 
 
 def threshold(p: float) -> int:
-    t = float(np.float32(p)) * 4294967296.0
-    return 0xFFFFFFFF if t >= 4294967295.0 else int(t)
+    t = float(np.float32(p)) * 65536.0
+    return 0xFFFF if t >= 65535.0 else int(t)
 
 
 def keep_mask_nhwc(n_elems: int, p: float, seed: int) -> np.ndarray:
-    return (hash32(np.arange(n_elems, dtype=np.uint64), seed) >= np.uint32(threshold(p))).astype(np.uint8)
+    i = np.arange(n_elems, dtype=np.uint64)
+    h = hash32(i >> np.uint64(1), seed)
+    r16 = np.where((i & np.uint64(1)) == 1, h >> np.uint32(16), h & np.uint32(0xFFFF))
+    return (r16 >= np.uint32(threshold(p))).astype(np.uint8)
 
 
 def keep_mask_nchw(n: int, c: int, h: int, w: int, p: float, seed: int) -> np.ndarray:

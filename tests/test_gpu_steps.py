@@ -19,6 +19,14 @@ DEV = torch.device("cuda:0")
 TOL = 1e-3
 
 
+def logit_tol(math):
+    """The fixtures are tiny (N=4, 32..64 px: BatchNorm over as few as 16 samples at the bottleneck), which amplifies any
+    perturbation of the forward pass over the training steps.  Exact-fp32 products stay inside 1e-3; the split-bf16 products
+    (~1e-5 per layer) end up at <= 3e-3 on the logits after 2-3 optimizer steps here, and inside 1e-3 at the BASELINE size
+    (test_mean_teacher_trace_224_vs_oracle)."""
+    return TOL if math == "f32" else 3e-3
+
+
 def _masks(d, key, n, hw):
     out = {}
     for lvl in range(5):
@@ -35,10 +43,12 @@ def _opt_args(**kw):
     return AttrDict(base)
 
 
-def test_supervised_trace(golden_dir):
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_supervised_trace(golden_dir, math):
     d = np.load(f"{golden_dir}/trace_sup.npz")
     torch.manual_seed(1)
     m = UNet(1, 4).to(DEV)
+    m.math = math
     m.train()
     st = SupervisedStep(m, _opt_args(weight_decay=5e-4, sched="cosine"))
     x, lab = torch.from_numpy(d["x"]).to(DEV), torch.from_numpy(d["labels"]).to(DEV)
@@ -51,15 +61,17 @@ def test_supervised_trace(golden_dir):
     m.eval()
     with torch.no_grad():
         fin = m(x).cpu()
-    assert maxerr(fin, torch.from_numpy(d["final_eval_logits"])) < TOL
+    assert maxerr(fin, torch.from_numpy(d["final_eval_logits"])) < logit_tol(math)
     dice = losses_ref.mean_foreground_dice(fin.argmax(1).numpy(), d["labels"], 4)
     assert abs(dice - float(d["final_dice"])) < TOL
 
 
-def test_mean_teacher_trace(golden_dir):
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_mean_teacher_trace(golden_dir, math):
     d = np.load(f"{golden_dir}/trace_mt.npz")
     torch.manual_seed(1337)
     m = UNet(1, 4).to(DEV)
+    m.math = math
     ema = deepcopy(m)
     for p in ema.parameters():
         p.requires_grad = False
@@ -75,15 +87,17 @@ def test_mean_teacher_trace(golden_dir):
         p = r["parts"].cpu()
         rows.append([float(r["loss"]), 0.5 * float(p[1]) + 0.5 * float(p[2]), float(p[5])])
     assert np.abs(np.array(rows) - d["losses"]).max() < TOL, (rows, d["losses"])
-    assert maxerr(r["logits"].cpu(), torch.from_numpy(d["student_logits_last"])) < TOL
-    assert maxerr(r["t_logits"].cpu(), torch.from_numpy(d["teacher_logits_last"])) < TOL
+    assert maxerr(r["logits"].cpu(), torch.from_numpy(d["student_logits_last"])) < logit_tol(math)
+    assert maxerr(r["t_logits"].cpu(), torch.from_numpy(d["teacher_logits_last"])) < logit_tol(math)
 
 
-def test_cps_trace(golden_dir):
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_cps_trace(golden_dir, math):
     d = np.load(f"{golden_dir}/trace_cps.npz")
     torch.manual_seed(1337)
     m1 = UNet(3, 2).to(DEV)
     m2 = UNet(3, 2).to(DEV)
+    m1.math = m2.math = math
     m1.train()
     m2.train()
     args = _opt_args()
@@ -97,15 +111,17 @@ def test_cps_trace(golden_dir):
         r = st.step(xl, yl, xu, k + 1, cons_w=float(d["cons_w"]))
         rows.append(float(r["loss"]))
     assert np.abs(np.array(rows) - d["losses"][:, 0]).max() < TOL, (rows, d["losses"])
-    assert maxerr(r["logits1"].cpu(), torch.from_numpy(d["logits1_last"])) < TOL
-    assert maxerr(r["logits2"].cpu(), torch.from_numpy(d["logits2_last"])) < TOL
+    assert maxerr(r["logits1"].cpu(), torch.from_numpy(d["logits1_last"])) < logit_tol(math)
+    assert maxerr(r["logits2"].cpu(), torch.from_numpy(d["logits2_last"])) < logit_tol(math)
 
 
-def test_hpfg_trace(golden_dir):
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_hpfg_trace(golden_dir, math):
     d = np.load(f"{golden_dir}/trace_hpfg.npz")
     torch.manual_seed(1)
     m1 = UNet_Plus(1, 4).to(DEV)
     m2 = UNet_Plus(1, 4).to(DEV)
+    m1.math = m2.math = math
     ema = deepcopy(m2)
     for p in ema.parameters():
         p.requires_grad = False
@@ -130,6 +146,42 @@ def test_hpfg_trace(golden_dir):
     ref = d["losses"]
     assert np.abs(np.array(rows)[:, 0] - ref[:, 0]).max() < TOL, (rows, ref)
     assert np.abs(np.array(rows)[:, 1] - ref[:, 4]).max() < TOL, (rows, ref)
-    assert maxerr(r["logits1"].cpu(), torch.from_numpy(d["logits1_last"])) < TOL
-    assert maxerr(r["logits2"].cpu(), torch.from_numpy(d["logits2_last"])) < TOL
-    assert maxerr(r["t_logits"].cpu(), torch.from_numpy(d["t_logits_last"])) < TOL
+    assert maxerr(r["logits1"].cpu(), torch.from_numpy(d["logits1_last"])) < logit_tol(math)
+    assert maxerr(r["logits2"].cpu(), torch.from_numpy(d["logits2_last"])) < logit_tol(math)
+    assert maxerr(r["t_logits"].cpu(), torch.from_numpy(d["t_logits_last"])) < logit_tol(math)
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_mean_teacher_trace_224_vs_oracle(math):
+    """BASELINE-sized images (224x224, 2 labelled + 2 unlabelled): three Mean-Teacher steps against the CPU oracle (itself pinned
+    to the reference by tests/test_oracle_golden.py), dropout masks taken from the HIP RNG.  Losses, student and teacher logits
+    and the mean foreground Dice of the final prediction within 1e-3 in BOTH math modes."""
+    from hpfg_amd.datasets.synthetic import synth_batch
+    from oracle import laws_ref, steps_ref, unet_ref
+    from tests.helpers import engine_masks, state_from_module
+    torch.manual_seed(1337)
+    m = UNet(1, 4).to(DEV)
+    m.math = math
+    ema = deepcopy(m)
+    for p in ema.parameters():
+        p.requires_grad = False
+    m.train()
+    ema.train()
+    st = MeanTeacherStep(m, ema, _opt_args())
+    so, eo, bufs = state_from_module(m), state_from_module(ema), {}
+    xl, yl = synth_batch(7, 2, 224, 224, 1, 4, 32)
+    xu, _ = synth_batch(8, 2, 224, 224, 1, 4, 32)
+    w = 0.05
+    for k in range(1, 4):
+        r = st.step(xl.to(DEV), yl.to(DEV), xu.to(DEV), k, cons_w=w)
+        es = next(iter(m._engines.values()))[0]
+        et = next(iter(ema._engines.values()))[0]
+        ms, mt = engine_masks(es, m._seed_counter, 4, 224, 224), engine_masks(et, ema._seed_counter, 4, 224, 224)
+        ro = steps_ref.mean_teacher_step(so, eo, bufs, xl, yl.long(), xu, laws_ref.medical_lr(k, 0.01, 30000), w, laws_ref.ema_alpha(k, 0.99), 0.9, 1e-4,
+                                         ms, mt)
+        assert abs(float(r["loss"]) - ro["loss"]) < TOL, (k, float(r["loss"]), ro["loss"])
+        assert maxerr(r["logits"].cpu(), ro["logits"]) < TOL, k
+        assert maxerr(r["t_logits"].cpu(), ro["t_logits"]) < TOL, k
+    d_hip = losses_ref.mean_foreground_dice(r["logits"][:2].argmax(1).cpu().numpy(), yl.numpy(), 4)
+    d_ref = losses_ref.mean_foreground_dice(ro["logits"][:2].argmax(1).numpy(), yl.numpy(), 4)
+    assert abs(d_hip - d_ref) < TOL
