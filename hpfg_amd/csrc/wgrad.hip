@@ -12,6 +12,7 @@
 // gradient in PyTorch's [Cout][Cin][k][k] layout.  3x3: three waves, wave w owns kernel row ky = w.  1x1: wave w owns
 // n-tile w.
 #include "wgrad_kernel.h"
+#include "wgrad_bf16_kernel.h"
 
 namespace {
 
@@ -98,7 +99,10 @@ extern "C" int hpfg_wgrad(const HpfgWgradArgs* a, void* stream) {
   const int akind = hpfg_kind_of(a->a0, a->a1);
   HPFG_ARG_CHECK(akind >= 0 && akind != HPFG_KIND_DZ, "wgrad: unsupported input source (a0.mode=%d, a1.mode=%d)", a->a0.mode, a->a1.mode);
   int rc;
-  if (a->g.mode == HPFG_ACT_DZ) rc = hpfg_wgrad_launch_dz(*a, akind, st);
+  const bool b16 = a->math == HPFG_MATH_BF16X3 && a->taps == 9;
+  if (b16 && a->g.mode == HPFG_ACT_DZ) rc = hpfg_wgrad16_launch_dz(*a, akind, st);
+  else if (b16 && (a->g.mode == HPFG_ACT_PLAIN || a->g.mode == HPFG_ACT_STRIDED)) rc = hpfg_wgrad16_launch_plain(*a, akind, st);
+  else if (a->g.mode == HPFG_ACT_DZ) rc = hpfg_wgrad_launch_dz(*a, akind, st);
   else if (a->g.mode == HPFG_ACT_PLAIN || a->g.mode == HPFG_ACT_STRIDED) rc = hpfg_wgrad_launch_plain(*a, akind, st);
   else {
     hpfg_set_error("wgrad: unsupported gradient source mode %d", a->g.mode);

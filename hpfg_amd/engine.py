@@ -322,6 +322,7 @@ class UNetEngine:
         wa.Cin, wa.CinPad, wa.Cout, wa.CoutPad = s.cin, s.cin_pad, s.cout, s.cout_pad
         wa.N, wa.H, wa.W, wa.taps = self.N, s.h, s.w, s.taps
         wa.S = self.lib.hpfg_wgrad_splits(self.N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps)
+        wa.math = self.math
         L.check(self.lib.hpfg_wgrad(C.byref(wa), self._stream()), f"wgrad[{s.name}]")
 
     def _dgrad(self, s: ConvSpec, g: L.Act, out: torch.Tensor):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 101
+#define HPFG_VERSION 102
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -80,6 +80,7 @@ typedef struct HpfgWgradArgs {
   int32_t Cin, CinPad, Cout, CoutPad;
   int32_t N, H, W, taps;
   int32_t S;            /* number of pixel splits (slabs), from hpfg_wgrad_splits() */
+  int32_t math;         /* HPFG_MATH_F32 or HPFG_MATH_BF16X3 (3x3 only; 1x1 always runs the exact fp32 kernel) */
 } HpfgWgradArgs;
 
 typedef struct HpfgPackDesc {   /* one conv layer for hpfg_pack_weights (device array of these) */

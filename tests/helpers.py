@@ -87,14 +87,14 @@ class AdHocConv:
         L.check(lib.hpfg_conv_fwd(C.byref(ca), stream(self.dev)), "conv_fwd")
         return out, part
 
-    def wgrad(self, a0, a1, g, N, H, W):
+    def wgrad(self, a0, a1, g, N, H, W, math=0):
         lib = L.load()
         wa = L.WgradArgs()
         wa.a0, wa.a1, wa.g = a0, (a1 if a1 is not None else L.Act()), g
         S = lib.hpfg_wgrad_splits(N, H, W, self.cin_pad, self.cout_pad, self.taps)
         slab = torch.empty(lib.hpfg_wgrad_slab_floats(N, H, W, self.cin_pad, self.cout_pad, self.taps), device=self.dev)
         dw = torch.full_like(self.w, float("nan"))
-        wa.slab, wa.dw_oihw = L.ptr(slab), L.ptr(dw)
+        wa.slab, wa.dw_oihw, wa.math = L.ptr(slab), L.ptr(dw), math
         wa.Cin, wa.CinPad, wa.Cout, wa.CoutPad, wa.N, wa.H, wa.W, wa.taps, wa.S = self.cin, self.cin_pad, self.cout, self.cout_pad, N, H, W, self.taps, S
         L.check(lib.hpfg_wgrad(C.byref(wa), stream(self.dev)), "wgrad")
         return dw

@@ -65,6 +65,10 @@ def test_conv_fwd_dgrad_wgrad_plain(N, H, W, cin, cout, taps):
     dw = layer.wgrad(plain_act(xd, cin, H, W), None, plain_act(gzd, cout, H, W), N, H, W)
     e = maxerr(dw.cpu(), wr.grad)
     assert e < 3e-4 * max(1.0, float(wr.grad.abs().max())), f"wgrad err {e}"
+    if taps == 9:
+        dw16 = layer.wgrad(plain_act(xd, cin, H, W), None, plain_act(gzd, cout, H, W), N, H, W, math=L.MATH_BF16X3)
+        e = maxerr(dw16.cpu(), wr.grad)
+        assert e < 5e-4 * max(1.0, float(wr.grad.abs().max())), f"bf16x3 wgrad err {e}"
 
 
 def _bn_table(C_, seed):
