@@ -241,24 +241,38 @@ __global__ __launch_bounds__(256, (C::NI >= 4 || (C::NI >= 2 && RawCount<KIND>::
       const int c0n = nch * C::KC + g8;
       const bool chvn = more && c0n < cin_total;
       if (more && nchunks > 1) load_tables<KIND>(tab, p.a0, c0n, chvn);
-      f32x4 raw[2][NR];
+      // Prefetch depth: kinds with few raw loads per piece (PLAIN/BNACT) put ALL pieces of the next item in flight before the
+      // first MFMA and finish them after the last one (a whole item of latency cover); DZ (4 raw float4 + 10 table registers) and POOL/CAT (8 raw float4 per piece) keep the
+      // two-k-step ring to stay inside the register budget.
+      constexpr bool DEEP = NR <= 2;
+      f32x4 raw[DEEP ? C::NLD : 2][NR];
+      if (DEEP) {
+#pragma unroll
+        for (int i = 0; i < C::NLD; ++i) {
+          const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
+          const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
+          issue_piece<KIND>(raw[DEEP ? i : 0], p.a0, p.a1, cx0, nn, gy, gx, c0n, ok);
+        }
+      }
 #pragma unroll
       for (int s = 0; s < C::KSTEPS; ++s) {
-        if (s >= 2 && s - 2 < C::NLD) {        // finish the piece issued two k-steps ago and park it in the other LDS buffer
-          const int i = s - 2 < C::NLD ? s - 2 : 0;
-          const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
-          const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
-          if (more) {
-            f32x4 v0, v1;
-            finish_piece<KIND>(v0, v1, raw[i & 1], tab, p.a0, p.a1, cx0, nn, gy, gx, c0n, ok);
-            store_piece<C>(nxt, pc[i], v0, v1);
+        if (!DEEP) {
+          if (s >= 2 && s - 2 < C::NLD) {        // finish the piece issued two k-steps ago and park it in the other LDS buffer
+            const int i = s - 2 < C::NLD ? s - 2 : 0;
+            const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
+            const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            if (more) {
+              f32x4 v0, v1;
+              finish_piece<KIND>(v0, v1, raw[i & 1], tab, p.a0, p.a1, cx0, nn, gy, gx, c0n, ok);
+              store_piece<C>(nxt, pc[i], v0, v1);
+            }
           }
-        }
-        if (s < C::NLD) {
-          const int i = s < C::NLD ? s : 0;
-          const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
-          const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
-          issue_piece<KIND>(raw[i & 1], p.a0, p.a1, cx0, nn, gy, gx, c0n, ok);
+          if (s < C::NLD) {
+            const int i = s < C::NLD ? s : 0;
+            const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
+            const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            issue_piece<KIND>(raw[i & 1], p.a0, p.a1, cx0, nn, gy, gx, c0n, ok);
+          }
         }
         if (s + 1 < C::KSTEPS) load_b<C>(nh, nl, wpk, ch * C::KSTEPS + s + 1, ntn, nt0, lane);
         else if (more) load_b<C>(nh, nl, wpk, nch * C::KSTEPS, ntn, nt0, lane);
@@ -273,6 +287,16 @@ __global__ __launch_bounds__(256, (C::NI >= 4 || (C::NI >= 2 && RawCount<KIND>::
         for (int j = 0; j < C::NI; ++j) {
           bh[j] = nh[j];
           bl[j] = nl[j];
+        }
+      }
+      if (DEEP && more) {
+#pragma unroll
+        for (int i = 0; i < C::NLD; ++i) {
+          const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
+          const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
+          f32x4 v0, v1;
+          finish_piece<KIND>(v0, v1, raw[DEEP ? i : 0], tab, p.a0, p.a1, cx0, nn, gy, gx, c0n, ok);
+          store_piece<C>(nxt, pc[i], v0, v1);
         }
       }
       __syncthreads();
@@ -385,8 +409,10 @@ int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st) {
     if (cp % 32 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 2, TAPS, KCB>, KIND>(a, st);
     return launch_cfg<Cfg<16, 16, 4, 1, 1, TAPS, KCB>, KIND>(a, st);
   }
-  if (cp % 128 == 0) return launch_cfg<Cfg<8, 8, 1, 4, 2, TAPS, 32>, KIND>(a, st);
-  if (cp % 64 == 0) return launch_cfg<Cfg<8, 8, 1, 4, 1, TAPS, 32>, KIND>(a, st);
+  // small spatial sizes have few 8x8 tiles: narrow the output-channel slice per workgroup until there are >= 2 workgroups per CU
+  const long nwork = (long)a.N * ((a.H + 7) / 8) * ((a.W + 7) / 8);
+  if (cp % 128 == 0 && nwork * (cp / 128) >= 512) return launch_cfg<Cfg<8, 8, 1, 4, 2, TAPS, 32>, KIND>(a, st);
+  if (cp % 64 == 0 && (nwork * (cp / 64) >= 512 || cp % 32 != 0)) return launch_cfg<Cfg<8, 8, 1, 4, 1, TAPS, 32>, KIND>(a, st);
   if (cp % 32 == 0) return launch_cfg<Cfg<8, 8, 2, 2, 1, TAPS, 32>, KIND>(a, st);
   return launch_cfg<Cfg<8, 8, 4, 1, 1, TAPS, 32>, KIND>(a, st);
 }
