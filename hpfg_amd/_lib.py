@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ = range(7)
 LOSS_NSUM = 32
-VERSION = 102
+VERSION = 103
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -65,6 +65,7 @@ PROTOTYPES = {
     "hpfg_conv3x3_first_fwd": (_i, [C.POINTER(Act), _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "hpfg_conv_fwd": (_i, [C.POINTER(ConvArgs), _p]),
     "hpfg_conv_stat_blocks": (_i, [_i, _i, _i]),
+    "hpfg_conv_stat_rows": (_i, [C.POINTER(ConvArgs)]),
     "hpfg_bn_fwd_finalize": (_i, [_p, _i, _p, _d, _p, _p, _p, _p, _f, _f, _p, _i, _p]),
     "hpfg_reduce_partials": (_i, [_p, _i, _i, _p, _p]),
     "hpfg_conv_kc": (_i, [_i, _i, _i]),

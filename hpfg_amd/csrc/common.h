@@ -28,12 +28,13 @@ static inline int hpfg_launch_status(const char* what) {
 }
 
 // ---- counter-based dropout RNG ------------------------------------------------------------------------------
-// One 32-bit hash serves two neighbouring elements: h = fmix32((i >> 1) * 0x9E3779B1 + seed), r16 = (i & 1) ? h >> 16 : h & 0xFFFF,
-// keep(i) = r16 >= floor(p * 65536); i = NHWC element index of the activated tensor (p is resolved to 1.5e-5).
+// One 32-bit hash serves four neighbouring elements: h = mix32((i >> 2) * 0x9E3779B1 + seed), r8 = byte (i & 3) of h,
+// keep(i) = r8 >= round(p * 256); i = NHWC element index of the activated tensor.  The kept values are scaled by the nominal
+// 1/(1-p) of nn.Dropout (the realised keep rate differs from 1-p by < 0.002: 8-bit threshold).
 // Stateless, so forward consumers and backward loaders regenerate the same mask without storing it.
 __host__ __device__ static inline uint32_t hpfg_hash32(uint32_t i, uint32_t seed) {
   uint32_t h = i * 0x9E3779B1u + seed;
-  h ^= h >> 16;
+  h ^= h >> 15;
   h *= 0x85EBCA6Bu;
   h ^= h >> 13;
   h *= 0xC2B2AE35u;
@@ -41,13 +42,12 @@ __host__ __device__ static inline uint32_t hpfg_hash32(uint32_t i, uint32_t seed
   return h;
 }
 __host__ __device__ static inline uint32_t hpfg_drop_threshold(float p) {
-  double t = (double)p * 65536.0;
-  if (t >= 65535.0) return 0xFFFFu;
-  return (uint32_t)t;
+  int t = (int)(p * 256.0f + 0.5f);
+  return (uint32_t)(t < 0 ? 0 : (t > 255 ? 255 : t));
 }
-__host__ __device__ static inline bool hpfg_keep(uint32_t i, uint32_t seed, uint32_t thresh16) {
-  const uint32_t h = hpfg_hash32(i >> 1, seed);
-  return ((i & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= thresh16;
+__host__ __device__ static inline bool hpfg_keep(uint32_t i, uint32_t seed, uint32_t thresh8) {
+  const uint32_t h = hpfg_hash32(i >> 2, seed);
+  return ((h >> (8 * (i & 3u))) & 0xFFu) >= thresh8;
 }
 
 __device__ static inline float lrelu(float y) { return fmaxf(y, HPFG_LEAKY * y); }   // == y > 0 ? y : 0.01*y
@@ -70,15 +70,15 @@ __device__ static inline bool keep_elem(const HpfgAct& s, const ActCtx& cx, uint
   return s.drop_mask ? s.drop_mask[e] != 0 : hpfg_keep(e, cx.seed, cx.thresh);
 }
 
-// keep flags of the 4 elements e..e+3 (e % 4 == 0) as a 4-bit mask: two hashes, or one 32-bit load of an explicit mask.
+// keep flags of the 4 elements e..e+3 (e % 4 == 0) as a 4-bit mask: one hash, or one 32-bit load of an explicit mask.
 __device__ static inline uint32_t keep4(const HpfgAct& s, const ActCtx& cx, uint32_t e) {
   if (s.drop_mask) {
     const uint32_t m = *reinterpret_cast<const uint32_t*>(s.drop_mask + e);
     return ((m & 0xFFu) ? 1u : 0u) | ((m & 0xFF00u) ? 2u : 0u) | ((m & 0xFF0000u) ? 4u : 0u) | ((m & 0xFF000000u) ? 8u : 0u);
   }
-  const uint32_t h0 = hpfg_hash32(e >> 1, cx.seed), h1 = hpfg_hash32((e >> 1) + 1, cx.seed);
-  return ((h0 & 0xFFFFu) >= cx.thresh ? 1u : 0u) | ((h0 >> 16) >= cx.thresh ? 2u : 0u) | ((h1 & 0xFFFFu) >= cx.thresh ? 4u : 0u) |
-         ((h1 >> 16) >= cx.thresh ? 8u : 0u);
+  const uint32_t h = hpfg_hash32(e >> 2, cx.seed);
+  return ((h & 0xFFu) >= cx.thresh ? 1u : 0u) | (((h >> 8) & 0xFFu) >= cx.thresh ? 2u : 0u) | (((h >> 16) & 0xFFu) >= cx.thresh ? 4u : 0u) |
+         ((h >> 24) >= cx.thresh ? 8u : 0u);
 }
 
 // 4 channels [c, c+4) of the virtual activation `s` at image n, virtual pixel (y, x); caller guarantees the pixel is

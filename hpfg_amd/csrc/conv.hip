@@ -92,7 +92,18 @@ extern "C" int hpfg_conv_stat_blocks(int N, int H, int W) {
   return N * ((H + t - 1) / t) * ((W + t - 1) / t);
 }
 
-extern "C" int hpfg_conv_fwd(const HpfgConvArgs* a, void* stream) {
+static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only);
+
+extern "C" int hpfg_conv_fwd(const HpfgConvArgs* a, void* stream) { return conv_fwd_impl(a, stream, nullptr); }
+
+// rows of stat_partials ([rows][2][CoutPad]) that hpfg_conv_fwd(args) fills; <0 on argument errors
+extern "C" int hpfg_conv_stat_rows(const HpfgConvArgs* a) {
+  int rows = -1;
+  int rc = conv_fwd_impl(a, nullptr, &rows);
+  return rc ? -1 : rows;
+}
+
+static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
   HPFG_ARG_CHECK(a && a->wpk && a->out, "conv_fwd: null pointer");
   HPFG_ARG_CHECK(a->taps == 9 || a->taps == 1, "conv_fwd: taps must be 1 or 9 (got %d)", a->taps);
   HPFG_ARG_CHECK(a->CoutPad % 16 == 0 && a->Cout <= a->CoutPad && a->Cout > 0, "conv_fwd: bad Cout %d / pad %d", a->Cout, a->CoutPad);
@@ -103,15 +114,19 @@ extern "C" int hpfg_conv_fwd(const HpfgConvArgs* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if ((a->math & 0xff) == HPFG_MATH_BF16X3) {
     switch (hpfg_kind_of(a->a0, a->a1)) {
-      case HPFG_KIND_PLAIN: return hpfg_conv16_launch_plain(*a, st);
-      case HPFG_KIND_BNACT: return hpfg_conv16_launch_bnact(*a, st);
-      case HPFG_KIND_POOL: return hpfg_conv16_launch_pool(*a, st);
-      case HPFG_KIND_CAT: return hpfg_conv16_launch_cat(*a, st);
-      case HPFG_KIND_DZ: return hpfg_conv16_launch_dz(*a, st);
+      case HPFG_KIND_PLAIN: return hpfg_conv16_launch_plain(*a, st, rows_only);
+      case HPFG_KIND_BNACT: return hpfg_conv16_launch_bnact(*a, st, rows_only);
+      case HPFG_KIND_POOL: return hpfg_conv16_launch_pool(*a, st, rows_only);
+      case HPFG_KIND_CAT: return hpfg_conv16_launch_cat(*a, st, rows_only);
+      case HPFG_KIND_DZ: return hpfg_conv16_launch_dz(*a, st, rows_only);
       default: break;
     }
     hpfg_set_error("conv_fwd(bf16x3): unsupported source combination (a0.mode=%d, a1.mode=%d)", a->a0.mode, a->a1.mode);
     return -1;
+  }
+  if (rows_only) {
+    *rows_only = hpfg_conv_stat_blocks(a->N, a->H, a->W);
+    return 0;
   }
   switch (hpfg_kind_of(a->a0, a->a1)) {
     case HPFG_KIND_PLAIN: return hpfg_conv_launch_plain(*a, st);

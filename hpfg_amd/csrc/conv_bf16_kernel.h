@@ -78,17 +78,15 @@ __device__ __forceinline__ void load_b(bf16x8 (&bh)[C::NI], bf16x8 (&bl)[C::NI],
   }
 }
 
-// Epilogue: acc holds D[cout = (lane>>4)*4 + r][pixel = lane & 15] per (m, j) tile -> one 16-B store per lane; BN partial sums.
+// Epilogue: acc holds D[cout = (lane>>4)*4 + r][pixel = lane & 15] per (m, j) tile -> one 16-B store per lane.  The BatchNorm
+// partial sums are accumulated per lane in (s1, s2) -- across ALL tiles of a persistent workgroup -- and flushed once.
 template <class C>
-__device__ __forceinline__ void conv16_epilogue(const HpfgConvArgs& p, f32x4 (&acc)[C::MI][C::NI], float* ldsf, int tid, int lane, int wm, int wn,
-                                                int nt0, int cb, int n, int ty0, int tx0, int blk) {
+__device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (&acc)[C::MI][C::NI], f32x4 (&s1)[C::NI], f32x4 (&s2)[C::NI], int lane,
+                                                  int wm, int nt0, int n, int ty0, int tx0) {
   const int H = p.H, W = p.W;
   const bool vec = (p.Cout & 3) == 0 && (p.out_pstride & 3) == 0;
-  f32x4 s1[C::NI], s2[C::NI];
 #pragma unroll
   for (int j = 0; j < C::NI; ++j) {
-    s1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    s2[j] = s1[j];
     const int co = (nt0 + j) * 16 + (lane >> 4) * 4;
     f32x4 b = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && co < p.CoutPad) b = ld4(p.bias, co);
@@ -99,7 +97,8 @@ __device__ __forceinline__ void conv16_epilogue(const HpfgConvArgs& p, f32x4 (&a
       if (gy < H && gx < W && co < p.Cout) {
         f32x4 v = acc[m][j] + b;
         float* o = p.out + ((n * H + gy) * W + gx) * p.out_pstride + co;
-        if (vec) {
+        if (p.math & 0x100) {
+        } else if (vec) {
           *reinterpret_cast<f32x4*>(o) = v;
         } else {
 #pragma unroll
@@ -113,38 +112,43 @@ __device__ __forceinline__ void conv16_epilogue(const HpfgConvArgs& p, f32x4 (&a
       }
     }
   }
-  if (p.stat_partials) {
+}
+
+// Reduce the per-lane partial sums over the 16 pixel lanes and the WM waves that share output channels; row `row` of
+// stat_partials ([rows][2][CoutPad]) receives this workgroup's sum(z), sum(z^2).
+template <class C>
+__device__ __forceinline__ void conv16_flush_stats(const HpfgConvArgs& p, f32x4 (&s1)[C::NI], f32x4 (&s2)[C::NI], float* ldsf, int tid, int lane, int wm,
+                                                   int wn, int cb, int row) {
+  if (!p.stat_partials || (p.math & 0x1000)) return;
 #pragma unroll
-    for (int j = 0; j < C::NI; ++j)
+  for (int j = 0; j < C::NI; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a = s1[j][r], b = s2[j][r];
+    for (int r = 0; r < 4; ++r) {
+      float a = s1[j][r], b = s2[j][r];
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          a += __shfl_xor(a, o);
-          b += __shfl_xor(b, o);
-        }
-        s1[j][r] = a;
-        s2[j][r] = b;
+      for (int o = 1; o < 16; o <<= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
       }
-    if ((lane & 15) == 0) {
-#pragma unroll
-      for (int j = 0; j < C::NI; ++j) {
-        const int cl = (wn * C::NI + j) * 16 + (lane >> 4) * 4;
-        *reinterpret_cast<f32x4*>(ldsf + (0 * C::WM + wm) * C::BN + cl) = s1[j];
-        *reinterpret_cast<f32x4*>(ldsf + (1 * C::WM + wm) * C::BN + cl) = s2[j];
-      }
+      s1[j][r] = a;
+      s2[j][r] = b;
     }
-    __syncthreads();
-    if (tid < 2 * C::BN) {
-      const int which = tid / C::BN, cl = tid % C::BN;
-      float t = 0.f;
+  if ((lane & 15) == 0) {
 #pragma unroll
-      for (int w = 0; w < C::WM; ++w) t += ldsf[(which * C::WM + w) * C::BN + cl];
-      const int co = cb * C::BN + cl;
-      if (co < p.CoutPad) p.stat_partials[((long)blk * 2 + which) * p.CoutPad + co] = t;
+    for (int j = 0; j < C::NI; ++j) {
+      const int cl = (wn * C::NI + j) * 16 + (lane >> 4) * 4;
+      *reinterpret_cast<f32x4*>(ldsf + (0 * C::WM + wm) * C::BN + cl) = s1[j];
+      *reinterpret_cast<f32x4*>(ldsf + (1 * C::WM + wm) * C::BN + cl) = s2[j];
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  if (tid < 2 * C::BN) {
+    const int which = tid / C::BN, cl = tid % C::BN;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < C::WM; ++w) t += ldsf[(which * C::WM + w) * C::BN + cl];
+    const int co = cb * C::BN + cl;
+    if (co < p.CoutPad) p.stat_partials[((long)row * 2 + which) * p.CoutPad + co] = t;
   }
 }
 
@@ -154,7 +158,7 @@ __device__ __forceinline__ void conv16_epilogue(const HpfgConvArgs& p, f32x4 (&a
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BH, AL, ACC, 0, 0, 0);
 
 template <class C, int KIND>
-__global__ __launch_bounds__(256, (C::NI >= 4 || (C::NI >= 2 && RawCount<KIND>::N >= 4)) ? 2 : 3) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   static_assert(C::TAPS == 9, "persistent kernel is the 3x3 path");
   constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
   constexpr int NR = RawCount<KIND>::N;
@@ -202,8 +206,17 @@ __global__ __launch_bounds__(256, (C::NI >= 4 || (C::NI >= 2 && RawCount<KIND>::
 
   int w = blockIdx.x;
   if (w >= nwork) return;
-  int n = w / ntiles, tl = w % ntiles;
-  int ty0 = (tl / tiles_x) * C::TH, tx0 = (tl % tiles_x) * C::TW;
+  int n = w / ntiles, tyi = (w % ntiles) / tiles_x, txi = (w % ntiles) % tiles_x;
+  int ty0 = tyi * C::TH, tx0 = txi * C::TW;
+  // stepping to this workgroup's next tile (w += gridDim.x) without divisions: decompose the stride once
+  const int G = (int)gridDim.x;
+  const int gn = G / ntiles, gty = (G % ntiles) / tiles_x, gtx = (G % ntiles) % tiles_x;
+  f32x4 s1[C::NI], s2[C::NI];
+#pragma unroll
+  for (int j = 0; j < C::NI; ++j) {
+    s1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s2[j] = s1[j];
+  }
   Tab tab;
   {
     const int c0 = g8;
@@ -219,8 +232,15 @@ __global__ __launch_bounds__(256, (C::NI >= 4 || (C::NI >= 2 && RawCount<KIND>::
       store_piece<C>(lds, pc[i], v0, v1);
     }
   }
-  bf16x8 bh[C::NI], bl[C::NI], nh[C::NI], nl[C::NI];
-  load_b<C>(bh, bl, wpk, 0, ntn, nt0, lane);
+  // B-fragment ring: the fragments of k-step g + BD are requested while k-step g computes (BD = ring size - 1 k-steps of latency
+  // cover; the ring position of a k-step is static because the ring size divides KSTEPS).  Weights do not depend on the tile, so
+  // the k-step sequence is periodic with period nchunks * KSTEPS.
+  constexpr int BR = C::KSTEPS == 5 ? 5 : 3, BD = BR - 1;
+  static_assert(C::KSTEPS % BR == 0, "ring size must divide the k-steps of a chunk");
+  const int kperiod = nchunks * C::KSTEPS;
+  bf16x8 bh[BR][C::NI], bl[BR][C::NI];
+#pragma unroll
+  for (int d = 0; d < BD; ++d) load_b<C>(bh[d], bl[d], wpk, d % kperiod, ntn, nt0, lane);
   __syncthreads();
   int item = 0;
   while (true) {
@@ -233,13 +253,21 @@ __global__ __launch_bounds__(256, (C::NI >= 4 || (C::NI >= 2 && RawCount<KIND>::
       const int nch = last_chunk ? 0 : ch + 1;
       int nn = n, nty = ty0, ntx = tx0;
       if (last_chunk && more) {
-        nn = w2 / ntiles;
-        const int t2 = w2 % ntiles;
-        nty = (t2 / tiles_x) * C::TH;
-        ntx = (t2 % tiles_x) * C::TW;
+        int x2 = txi + gtx, y2 = tyi + gty;
+        nn = n + gn;
+        if (x2 >= tiles_x) {
+          x2 -= tiles_x;
+          ++y2;
+        }
+        if (y2 >= tiles_y) {
+          y2 -= tiles_y;
+          ++nn;
+        }
+        nty = y2 * C::TH;
+        ntx = x2 * C::TW;
       }
       const int c0n = nch * C::KC + g8;
-      const bool chvn = more && c0n < cin_total;
+      const bool chvn = more && c0n < cin_total && !(p.math & 0x400);
       if (more && nchunks > 1) load_tables<KIND>(tab, p.a0, c0n, chvn);
       // Prefetch depth: kinds with few raw loads per piece (PLAIN/BNACT) put ALL pieces of the next item in flight before the
       // first MFMA and finish them after the last one (a whole item of latency cover); DZ (4 raw float4 + 10 table registers) and POOL/CAT (8 raw float4 per piece) keep the
@@ -274,19 +302,18 @@ __global__ __launch_bounds__(256, (C::NI >= 4 || (C::NI >= 2 && RawCount<KIND>::
             issue_piece<KIND>(raw[i & 1], p.a0, p.a1, cx0, nn, gy, gx, c0n, ok);
           }
         }
-        if (s + 1 < C::KSTEPS) load_b<C>(nh, nl, wpk, ch * C::KSTEPS + s + 1, ntn, nt0, lane);
-        else if (more) load_b<C>(nh, nl, wpk, nch * C::KSTEPS, ntn, nt0, lane);
+        if (!(p.math & 0x800)) {
+          int ksn = ch * C::KSTEPS + s + BD;
+          ksn = ksn >= kperiod ? ksn % kperiod : ksn;
+          load_b<C>(bh[(s + BD) % BR], bl[(s + BD) % BR], wpk, ksn, ntn, nt0, lane);
+        }
+        if (!(p.math & 0x200))
 #pragma unroll
         for (int m = 0; m < C::MI; ++m) {
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(cur + aoff[m] + toff[s]);
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(cur + aoff[m] + toff[s] + C::PLANE);
 #pragma unroll
-          for (int j = 0; j < C::NI; ++j) { HPFG16_MFMA3(acc[m][j], ah, al, bh[j], bl[j]) }
-        }
-#pragma unroll
-        for (int j = 0; j < C::NI; ++j) {
-          bh[j] = nh[j];
-          bl[j] = nl[j];
+          for (int j = 0; j < C::NI; ++j) { HPFG16_MFMA3(acc[m][j], ah, al, bh[s % BR][j], bl[s % BR][j]) }
         }
       }
       if (DEEP && more) {
@@ -301,18 +328,28 @@ __global__ __launch_bounds__(256, (C::NI >= 4 || (C::NI >= 2 && RawCount<KIND>::
       }
       __syncthreads();
     }
-    conv16_epilogue<C>(p, acc, ldsf, tid, lane, wm, wn, nt0, cb, n, ty0, tx0, w);
+    conv16_store_tile<C>(p, acc, s1, s2, lane, wm, nt0, n, ty0, tx0);
 #pragma unroll
     for (int m = 0; m < C::MI; ++m)
 #pragma unroll
       for (int j = 0; j < C::NI; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    w += gridDim.x;
+    w += G;
     if (w >= nwork) break;
-    n = w / ntiles;
-    tl = w % ntiles;
-    ty0 = (tl / tiles_x) * C::TH;
-    tx0 = (tl % tiles_x) * C::TW;
+    txi += gtx;
+    tyi += gty;
+    n += gn;
+    if (txi >= tiles_x) {
+      txi -= tiles_x;
+      ++tyi;
+    }
+    if (tyi >= tiles_y) {
+      tyi -= tiles_y;
+      ++n;
+    }
+    ty0 = tyi * C::TH;
+    tx0 = txi * C::TW;
   }
+  conv16_flush_stats<C>(p, s1, s2, ldsf, tid, lane, wm, wn, cb, (int)blockIdx.x);
 }
 
 // 1x1: one tile per workgroup, K = 32 input channels per MFMA step, no halo.
@@ -374,23 +411,40 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int
       for (int j = 0; j < C::NI; ++j) { HPFG16_MFMA3(acc[m][j], ah, al, bh[j], bl[j]) }
     }
   }
+  f32x4 s1[C::NI], s2[C::NI];
+#pragma unroll
+  for (int j = 0; j < C::NI; ++j) {
+    s1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s2[j] = s1[j];
+  }
+  conv16_store_tile<C>(p, acc, s1, s2, lane, wm, nt0, n, ty0, tx0);
   __syncthreads();
-  conv16_epilogue<C>(p, acc, ldsf, tid, lane, wm, wn, nt0, cb, n, ty0, tx0, n * (tiles_x * tiles_y) + tile);
+  conv16_flush_stats<C>(p, s1, s2, ldsf, tid, lane, wm, wn, cb, n * (tiles_x * tiles_y) + tile);
+}
+
+// number of stat_partials rows the kernel for this configuration writes (persistent 3x3: one per workgroup)
+template <class C, int KIND>
+int persistent_grid(const HpfgConvArgs& a) {
+  const int tx = (a.W + C::TW - 1) / C::TW, ty = (a.H + C::TH - 1) / C::TH;
+  const int lds_bytes = 2 * C::BUF_BYTES + 2 * 4 * C::BN * 4;
+  int per_cu = 160 * 1024 / lds_bytes;
+  const int reg_cap = (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3;   // matches __launch_bounds__
+  if (per_cu > reg_cap) per_cu = reg_cap;
+  if (per_cu < 1) per_cu = 1;
+  long nwork = (long)tx * ty * a.N;
+  long gx = 256L * per_cu;
+  return (int)(gx > nwork ? nwork : gx);
 }
 
 template <class C, int KIND>
-int launch_cfg(const HpfgConvArgs& a, hipStream_t st) {
+int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   int tx = (a.W + C::TW - 1) / C::TW, ty = (a.H + C::TH - 1) / C::TH;
+  if (rows_only) {
+    *rows_only = C::TAPS == 9 ? persistent_grid<C, KIND>(a) : tx * ty * a.N;
+    return 0;
+  }
   if constexpr (C::TAPS == 9) {
-    const int lds_bytes = 2 * C::BUF_BYTES + 2 * 4 * C::BN * 4;
-    int per_cu = 160 * 1024 / lds_bytes;
-    const int reg_cap = (C::NI >= 4 || (C::NI >= 2 && RawCount<KIND>::N >= 4)) ? 2 : 3;   // matches __launch_bounds__
-    if (per_cu > reg_cap) per_cu = reg_cap;
-    if (per_cu < 1) per_cu = 1;
-    long nwork = (long)tx * ty * a.N;
-    long gx = 256L * per_cu;
-    if (gx > nwork) gx = nwork;
-    dim3 grid((unsigned)gx, a.CoutPad / C::BN);
+    dim3 grid((unsigned)persistent_grid<C, KIND>(a), a.CoutPad / C::BN);
     hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND>), grid, dim3(256), 0, st, a, tx, ty);
   } else {
     dim3 grid(tx * ty, a.N, a.CoutPad / C::BN);
@@ -400,27 +454,29 @@ int launch_cfg(const HpfgConvArgs& a, hipStream_t st) {
 }
 
 template <int KIND, int TAPS>
-int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st) {
+int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   const bool big = (a.H % 16 == 0) && (a.W % 16 == 0);
   const int cp = a.CoutPad;
   constexpr int KCB = TAPS == 9 ? 16 : 32;
   if (big) {
-    if (cp % 64 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 4, TAPS, KCB>, KIND>(a, st);
-    if (cp % 32 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 2, TAPS, KCB>, KIND>(a, st);
-    return launch_cfg<Cfg<16, 16, 4, 1, 1, TAPS, KCB>, KIND>(a, st);
+    if constexpr (TAPS == 1) {
+      if (cp % 64 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 4, TAPS, KCB>, KIND>(a, st, rows_only);
+    }
+    if (cp % 32 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 2, TAPS, KCB>, KIND>(a, st, rows_only);   // 3x3: 32-channel slices (B ring = 80 VGPRs)
+    return launch_cfg<Cfg<16, 16, 4, 1, 1, TAPS, KCB>, KIND>(a, st, rows_only);
   }
   // small spatial sizes have few 8x8 tiles: narrow the output-channel slice per workgroup until there are >= 2 workgroups per CU
   const long nwork = (long)a.N * ((a.H + 7) / 8) * ((a.W + 7) / 8);
-  if (cp % 128 == 0 && nwork * (cp / 128) >= 512) return launch_cfg<Cfg<8, 8, 1, 4, 2, TAPS, 32>, KIND>(a, st);
-  if (cp % 64 == 0 && (nwork * (cp / 64) >= 512 || cp % 32 != 0)) return launch_cfg<Cfg<8, 8, 1, 4, 1, TAPS, 32>, KIND>(a, st);
-  if (cp % 32 == 0) return launch_cfg<Cfg<8, 8, 2, 2, 1, TAPS, 32>, KIND>(a, st);
-  return launch_cfg<Cfg<8, 8, 4, 1, 1, TAPS, 32>, KIND>(a, st);
+  if (cp % 128 == 0 && nwork * (cp / 128) >= 512) return launch_cfg<Cfg<8, 8, 1, 4, 2, TAPS, 32>, KIND>(a, st, rows_only);
+  if (cp % 64 == 0 && (nwork * (cp / 64) >= 512 || cp % 32 != 0)) return launch_cfg<Cfg<8, 8, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only);
+  if (cp % 32 == 0) return launch_cfg<Cfg<8, 8, 2, 2, 1, TAPS, 32>, KIND>(a, st, rows_only);
+  return launch_cfg<Cfg<8, 8, 4, 1, 1, TAPS, 32>, KIND>(a, st, rows_only);
 }
 
 }  // namespace hpfg_conv16
 
-int hpfg_conv16_launch_plain(const HpfgConvArgs& a, hipStream_t st);
-int hpfg_conv16_launch_bnact(const HpfgConvArgs& a, hipStream_t st);
-int hpfg_conv16_launch_pool(const HpfgConvArgs& a, hipStream_t st);
-int hpfg_conv16_launch_cat(const HpfgConvArgs& a, hipStream_t st);
-int hpfg_conv16_launch_dz(const HpfgConvArgs& a, hipStream_t st);
+int hpfg_conv16_launch_plain(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
+int hpfg_conv16_launch_bnact(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
+int hpfg_conv16_launch_pool(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
+int hpfg_conv16_launch_cat(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
+int hpfg_conv16_launch_dz(const HpfgConvArgs& a, hipStream_t st, int* rows_only);

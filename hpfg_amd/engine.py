@@ -238,6 +238,8 @@ class UNetEngine:
                 ca.out_pstride, ca.Cout, ca.CoutPad = s.cout, s.cout, s.cout_pad
                 ca.N, ca.H, ca.W, ca.taps = self.N, s.h, s.w, s.taps
                 L.check(self.lib.hpfg_conv_fwd(C.byref(ca), st), f"conv_fwd[{s.name}]")
+                if want_stats:
+                    nblk = self.lib.hpfg_conv_stat_rows(C.byref(ca))
             if s.bn:
                 if train:
                     self._finalize_bn(s, nblk, track_running)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 102
+#define HPFG_VERSION 103
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -106,7 +106,8 @@ int hpfg_conv3x3_first_fwd(const HpfgAct* x, const float* w_oihw, const float* b
 /* nn.Conv2d k3/k1 (+ fused producer BN/LeakyReLU/Dropout/MaxPool/Upsample/cat on load) + BN partial sums.
  * Also serves dgrad: a0 = dZ (mode DZ/PLAIN), wpk = wpk_dgrad. */
 int hpfg_conv_fwd(const HpfgConvArgs* args, void* stream);
-int hpfg_conv_stat_blocks(int N, int H, int W);
+int hpfg_conv_stat_blocks(int N, int H, int W);          /* rows written by the fp32 kernels / upper bound for workspace sizing */
+int hpfg_conv_stat_rows(const HpfgConvArgs* args);         /* rows hpfg_conv_fwd(args) writes (depends on args->math) */
 /* BatchNorm2d train-mode statistics -> table rows mean/rstd/scale/shift, running stats (momentum .1, unbiased var)
  * (unet.py:19,23).  Either partials (float [nblk][2][C]) or pre-reduced sums (double [2][C], e.g. after an all-reduce). */
 int hpfg_bn_fwd_finalize(const float* partials, int nblk, const double* sums, double count, const float* gamma, const float* beta,

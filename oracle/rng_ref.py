@@ -1,8 +1,8 @@
 """Oracle (test infrastructure): numpy restatement of the HIP path's counter-based dropout RNG.
 
 The reference draws dropout masks from torch's Philox/MT streams (nn.Dropout, model/unet.py:21), which cannot be reproduced
-on the device; the HIP path instead uses  h = fmix32((i>>1)*0x9E3779B1 + seed), r16 = (i&1) ? h>>16 : h&0xFFFF,
-keep(i) = r16 >= floor(p*65536)  over the NHWC element index
+on the device; the HIP path instead uses  h = mix32((i>>2)*0x9E3779B1 + seed), r8 = byte (i&3) of h,
+keep(i) = r8 >= round(p*256)  over the NHWC element index
 (hpfg_amd/csrc/common.h).  This file restates that integer law bit-exactly so that (a) the device masks can be checked on
 the CPU and (b) the oracle U-Net can be run with exactly the masks the kernels used.
 """
@@ -11,7 +11,7 @@ import numpy as np
 
 def hash32(i: np.ndarray, seed: int) -> np.ndarray:
     h = (i.astype(np.uint64) * np.uint64(0x9E3779B1) + np.uint64(seed & 0xFFFFFFFF)) & np.uint64(0xFFFFFFFF)
-    h ^= h >> np.uint64(16)
+    h ^= h >> np.uint64(15)
     h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
     h ^= h >> np.uint64(13)
     h = (h * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
@@ -20,15 +20,15 @@ def hash32(i: np.ndarray, seed: int) -> np.ndarray:
 
 
 def threshold(p: float) -> int:
-    t = float(np.float32(p)) * 65536.0
-    return 0xFFFF if t >= 65535.0 else int(t)
+    t = int(np.float32(p) * np.float32(256.0) + np.float32(0.5))
+    return max(0, min(255, t))
 
 
 def keep_mask_nhwc(n_elems: int, p: float, seed: int) -> np.ndarray:
     i = np.arange(n_elems, dtype=np.uint64)
-    h = hash32(i >> np.uint64(1), seed)
-    r16 = np.where((i & np.uint64(1)) == 1, h >> np.uint32(16), h & np.uint32(0xFFFF))
-    return (r16 >= np.uint32(threshold(p))).astype(np.uint8)
+    h = hash32(i >> np.uint64(2), seed).astype(np.uint64)
+    r8 = (h >> (np.uint64(8) * (i & np.uint64(3)))) & np.uint64(0xFF)
+    return (r8 >= np.uint64(threshold(p))).astype(np.uint8)
 
 
 def keep_mask_nchw(n: int, c: int, h: int, w: int, p: float, seed: int) -> np.ndarray:

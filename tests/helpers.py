@@ -81,7 +81,7 @@ class AdHocConv:
         ca.out = L.ptr(out)
         part = None
         if stats:
-            part = torch.empty(lib.hpfg_conv_stat_blocks(N, H, W) * 2 * cpad, device=self.dev)
+            part = torch.zeros(lib.hpfg_conv_stat_blocks(N, H, W) * 2 * cpad, device=self.dev)   # unused rows stay 0
             ca.stat_partials = L.ptr(part)
         ca.out_pstride, ca.Cout, ca.CoutPad, ca.N, ca.H, ca.W, ca.taps = cout, cout, cpad, N, H, W, self.taps
         L.check(lib.hpfg_conv_fwd(C.byref(ca), stream(self.dev)), "conv_fwd")

@@ -1,4 +1,4 @@
-"""Timing ablation of one conv layer of the U-Net (GPU only, diagnostics): which part of the bf16x3 kernel dominates?
+"""Timing ablation (0x1000: no BN partial sums).   of one conv layer of the U-Net (GPU only, diagnostics): which part of the bf16x3 kernel dominates?
 flags (HpfgConvArgs.math bits): 0x100 no output stores, 0x200 no MFMA/LDS reads, 0x400 no global tile loads, 0x800 no B loads."""
 import ctypes as C
 import sys
@@ -46,6 +46,7 @@ for name in ["encoder.in_conv.conv_conv.4", "decoder.up4.conv.conv_conv.0", "enc
     base = run(name, 0)
     f32 = run(name, 0, L.MATH_F32)
     row = {"full": base, "f32": f32, "no_store": run(name, 0x100), "no_mfma": run(name, 0x200), "no_tile_loads": run(name, 0x400), "no_B": run(name, 0x800),
-           "only_loads": run(name, 0x100 | 0x200 | 0x800), "nothing": run(name, 0x100 | 0x200 | 0x400 | 0x800)}
+           "no_stats": run(name, 0x1000), "only_loads": run(name, 0x100 | 0x200 | 0x800 | 0x1000), "only_mfma": run(name, 0x100 | 0x400 | 0x800 | 0x1000),
+           "nothing": run(name, 0x100 | 0x200 | 0x400 | 0x800 | 0x1000)}
     gf = eng.N * s.h * s.w * s.cin * s.cout * 18 / 1e9
     print(f"{name} ({s.cin}->{s.cout} @{s.h}) GFLOP={gf:.2f}: " + "  ".join(f"{k}={v:.1f}us" for k, v in row.items()))
