@@ -1,0 +1,152 @@
+"""CPU: the oracle (oracle/*.py) reproduces every golden vector that oracle/make_golden.py captured from the REFERENCE's own
+modules (/root/reference/model/unet.py, utils/loss/*.py, utils/scheduler/*.py, utils/utils.py).  This is what pins the oracle; the
+GPU tests then compare the HIP path with the same fixtures and with the oracle."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import laws_ref, losses_ref, steps_ref, unet_ref
+
+torch.set_num_threads(4)
+
+
+def _unpack_masks(d, prefix, n, hw):
+    out = []
+    for lvl in range(5):
+        c, h = unet_ref.WIDTHS[lvl], hw >> lvl
+        bits = np.unpackbits(d[f"{prefix}{lvl}"])[: n * c * h * h].reshape(n, c, h, h)
+        out.append(torch.from_numpy(bits.astype(np.float32)))
+    return out
+
+
+def test_anchor_values(golden_dir):
+    a = json.load(open(f"{golden_dir}/anchors.json"))
+    assert a["param_count"] == 1813764 and a["param_count_plus"] == 3663620
+    st = unet_ref.init_state(1, 1, 4)
+    assert sum(st[k].numel() for k in unet_ref.param_names(st)) == a["param_count"]
+    for k in range(1, 7):
+        assert abs(laws_ref.medical_lr(k, 0.01, 30000) - a["medical_lr_first6"][k - 1]) < 1e-12
+    table = laws_ref.cosine_table(0.01, 0, 1e-4, 1e-6, 200, 150)
+    for k in range(1, 7):
+        assert abs(laws_ref.cosine_lr(k, table) - a["cosine_lr_first6"][k - 1]) < 1e-12
+    assert abs(a["cosine_lr_first6"][0] - 1e-6) < 1e-7        # first optimizer step runs at ~final_lr (reference quirk)
+    for e, v in zip(a["rampup_epochs"], a["rampup_sigmoid"]):
+        assert abs(laws_ref.sigmoid_rampup(e, 200.0) - v) < 1e-12
+    for e, v in zip(a["rampup_epochs"], a["rampup_linear"]):
+        assert abs(laws_ref.linear_rampup(e, 200.0) - v) < 1e-12
+    for s, v in zip((1, 2, 3, 200), a["ema_alpha_first4"]):
+        assert abs(laws_ref.ema_alpha(s, 0.99) - v) < 1e-15
+    m = laws_ref.box_masks(5, (64, 64), np.random.RandomState(1))
+    assert float(m.sum()) == a["box_mask_seed1_n5_64_sum"]
+
+
+def test_eval_forward_anchor(golden_dir):
+    a = json.load(open(f"{golden_dir}/anchors.json"))
+    st = unet_ref.init_state(1, 1, 4)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(8, 1, 224, 224, generator=g)
+    t = torch.randint(0, 4, (8, 224, 224), generator=g)
+    with torch.no_grad():
+        y = unet_ref.unet_forward(st, x, train=False)
+    assert abs(float(y.double().sum()) - a["eval_logits_sum"]) < 0.05
+    assert abs(float(y.abs().mean()) - a["eval_logits_meanabs"]) < 1e-6
+    assert np.allclose(y[0, :, 0, 0].numpy(), a["eval_logits_px00"], atol=1e-6)
+    assert abs(float(losses_ref.med_sup_loss(y, t)) - a["eval_med_sup_loss"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_train_forward_backward_fixture(golden_dir, tag):
+    d = np.load(f"{golden_dir}/unet_fwd_bwd_{tag}.npz")
+    n, hw, in_ch, ncls, seed, _ = [int(v) for v in d["meta"]]
+    st = unet_ref.init_state(seed, in_ch, ncls)
+    masks = _unpack_masks(d, "mask", n, hw)
+    names = steps_ref._train_state(st)
+    taps = {}
+    out = unet_ref.unet_forward(st, torch.from_numpy(d["x"]), True, masks, taps=taps)
+    loss = losses_ref.med_sup_loss(out, torch.from_numpy(d["labels"]).long())
+    grads = steps_ref._grads(loss, st, names)
+    assert float((out.detach() - torch.from_numpy(d["logits"])).abs().max()) < 1e-5
+    assert abs(float(loss) - float(d["loss"])) < 1e-6
+    for k in d.files:
+        if k.startswith("grad/"):
+            ref = torch.from_numpy(d[k])
+            assert float((grads[k[5:]] - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), k
+        if k.startswith("raw/"):
+            assert float((taps[k[4:]].detach() - torch.from_numpy(d[k])).abs().max()) < 1e-5, k
+        if k.startswith("bn/"):
+            assert float((st[k[3:]] - torch.from_numpy(d[k])).abs().max()) < 1e-6, k
+
+
+def test_losses_fixture(golden_dir):
+    d = np.load(f"{golden_dir}/losses.npz")
+    lg, tl, lab = torch.from_numpy(d["logits"]), torch.from_numpy(d["t_logits"]), torch.from_numpy(d["labels"])
+    p = torch.softmax(lg, 1)
+    assert abs(float(losses_ref.dice_loss(p, lab.unsqueeze(1))) - float(d["dice"])) < 1e-6
+    assert abs(float(losses_ref.dice_loss(p, lab.float())) - float(d["dice_float"])) < 1e-6
+    assert abs(float(losses_ref.med_sup_loss(lg, lab)) - float(d["med"])) < 1e-6
+    assert abs(float(losses_ref.cross_entropy(lg, lab)) - float(d["ce"])) < 1e-6
+    assert abs(float(losses_ref.mse_consistency(p, torch.softmax(tl, 1))) - float(d["mse"])) < 1e-7
+    hg = (torch.from_numpy(d["hg0"]), torch.from_numpy(d["hg1"]))
+    tg = (torch.from_numpy(d["tg0"]), torch.from_numpy(d["tg1"]))
+    assert abs(float(losses_ref.dense_loss(hg, tg)) - float(d["dense"])) < 1e-5
+    x = lg.clone().requires_grad_(True)
+    comp = losses_ref.med_sup_loss(x[:1], lab[:1]) + 0.3 * losses_ref.mse_consistency(torch.softmax(x[1:], 1), torch.softmax(tl[1:], 1))
+    comp.backward()
+    assert abs(float(comp) - float(d["comp"])) < 1e-6
+    assert float((x.grad - torch.from_numpy(d["comp_dlogits"])).abs().max()) < 1e-8
+
+
+def test_supervised_and_mean_teacher_traces(golden_dir):
+    d = np.load(f"{golden_dir}/trace_sup.npz")
+    st, bufs = unet_ref.init_state(1, 1, 4), {}
+    table = laws_ref.cosine_table(0.01, 0, 1e-4, 1e-6, 200, 150)
+    x, lab = torch.from_numpy(d["x"]), torch.from_numpy(d["labels"]).long()
+    losses = [steps_ref.supervised_step(st, bufs, x, lab, laws_ref.cosine_lr(k + 1, table), 0.9, 5e-4, _unpack_masks(d, f"it{k}_mask", 4, 32))["loss"]
+              for k in range(4)]
+    assert np.abs(np.array(losses) - d["losses"]).max() < 2e-5
+    with torch.no_grad():
+        fin = unet_ref.unet_forward(st, x, train=False)
+    assert float((fin - torch.from_numpy(d["final_eval_logits"])).abs().max()) < 2e-4
+    assert abs(losses_ref.mean_foreground_dice(fin.argmax(1).numpy(), d["labels"], 4) - float(d["final_dice"])) < 1e-6
+
+    d = np.load(f"{golden_dir}/trace_mt.npz")
+    st = unet_ref.init_state(1337, 1, 4)
+    ema, bufs = unet_ref.clone_state(st), {}
+    xl, yl, xu = torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xu"])
+    rows = []
+    for k in range(3):
+        r = steps_ref.mean_teacher_step(st, ema, bufs, xl, yl, xu, laws_ref.medical_lr(k + 1, 0.01, 30000), float(d["cons_w"]),
+                                        laws_ref.ema_alpha(k + 1, 0.99), 0.9, 1e-4, _unpack_masks(d, f"it{k}_s", 4, 32), _unpack_masks(d, f"it{k}_t", 4, 32))
+        rows.append([r["loss"], r["sup"], r["cons"]])
+    assert np.abs(np.array(rows) - d["losses"]).max() < 2e-5
+    assert float((r["logits"] - torch.from_numpy(d["student_logits_last"])).abs().max()) < 1e-4
+
+
+def test_cps_and_hpfg_traces(golden_dir):
+    d = np.load(f"{golden_dir}/trace_cps.npz")
+    torch.manual_seed(1337)
+    sa, sb = unet_ref.init_state(None, 3, 2), unet_ref.init_state(None, 3, 2)
+    ba, bb = {}, {}
+    xl, yl, xu = torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xu"])
+    rows = []
+    for k in range(2):
+        lr = laws_ref.medical_lr(k + 1, 0.01, 30000)
+        r = steps_ref.cps_step(sa, sb, ba, bb, xl, yl, xu, lr, lr, float(d["cons_w"]), 0.9, 1e-4, _unpack_masks(d, f"it{k}_a", 4, 48),
+                               _unpack_masks(d, f"it{k}_b", 4, 48))
+        rows.append([r["loss"], r["sup"], r["semi"]])
+    assert np.abs(np.array(rows) - d["losses"]).max() < 5e-5
+
+    d = np.load(f"{golden_dir}/trace_hpfg.npz")
+    torch.manual_seed(1)
+    sa, sb = unet_ref.init_state(None, 1, 4, True), unet_ref.init_state(None, 1, 4, True)
+    se, ba, bb = unet_ref.clone_state(sb), {}, {}
+    rows = []
+    for j, cur in enumerate(d["cur_itrs"]):
+        r = steps_ref.hpfg_step(sa, sb, se, ba, bb, torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xl1"]),
+                                torch.from_numpy(d["yl1"]).long(), torch.from_numpy(d["xu"]), torch.from_numpy(d["cutmix"][j]), int(cur), 0.01, 0.01, 0.1,
+                                200.0, 0.99, 0.9, 5e-4, _unpack_masks(d, f"it{j}_a", 4, 64), _unpack_masks(d, f"it{j}_b", 4, 64),
+                                _unpack_masks(d, f"it{j}_t", 4, 64))
+        rows.append([r["loss"], r["sup"], r["semi"], r["pseudo_sup"], r["contrast"]])
+    assert np.abs(np.array(rows) - d["losses"]).max() < 1e-4
