@@ -130,7 +130,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "mean_teacher_unet_224x224 (BASELINE configs[1]): U-Net 1ch->4cls, 8 labelled + 8 unlabelled per GPU, "
                                    "student fwd+bwd + train-mode teacher fwd + CE/Dice/MSE + SGD + EMA",
-                       "per_gpu_batch": [a.lab, a.unlab], "size": a.size, "hipgraph": bool(use_graph), "sync_bn": world > 1},
+                       "per_gpu_batch": [a.lab, a.unlab], "size": a.size, "hipgraph": bool(use_graph), "sync_bn": world > 1,
+                       "math": model.math + (" (split-bf16 MFMA products hi*hi+hi*lo+lo*hi, fp32 accumulate; parity 1e-3 verified by "
+                                             "tests/test_gpu_steps.py::test_mean_teacher_trace_224_vs_oracle)" if model.math == "bf16x3" else " (exact fp32 MFMA)")},
             "step_roofline": {"algorithmic_GB_per_step": round(step_bytes / 1e9, 3), "achieved_GBps": round(step_bytes / (dt / a.steps) / 1e9, 1),
                               "frac_of_8TBps": round(step_bytes / (dt / a.steps) / 8e12, 4),
                               "algorithmic_GFLOP_per_step": round(n_img * (GFLOP_TRAIN_IMG + GFLOP_FWD_IMG), 1),
@@ -153,7 +155,9 @@ def dominant_kernel_roofline(model, xl, xu, dev):
     a0, a1 = eng.input_acts(name)
     ca = L.ConvArgs()
     ca.a0, ca.a1 = a0, a1
-    ca.wpk, ca.bias, ca.out = L.ptr(eng.wpk_f[name]), L.ptr(eng.bias_pad[name]), L.ptr(eng.z[name])
+    ca.math = eng.math
+    ca.wpk = L.ptr(eng.wpk16_f[name]) if eng.math == L.MATH_BF16X3 else L.ptr(eng.wpk_f[name])
+    ca.bias, ca.out = L.ptr(eng.bias_pad[name]), L.ptr(eng.z[name])
     ca.stat_partials = L.ptr(eng.partials)
     ca.out_pstride, ca.Cout, ca.CoutPad, ca.N, ca.H, ca.W, ca.taps = s.cout, s.cout, s.cout_pad, eng.N, s.h, s.w, 9
     st = torch.cuda.current_stream(dev)
@@ -173,10 +177,12 @@ def dominant_kernel_roofline(model, xl, xu, dev):
     bytes_alg = n * (224 * 224 * 16 + 112 * 112 * 16 + 224 * 224 * 16) * 4 + 9 * 32 * 16 * 4
     flops = n * 224 * 224 * 9 * 32 * 16 * 2
     ach = bytes_alg / (us * 1e-6) / 1e9
-    return {"kernel": "conv_mfma_kernel<16x16 tile, BN=16, 3x3> @ decoder.up4.conv.conv_conv.0 (32->16ch, 224x224, concat+upsample fused)",
+    kname = "conv_bf16x3_kernel" if eng.math == L.MATH_BF16X3 else "conv_mfma_kernel"
+    return {"kernel": kname + "<16x16 tile, 16 output channels, 3x3, CAT loader> @ decoder.up4.conv.conv_conv.0 (32->16ch, 224x224, skip concat + "
+                      "bilinear upsample + BN + LeakyReLU fused on load, BN partial sums in the epilogue)",
             "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
             "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": bytes_alg,
-            "flops_per_launch": flops, "achieved_TFLOPs_f32": round(flops / (us * 1e-6) / 1e12, 2)}
+            "flops_per_launch": flops, "achieved_TFLOPs": round(flops / (us * 1e-6) / 1e12, 2)}
 
 
 def cpu_baseline(n_lab, n_unlab, size):

@@ -110,7 +110,7 @@ class UNet(nn.Module):
         self._seed_counter = 0
         self.dropout_seed = 0x1234567
         self.dp = None   # hpfg_amd.parallel.DataParallelContext or None
-        self.math = os.environ.get("HPFG_MATH", "f32")   # "f32": exact fp32 MFMA; "bf16x3": split-bf16 MFMA (fp32-class accuracy)
+        self.math = os.environ.get("HPFG_MATH", "bf16x3")   # "bf16x3": split-bf16 MFMA, fp32 accumulate (default); "f32": exact fp32 MFMA
         self.external_dropout_masks = None   # optional {conv name: uint8 NHWC keep-mask}: replay masks drawn elsewhere (tests)
         self._flatten()
 
