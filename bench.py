@@ -177,10 +177,17 @@ def dominant_kernel_roofline(model, xl, xu, dev):
     bytes_alg = n * (224 * 224 * 16 + 112 * 112 * 16 + 224 * 224 * 16) * 4 + 9 * 32 * 16 * 4
     flops = n * 224 * 224 * 9 * 32 * 16 * 2
     ach = bytes_alg / (us * 1e-6) / 1e9
+    traffic = None
+    try:      # HBM bytes of this launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, see the file)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_dominant_kernel.json")))
+        if n == 16 and eng.math == L.MATH_BF16X3:
+            traffic = int(tj["hbm_bytes_per_launch"])
+    except Exception:
+        traffic = None
     kname = "conv_bf16x3_kernel" if eng.math == L.MATH_BF16X3 else "conv_mfma_kernel"
     return {"kernel": kname + "<16x16 tile, 16 output channels, 3x3, CAT loader> @ decoder.up4.conv.conv_conv.0 (32->16ch, 224x224, skip concat + "
                       "bilinear upsample + BN + LeakyReLU fused on load, BN partial sums in the epilogue)",
-            "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+            "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
             "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": bytes_alg,
             "flops_per_launch": flops, "achieved_TFLOPs": round(flops / (us * 1e-6) / 1e12, 2)}
 
