@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--lab", type=int, default=8)
     ap.add_argument("--unlab", type=int, default=8)
     ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--force-sync", action="store_true", help="diagnostics: run the data-parallel code path (RCCL collectives) on one rank")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -61,7 +62,10 @@ def main():
     from hpfg_amd.train import GraphedStep, MeanTeacherStep
     from hpfg_amd.utils import loadyaml
 
-    dp = parallel.init_from_env(dev) if world > 1 else None
+    dp = parallel.init_from_env(dev) if (world > 1 or a.force_sync) else None
+    if a.force_sync and dp is not None:
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dp.force_sync = True
     args = loadyaml(os.path.join(ROOT, "config", "mean_teacher_unet_30k_224x224_ACDC.yaml"))
     args.batch_size, args.unlabel_batch_size = a.lab, a.unlab
     torch.manual_seed(args.seed)
@@ -76,7 +80,9 @@ def main():
     xu, _ = synth_batch(91234 + rank, a.unlab, a.size, a.size, 1, 4, 32)
     xl, yl, xu = xl.to(dev), yl.to(dev), xu.to(dev)
 
-    use_graph = (not a.no_graph) and world == 1
+    # N > 1 runs eager: the ~90 small BatchNorm collectives per step, not launch overhead, bound the multi-GPU step; a captured
+    # step with RCCL nodes works on one rank (tests/test_gpu_dp_path.py) and can be forced with HPFG_DP_GRAPH=1
+    use_graph = (not a.no_graph) and (world == 1 or os.environ.get("HPFG_DP_GRAPH", "0") == "1")
     runner = None
     it = 0
     if use_graph:

@@ -118,6 +118,7 @@ class UNetEngine:
         self._bwd_alloc = False
         self.x: Optional[torch.Tensor] = None
         self.world = 1
+        self.force_sync = False  # run the data-parallel code path (reduce -> all-reduce -> finalize) even with one rank (tests)
         self.math = L.MATH_F32      # L.MATH_BF16X3 selects the split-bf16 matrix-core kernels for conv forward / dgrad
         self.ext_masks: Dict[str, torch.Tensor] = {}   # conv name -> uint8 NHWC keep-mask (parity tests replaying torch's masks)
         self.allreduce = None    # callable(tensor) -> in-place sum across ranks (data parallel), set by hpfg_amd.parallel
@@ -197,7 +198,7 @@ class UNetEngine:
         g, b = self.params[f"{s.bn}.weight"], self.params[f"{s.bn}.bias"]
         rm = self.buffers[f"{s.bn}.running_mean"] if track else None
         rv = self.buffers[f"{s.bn}.running_var"] if track else None
-        if self.world > 1:
+        if self.world > 1 or self.force_sync:
             sums = self.sums[: 2 * s.cout_pad]
             L.check(self.lib.hpfg_reduce_partials(L.ptr(self.partials), nblk, s.cout_pad, L.ptr(sums), st), "reduce_partials")
             self.allreduce(sums)
@@ -305,7 +306,7 @@ class UNetEngine:
         count = float(self.N * s.h * s.w * self.world)
         gam = self.params[f"{s.bn}.weight"]
         dg, db = self.grads[f"{s.bn}.weight"], self.grads[f"{s.bn}.bias"]
-        if self.world > 1:
+        if self.world > 1 or self.force_sync:
             sums = self.sums[: 2 * s.cout]
             L.check(self.lib.hpfg_reduce_partials(L.ptr(self.partials), nblk, s.cout, L.ptr(sums), st), "reduce_partials")
             self.allreduce(sums)

@@ -252,6 +252,7 @@ class UNet(nn.Module):
         eng.ext_masks = self.external_dropout_masks or {}
         if self.dp is not None:
             eng.world, eng.allreduce = self.dp.world_size, self.dp.allreduce_sum
+            eng.force_sync = bool(getattr(self.dp, "force_sync", False))
         return eng
 
     def _accumulate_grads(self, eng: E.UNetEngine):

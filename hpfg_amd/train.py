@@ -76,7 +76,7 @@ class _StepBase:
         model.dp = self.dp
 
     def _reduce_grads(self, *models):
-        if self.dp is not None and self.dp.world_size > 1:
+        if self.dp is not None and (self.dp.world_size > 1 or self.dp.force_sync):
             for m in models:
                 self.dp.allreduce_sum(m.flat_grads)
 

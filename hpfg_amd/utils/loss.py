@@ -55,7 +55,7 @@ class _SegLossFn(torch.autograd.Function):
         a.input_is_prob = 1 if is_prob else 0
         st = torch.cuda.current_stream(dev).cuda_stream
         L.check(lib.hpfg_seg_loss_partials(C.byref(a), st), "seg_loss_partials")
-        if dp is not None and dp.world_size > 1:
+        if dp is not None and (dp.world_size > 1 or dp.force_sync):
             dp.allreduce_sum(sums)
         L.check(lib.hpfg_seg_loss_finalize(C.byref(a), st), "seg_loss_finalize")
         ctx.args, ctx.keep = a, (x, t, labels0, labels1, coef, sums)

@@ -1,0 +1,68 @@
+"""GPU, one rank: the data-parallel code path (BN partial sums -> reduce -> RCCL all-reduce -> finalize; loss-sum and flat-gradient
+all-reduce) run on a 1-rank `nccl` process group must reproduce the single-GPU path exactly, eagerly and captured into a hipGraph."""
+import os
+from copy import deepcopy
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from hpfg_amd import parallel
+from hpfg_amd.datasets.synthetic import synth_batch
+from hpfg_amd.model import UNet
+from hpfg_amd.train import GraphedStep, MeanTeacherStep
+from hpfg_amd.utils import AttrDict
+from tests.helpers import maxerr
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _args():
+    return AttrDict(opt="sgd", lr=0.01, momentum=0.9, weight_decay=1e-4, sched="medical", total_itrs=30000, step_size=200, warmup_epochs=0,
+                    warmup_lr=1e-4, min_lr=1e-6, consistency=0.1, consistency_rampup=200.0, ema_decay=0.99)
+
+
+def _run(dp, graphed=False, steps=3):
+    torch.manual_seed(7)
+    m = UNet(1, 4).to(DEV)
+    ema = deepcopy(m)
+    for p in ema.parameters():
+        p.requires_grad = False
+    m.train()
+    ema.train()
+    st = MeanTeacherStep(m, ema, _args(), dp)
+    xl, yl = synth_batch(1, 2, 64, 64, 1, 4, 8)
+    xu, _ = synth_batch(2, 2, 64, 64, 1, 4, 8)
+    xl, yl, xu = xl.to(DEV), yl.to(DEV), xu.to(DEV)
+    if graphed:
+        g = GraphedStep(st, [xl, yl, xu], warmup=1)
+        outs = [float(g.step([xl, yl, xu], k, cons_w=0.05)["loss"]) for k in range(2, steps + 2)]
+        return outs, m.flat_params.clone()
+    outs = [float(st.step(xl, yl, xu, k, cons_w=0.05)["loss"]) for k in range(1, steps + 1)]
+    return outs, m.flat_params.clone()
+
+
+@pytest.fixture(scope="module")
+def dp():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    ctx = parallel.init_from_env(DEV)
+    ctx.force_sync = True
+    yield ctx
+    ctx.shutdown()
+
+
+def test_sync_path_equals_local_path(dp):
+    l0, p0 = _run(None)
+    l1, p1 = _run(dp)
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 1e-5, (l0, l1)
+    assert maxerr(p0.cpu(), p1.cpu()) < 1e-5
+
+
+def test_sync_path_captures_into_a_graph(dp):
+    """RCCL collectives inside the captured step (what bench.py does for N > 1 when HPFG_DP_GRAPH=1)."""
+    lg, _ = _run(dp, graphed=True, steps=2)
+    assert all(x == x and abs(x) < 10 for x in lg)
