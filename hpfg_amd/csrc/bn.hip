@@ -74,41 +74,61 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   if (threadIdx.x == 0) sums[which * C + c] = a;
 }
 
-// Backward reduction.  Each workgroup walks PIX_PER_BLOCK pixels; thread t owns channel quad (t % Q) and pixel lane t / Q.
-constexpr int BWD_PIX_PER_BLOCK = 512;
+// Backward reduction: streaming pass over (dA, z).  Thread t owns channel quad t % Q (its BatchNorm table lives in registers)
+// and pixel lane t / Q; a workgroup strides over the pixels with four independent pixel loads in flight per thread.
+constexpr int BWD_MAX_BLOCKS = 1024;
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(HpfgAct s, long npix, float* __restrict__ partials) {
   __shared__ float red[256 * 8];
   const int C = s.C, Q = C >> 2, tid = threadIdx.x;
   const ActCtx cx = make_ctx(s);
-  float a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-  const long p0 = (long)blockIdx.x * BWD_PIX_PER_BLOCK;
-  long p1 = p0 + BWD_PIX_PER_BLOCK;
-  if (p1 > npix) p1 = npix;
-  if (Q <= 256) {
-    const int q = tid % Q, pl = tid / Q, PL = 256 / Q;
-    for (long pix = p0 + pl; pix < p1; pix += PL) {
-      f32x4 g, xh;
-      dz_load_g_xhat(s, cx, pix, q * 4, g, xh);
+  const int q = tid % Q, pl = tid / Q, PL = 256 / Q;
+  const int c = q * 4;
+  const float* t = s.bn + s.bn_coff + c;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(t + HPFG_BN_MEAN * s.bn_stride);
+  const f32x4 rs = *reinterpret_cast<const f32x4*>(t + HPFG_BN_RSTD * s.bn_stride);
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(t + HPFG_BN_SCALE * s.bn_stride);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(t + HPFG_BN_SHIFT * s.bn_stride);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+  const long stride = (long)gridDim.x * PL;
+  for (long p0 = (long)blockIdx.x * PL + pl; p0 < npix; p0 += 4 * stride) {
+    f32x4 z[4], g[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        a[j] += g[j];
-        b[j] += g[j] * xh[j];
+    for (int u = 0; u < 4; ++u) {
+      const long pix = p0 + u * stride;
+      if (pix < npix) {
+        z[u] = *reinterpret_cast<const f32x4*>(s.z + pix * s.pstride + c);
+        g[u] = *reinterpret_cast<const f32x4*>(s.aux + pix * s.aux_pstride + c);
+      } else {
+        z[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        g[u] = z[u];
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      red[tid * 8 + j] = a[j];
-      red[tid * 8 + 4 + j] = b[j];
+    for (int u = 0; u < 4; ++u) {
+      const long pix = p0 + u * stride;
+      uint32_t km = 0xFu;
+      if (s.drop_p > 0.f && pix < npix) km = keep4(s, cx, (uint32_t)(pix * C + c));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float gg = (km >> j) & 1u ? g[u][j] * cx.inv_keep : 0.f;
+        gg = z[u][j] * sc[j] + sh[j] > 0.f ? gg : HPFG_LEAKY * gg;
+        a[j] += gg;
+        b[j] += gg * ((z[u][j] - mu[j]) * rs[j]);
+      }
     }
-    __syncthreads();
-    // thread (which, c) for c < C sums over pixel lanes
-    for (int o = tid; o < 2 * C; o += 256) {
-      int which = o / C, c = o % C, qq = c >> 2, j = c & 3;
-      float t = 0.f;
-      for (int l = 0; l < PL; ++l) t += red[(l * Q + qq) * 8 + which * 4 + j];
-      partials[((long)blockIdx.x * 2 + which) * C + c] = t;
-    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[tid * 8 + j] = a[j];
+    red[tid * 8 + 4 + j] = b[j];
+  }
+  __syncthreads();
+  for (int o = tid; o < 2 * C; o += 256) {
+    const int which = o / C, cc = o % C, qq = cc >> 2, j = cc & 3;
+    float acc = 0.f;
+    for (int l = 0; l < PL; ++l) acc += red[(l * Q + qq) * 8 + which * 4 + j];
+    partials[((long)blockIdx.x * 2 + which) * C + cc] = acc;
   }
 }
 
@@ -180,9 +200,11 @@ extern "C" int hpfg_reduce_partials(const float* partials, int nblk, int C, doub
 }
 
 extern "C" int hpfg_bn_bwd_blocks(int N, int H, int W, int C) {
-  (void)C;
-  long npix = (long)N * H * W;
-  return (int)((npix + BWD_PIX_PER_BLOCK - 1) / BWD_PIX_PER_BLOCK);
+  const long npix = (long)N * H * W;
+  const int PL = 256 / (C / 4);                       // pixels a workgroup covers per sweep
+  long want = (npix + (long)PL * 16 - 1) / ((long)PL * 16);   // ~16 pixels per thread
+  if (want < 1) want = 1;
+  return (int)(want > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : want);
 }
 
 extern "C" int hpfg_bn_bwd_reduce(const HpfgAct* g, int N, int H, int W, float* partials, void* stream) {

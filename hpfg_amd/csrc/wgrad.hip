@@ -45,6 +45,36 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
+// all layers of a backward pass in one launch: blockIdx.y = layer, workgroups stride over that layer's 16-element groups
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const HpfgSlabDesc* __restrict__ table) {
+  __shared__ float red[16][17];
+  const HpfgSlabDesc d = table[blockIdx.y];
+  const long per = (long)d.taps * d.CinPad * d.CoutPad;
+  const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  for (long g0 = (long)blockIdx.x * 16; g0 < per; g0 += (long)gridDim.x * 16) {
+    const long i = g0 + il;
+    float t0 = 0.f, t1 = 0.f;
+    if (i < per) {
+      int s = sl;
+      for (; s + 16 < d.S; s += 32) {
+        t0 += d.slab[s * per + i];
+        t1 += d.slab[(s + 16) * per + i];
+      }
+      if (s < d.S) t0 += d.slab[s * per + i];
+    }
+    __syncthreads();
+    red[sl][il] = t0 + t1;
+    __syncthreads();
+    if (sl == 0 && i < per) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[k][il];
+      const int co = (int)(i % d.CoutPad), ci = (int)((i / d.CoutPad) % d.CinPad), tap = (int)(i / ((long)d.CoutPad * d.CinPad));
+      if (co < d.Cout && ci < d.Cin) d.dw_oihw[((long)co * d.Cin + ci) * d.taps + tap] = t;
+    }
+  }
+}
+
 // db[c] = sum_p g[p*pstride + c]: two-stage deterministic reduction
 __global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restrict__ g, int pstride, long npix, int C, float* __restrict__ scratch) {
   __shared__ float red[256];
@@ -108,11 +138,24 @@ extern "C" int hpfg_wgrad(const HpfgWgradArgs* a, void* stream) {
     hpfg_set_error("wgrad: unsupported gradient source mode %d", a->g.mode);
     return -1;
   }
-  if (rc) return rc;
+  if (rc || a->defer_reduce) return rc;
   long per = (long)a->taps * a->CinPad * a->CoutPad;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((per + 15) / 16)), dim3(256), 0, st, a->slab, a->dw_oihw, a->S, a->taps, a->Cin, a->CinPad,
                      a->Cout, a->CoutPad);
   return hpfg_launch_status("slab_reduce_kernel");
+}
+
+extern "C" int hpfg_slab_reduce_multi(const HpfgSlabDesc* table_dev, const HpfgSlabDesc* table_host, int nlayers, void* stream) {
+  HPFG_ARG_CHECK(table_dev && table_host && nlayers > 0 && nlayers < 65536, "slab_reduce_multi: bad args");
+  long mx = 0;
+  for (int i = 0; i < nlayers; ++i) {
+    long per = (long)table_host[i].taps * table_host[i].CinPad * table_host[i].CoutPad;
+    if (per > mx) mx = per;
+  }
+  long gx = (mx + 15) / 16;
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((unsigned)gx, nlayers), dim3(256), 0, (hipStream_t)stream, table_dev);
+  return hpfg_launch_status("slab_reduce_multi_kernel");
 }
 
 extern "C" int hpfg_channel_sum(const float* g, int pstride, long npix, int C, float* out, float* scratch, void* stream) {

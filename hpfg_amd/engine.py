@@ -292,8 +292,19 @@ class UNetEngine:
                                   self.specs[f"decoder.up{k}.conv1x1"].cout, **f32) for k in range(1, 5)}
         self.dP = {lvl: torch.empty(N, self.specs[enc_prefix(lvl) + ".0"].h, self.specs[enc_prefix(lvl) + ".0"].w,
                                     self.specs[enc_prefix(lvl) + ".0"].cin, **f32) for lvl in range(1, 5)}
-        slab = max(self.lib.hpfg_wgrad_slab_floats(N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps) for s in self.order)
-        self.slab = torch.empty(slab, **f32)
+        # one slab region per layer; all of them are summed by ONE launch at the end of backward()
+        sizes = [self.lib.hpfg_wgrad_slab_floats(N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps) for s in self.order]
+        self.slab_all = torch.empty(sum(sizes), **f32)
+        self.slab_of, off = {}, 0
+        descs = (L.SlabDesc * len(self.order))()
+        for d, s, sz in zip(descs, self.order, sizes):
+            self.slab_of[s.name] = self.slab_all[off:off + sz]
+            off += sz
+            d.slab, d.dw_oihw = L.ptr(self.slab_of[s.name]), L.ptr(self.grads[f"{s.name}.weight"])
+            d.S = self.lib.hpfg_wgrad_splits(N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps)
+            d.taps, d.Cin, d.CinPad, d.Cout, d.CoutPad = s.taps, s.cin, s.cin_pad, s.cout, s.cout_pad
+        self._slab_host = descs
+        self._slab_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.dev)
         self.csum_scratch = torch.empty(512 * 256, **f32)
         self._bwd_alloc = True
 
@@ -321,7 +332,7 @@ class UNetEngine:
         wa = L.WgradArgs()
         wa.a0, wa.a1 = self.input_acts(s.name)
         wa.g = g
-        wa.slab, wa.dw_oihw = L.ptr(self.slab), L.ptr(self.grads[f"{s.name}.weight"])
+        wa.slab, wa.dw_oihw, wa.defer_reduce = L.ptr(self.slab_of[s.name]), L.ptr(self.grads[f"{s.name}.weight"]), 1
         wa.Cin, wa.CinPad, wa.Cout, wa.CoutPad = s.cin, s.cin_pad, s.cout, s.cout_pad
         wa.N, wa.H, wa.W, wa.taps = self.N, s.h, s.w, s.taps
         wa.S = self.lib.hpfg_wgrad_splits(self.N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps)
@@ -394,4 +405,5 @@ class UNetEngine:
                 src.drop_p = 0.0
                 L.check(self.lib.hpfg_pool_scatter_add(C.byref(src), L.ptr(self.dP[lvl]), s1.cin, L.ptr(self.dA[below]), self.dA_ps[below],
                                                        N, s1.h, s1.w, st), "pool_scatter_add")
+        L.check(self.lib.hpfg_slab_reduce_multi(self._slab_dev.data_ptr(), self._slab_host, len(self.order), st), "slab_reduce_multi")
         self.bwd_ready = False

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 103
+#define HPFG_VERSION 104
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -81,7 +81,14 @@ typedef struct HpfgWgradArgs {
   int32_t N, H, W, taps;
   int32_t S;            /* number of pixel splits (slabs), from hpfg_wgrad_splits() */
   int32_t math;         /* HPFG_MATH_F32 or HPFG_MATH_BF16X3 (3x3 only; 1x1 always runs the exact fp32 kernel) */
+  int32_t defer_reduce; /* 1: leave the slabs in `slab`; the caller sums them later with hpfg_slab_reduce_multi (one launch per backward) */
 } HpfgWgradArgs;
+
+typedef struct HpfgSlabDesc {   /* one layer of hpfg_slab_reduce_multi: dw_oihw[co][ci][tap] = sum_s slab[s][tap][ci][co] */
+  const float* slab;
+  float* dw_oihw;
+  int32_t S, taps, Cin, CinPad, Cout, CoutPad;
+} HpfgSlabDesc;
 
 typedef struct HpfgPackDesc {   /* one conv layer for hpfg_pack_weights (device array of these) */
   const float* w_oihw;  /* [Cout][Cin][k][k] (nn.Conv2d.weight, unet.py:18,22,50,99) */
@@ -132,6 +139,7 @@ int hpfg_bn_bwd_blocks(int N, int H, int W, int C);
 int hpfg_bn_bwd_finalize(const float* partials, int nblk, const double* sums, double count, const float* gamma,
                          float* bn, float* dgamma, float* dbeta, int C, void* stream);
 int hpfg_wgrad(const HpfgWgradArgs* args, void* stream);
+int hpfg_slab_reduce_multi(const HpfgSlabDesc* table_dev, const HpfgSlabDesc* table_host, int nlayers, void* stream);
 int hpfg_wgrad_splits(int N, int H, int W, int CinPad, int CoutPad, int taps);
 long hpfg_wgrad_slab_floats(int N, int H, int W, int CinPad, int CoutPad, int taps);
 /* first-layer wgrad: dW[co][ci][tap] for Cin<=4 from the strided input */
