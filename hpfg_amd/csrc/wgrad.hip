@@ -108,7 +108,7 @@ extern "C" int hpfg_wgrad_splits(int N, int H, int W, int CinPad, int CoutPad, i
   int nj = pick_nj(CoutPad);
   long pairs = (long)(CinPad / 16) * (CoutPad / (16 * nj));
   long nwork = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-  long target = 1024 / pairs;               // aim at ~1k workgroups per launch
+  long target = 640 / pairs;                // aim at ~one resident wave of workgroups (2-3 per CU): fewer, longer slabs
   if (target < 1) target = 1;
   if (target > nwork) target = nwork;
   long per_block = (nwork + target - 1) / target;   // work items per workgroup

@@ -16,6 +16,7 @@ The driver loops at the bottom keep the reference's function names and signature
 from __future__ import annotations
 
 import ctypes as C
+import os
 from copy import deepcopy
 from typing import Dict, Optional
 
@@ -71,6 +72,33 @@ class _StepBase:
     def __init__(self, dev, dp=None):
         self.dev, self.dp = dev, dp
         self.sc = StepScalars(dev)
+        # the no-grad teacher forward is independent of the student forward: run it on a second HIP stream so that the two
+        # kernel chains (and, data parallel, their small BatchNorm collectives) overlap; joins before the loss.
+        self.overlap = os.environ.get("HPFG_OVERLAP", "1") == "1"
+        self.side = torch.cuda.Stream(device=dev) if self.overlap else None
+
+    def _teacher_forward(self, ema_model, x):
+        """ema_model(x) under no_grad, on the side stream when overlap is enabled.  Returns the teacher outputs."""
+        if not self.overlap:
+            with torch.no_grad():
+                return ema_model(x)
+        cur = torch.cuda.current_stream(self.dev)
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side), torch.no_grad():
+            out = ema_model(x)
+        self._pending_join = True
+        return out
+
+    def _join_teacher(self, *outs):
+        if self.overlap and getattr(self, "_pending_join", False):
+            cur = torch.cuda.current_stream(self.dev)
+            cur.wait_stream(self.side)
+            for o in outs:
+                for t_ in (o if isinstance(o, (tuple, list)) else (o,)):
+                    for u in (t_ if isinstance(t_, (tuple, list)) else (t_,)):
+                        if torch.is_tensor(u):
+                            u.record_stream(cur)
+            self._pending_join = False
 
     def _attach(self, model):
         model.dp = self.dp
@@ -140,9 +168,9 @@ class MeanTeacherStep(_StepBase):
     def device_step(self, label_img, target_label, unlabel_img):
         nl = label_img.shape[0]
         x = torch.cat([label_img, unlabel_img], 0)
+        t_out = self._teacher_forward(self.ema_model, x)
         out = self.model(x)
-        with torch.no_grad():
-            t_out = self.ema_model(x)
+        self._join_teacher(t_out)
         res = seg_loss(out, target_label, nl, coef=self.sc.view(S_COEF_A, 8), teacher_logits=t_out, dp=self.dp)
         self.optimizer.zero_grad()
         res[0].backward()
@@ -255,9 +283,10 @@ class HPFGStep(_StepBase):
         batch_mix = torch.cat([label_img, mix_un], 0)
         o1, _, _ = self.model1(batch_mix)
         volume = torch.cat([label_img, img_unlabel], 0)
+        volume_t = volume
+        ot, th1, th2 = self._teacher_forward(self.ema_model, volume_t)
         o2, h1, h2 = self.model2(volume)
-        with torch.no_grad():
-            ot, th1, th2 = self.ema_model(volume)
+        self._join_teacher(ot, th1, th2)
         pseudo = argmax_labels(ot[nl:], target_label1, cutmix_mask[:, 0])
         r1 = seg_loss(o1, target_label, nl, coef=self.sc.view(S_COEF_A, 8), pseudo=pseudo, dp=self.dp)
         r2 = seg_loss(o2, target_label, nl, coef=self.sc.view(S_COEF_B, 8), teacher_logits=ot, dp=self.dp)
