@@ -88,8 +88,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(HpfgAct x, const float*
 }  // namespace
 
 extern "C" int hpfg_conv_stat_blocks(int N, int H, int W) {
-  int t = tile_is_big(H, W) ? 16 : 8;
-  return N * ((H + t - 1) / t) * ((W + t - 1) / t);
+  if (tile_is_big(H, W)) return N * (H / 16) * (W / 16);
+  const int a = N * ((H + 7) / 8) * ((W + 7) / 8), b = N * ((H + 3) / 4) * ((W + 15) / 16);   // 8x8 (fp32 path) / 4x16 (bf16x3 3x3 path)
+  return a > b ? a : b;
 }
 
 static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only);
@@ -124,8 +125,9 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
     hpfg_set_error("conv_fwd(bf16x3): unsupported source combination (a0.mode=%d, a1.mode=%d)", a->a0.mode, a->a1.mode);
     return -1;
   }
-  if (rows_only) {
-    *rows_only = hpfg_conv_stat_blocks(a->N, a->H, a->W);
+  if (rows_only) {   // fp32 kernels: one row per 16x16 (or 8x8) tile
+    const int tl = tile_is_big(a->H, a->W) ? 16 : 8;
+    *rows_only = a->N * ((a->H + tl - 1) / tl) * ((a->W + tl - 1) / tl);
     return 0;
   }
   switch (hpfg_kind_of(a->a0, a->a1)) {

@@ -16,6 +16,7 @@
 //     hoisted into registers, addresses are 32-bit, and the producer chain (BN + LeakyReLU + Dropout | MaxPool | bilinear)
 //     is specialised per loader kind at compile time.
 #pragma once
+#include <stdlib.h>
 #include "stage.h"
 
 namespace hpfg_conv16 {
@@ -204,12 +205,26 @@ __global__ __launch_bounds__(256, (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3
   const int nt0 = (cb * C::WN + wn) * C::NI;
   const bf16x8* wpk = reinterpret_cast<const bf16x8*>(p.wpk);
 
-  int w = blockIdx.x;
-  if (w >= nwork) return;
+  // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (b % 8 names the XCD group), each XCD has its own
+  // L2.  Give every XCD group a CONTIGUOUS range of tiles (row-major inside an image) so that tiles sharing a halo are read
+  // through the same L2; inside a group, workgroup j takes tiles j, j + G, j + 2G, ... of the range.  (Speed only: any mapping
+  // is correct.)
+  const int nx = gridDim.x >= 8 ? 8 : 1;
+  const int xg = (int)blockIdx.x % nx, xj = (int)blockIdx.x / nx;
+  const int per_x = (nwork + nx - 1) / nx;                 // tiles per XCD group
+  const int wend = (xg + 1) * per_x < nwork ? (xg + 1) * per_x : nwork;
+  const int G = ((int)gridDim.x - xg + nx - 1) / nx;       // workgroups in this group
+  int w = xg * per_x + xj;
+  if (w >= wend) {   // no tile for this workgroup: its BatchNorm partial row must still be defined
+    if (p.stat_partials && threadIdx.x < 2 * C::BN) {
+      const int co = cb * C::BN + (int)threadIdx.x % C::BN;
+      if (co < p.CoutPad) p.stat_partials[((long)blockIdx.x * 2 + (int)threadIdx.x / C::BN) * p.CoutPad + co] = 0.f;
+    }
+    return;
+  }
   int n = w / ntiles, tyi = (w % ntiles) / tiles_x, txi = (w % ntiles) % tiles_x;
   int ty0 = tyi * C::TH, tx0 = txi * C::TW;
-  // stepping to this workgroup's next tile (w += gridDim.x) without divisions: decompose the stride once
-  const int G = (int)gridDim.x;
+  // stepping to this workgroup's next tile (w += G) without divisions: decompose the stride once
   const int gn = G / ntiles, gty = (G % ntiles) / tiles_x, gtx = (G % ntiles) % tiles_x;
   f32x4 s1[C::NI], s2[C::NI];
 #pragma unroll
@@ -248,8 +263,8 @@ __global__ __launch_bounds__(256, (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3
       const unsigned char* cur = lds + (item & 1) * C::BUF_BYTES;
       unsigned char* nxt = lds + ((item + 1) & 1) * C::BUF_BYTES;
       const bool last_chunk = ch + 1 == nchunks;
-      const int w2 = w + (int)gridDim.x;
-      const bool more = !last_chunk || w2 < nwork;
+      const int w2 = w + G;
+      const bool more = !last_chunk || w2 < wend;
       const int nch = last_chunk ? 0 : ch + 1;
       int nn = n, nty = ty0, ntx = tx0;
       if (last_chunk && more) {
@@ -334,7 +349,7 @@ __global__ __launch_bounds__(256, (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3
 #pragma unroll
       for (int j = 0; j < C::NI; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     w += G;
-    if (w >= nwork) break;
+    if (w >= wend) break;
     txi += gtx;
     tyi += gty;
     n += gn;
@@ -428,7 +443,7 @@ int persistent_grid(const HpfgConvArgs& a) {
   const int tx = (a.W + C::TW - 1) / C::TW, ty = (a.H + C::TH - 1) / C::TH;
   const int lds_bytes = 2 * C::BUF_BYTES + 2 * 4 * C::BN * 4;
   int per_cu = 160 * 1024 / lds_bytes;
-  const int reg_cap = (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3;   // matches __launch_bounds__
+  const int reg_cap = (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3;   // matches __launch_bounds__ (waves per SIMD)
   if (per_cu > reg_cap) per_cu = reg_cap;
   if (per_cu < 1) per_cu = 1;
   long nwork = (long)tx * ty * a.N;
@@ -464,6 +479,21 @@ int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
     }
     if (cp % 32 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 2, TAPS, KCB>, KIND>(a, st, rows_only);   // 3x3: 32-channel slices (B ring = 80 VGPRs)
     return launch_cfg<Cfg<16, 16, 4, 1, 1, TAPS, KCB>, KIND>(a, st, rows_only);
+  }
+  if constexpr (TAPS == 9) {
+    // 3x3 on sizes that are not multiples of 16 (56, 28, 14, ...): 4x16-pixel tiles.  Same 64 pixels per workgroup as an 8x8 tile
+    // but the LDS image needs no row padding (14 KB instead of 31 KB per buffer), which doubles the resident workgroups per CU --
+    // these channel-rich layers are latency bound, not LDS- or MFMA-bound.  Narrow the output-channel slice until the grid
+    // has >= 3 workgroups per CU.
+    const long nw = (long)a.N * ((a.H + 3) / 4) * ((a.W + 15) / 16);
+    const char* f = getenv("HPFG_SMALL_BN");
+    const int force = f ? atoi(f) : 0;
+    if (force != 999) {
+      if (cp % 128 == 0 && (force == 128 || (!force && nw * (cp / 128) >= 768))) return launch_cfg<Cfg<4, 16, 1, 4, 2, TAPS, 32>, KIND>(a, st, rows_only);
+      if (cp % 64 == 0 && (force == 64 || (!force && (nw * (cp / 64) >= 768 || cp % 32 != 0)))) return launch_cfg<Cfg<4, 16, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only);
+      if (cp % 32 == 0) return launch_cfg<Cfg<4, 16, 2, 2, 1, TAPS, 32>, KIND>(a, st, rows_only);
+      return launch_cfg<Cfg<4, 16, 4, 1, 1, TAPS, 32>, KIND>(a, st, rows_only);
+    }
   }
   // small spatial sizes have few 8x8 tiles: narrow the output-channel slice per workgroup until there are >= 2 workgroups per CU
   const long nwork = (long)a.N * ((a.H + 7) / 8) * ((a.W + 7) / 8);

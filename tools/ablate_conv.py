@@ -40,8 +40,15 @@ def run(name, flags, math=L.MATH_BF16X3, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for name in ["encoder.in_conv.conv_conv.4", "decoder.up4.conv.conv_conv.0", "encoder.down1.maxpool_conv.1.conv_conv.4", "encoder.down3.maxpool_conv.1.conv_conv.4",
-             "encoder.down4.maxpool_conv.1.conv_conv.4"]:
+import os
+names = os.environ.get("LAYERS", "encoder.in_conv.conv_conv.4,decoder.up4.conv.conv_conv.0,encoder.down1.maxpool_conv.1.conv_conv.4,"
+                       "encoder.down3.maxpool_conv.1.conv_conv.4,encoder.down4.maxpool_conv.1.conv_conv.4").split(",")
+if os.environ.get("QUICK"):
+    for name in names:
+        s = eng.specs[name]
+        print(f"{name} ({s.cin}->{s.cout} @{s.h}): {run(name, 0):.1f} us")
+    raise SystemExit
+for name in names:
     s = eng.specs[name]
     base = run(name, 0)
     f32 = run(name, 0, L.MATH_F32)
