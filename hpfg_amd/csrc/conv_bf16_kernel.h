@@ -44,6 +44,8 @@ struct Cfg {
   static_assert(TAPS == 1 || NLD + 2 <= KSTEPS, "stage pipeline must fit into the k-steps of a chunk");
 };
 
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
 // per-thread, tile-invariant description of staging piece i: local pixel (ly, lx) and LDS byte offset
 struct Piece {
   int ly, lx, lds, ok;
@@ -242,8 +244,9 @@ __global__ __launch_bounds__(256, (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3
       const int gy = ty0 + pc[i].ly, gx = tx0 + pc[i].lx;
       const bool ok = pc[i].ok && chv && gy >= 0 && gy < H && gx >= 0 && gx < W;
       f32x4 raw[NR], v0, v1;
-      issue_piece<KIND>(raw, p.a0, p.a1, cx0, n, gy, gx, c0, ok);
-      finish_piece<KIND>(v0, v1, raw, tab, p.a0, p.a1, cx0, n, gy, gx, c0, ok);
+      const int gyc = clampi(gy, 0, H - 1), gxc = clampi(gx, 0, W - 1), c0c = chv ? c0 : 0;
+      issue_piece<KIND>(raw, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
+      finish_piece<KIND>(v0, v1, raw, tab, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
       store_piece<C>(lds, pc[i], v0, v1);
     }
   }
@@ -287,14 +290,14 @@ __global__ __launch_bounds__(256, (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3
       // Prefetch depth: kinds with few raw loads per piece (PLAIN/BNACT) put ALL pieces of the next item in flight before the
       // first MFMA and finish them after the last one (a whole item of latency cover); DZ (4 raw float4 + 10 table registers) and POOL/CAT (8 raw float4 per piece) keep the
       // two-k-step ring to stay inside the register budget.
-      constexpr bool DEEP = NR <= 2;
+      constexpr bool DEEP = NR <= 2 || C::NLD <= 2;
       f32x4 raw[DEEP ? C::NLD : 2][NR];
       if (DEEP) {
 #pragma unroll
         for (int i = 0; i < C::NLD; ++i) {
           const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
           const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
-          issue_piece<KIND>(raw[DEEP ? i : 0], p.a0, p.a1, cx0, nn, gy, gx, c0n, ok);
+          issue_piece<KIND>(raw[DEEP ? i : 0], p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), chvn ? c0n : 0, ok);
         }
       }
 #pragma unroll
@@ -304,25 +307,22 @@ __global__ __launch_bounds__(256, (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3
             const int i = s - 2 < C::NLD ? s - 2 : 0;
             const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
             const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            if (more) {
-              f32x4 v0, v1;
-              finish_piece<KIND>(v0, v1, raw[i & 1], tab, p.a0, p.a1, cx0, nn, gy, gx, c0n, ok);
-              store_piece<C>(nxt, pc[i], v0, v1);
-            }
+            f32x4 v0, v1;       // also on the last item (more == false): the parked piece lands in the unused buffer, no branch
+            finish_piece<KIND>(v0, v1, raw[i & 1], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), chvn ? c0n : 0, ok);
+            store_piece<C>(nxt, pc[i], v0, v1);
           }
           if (s < C::NLD) {
             const int i = s < C::NLD ? s : 0;
             const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
             const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            issue_piece<KIND>(raw[i & 1], p.a0, p.a1, cx0, nn, gy, gx, c0n, ok);
+            issue_piece<KIND>(raw[i & 1], p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), chvn ? c0n : 0, ok);
           }
         }
-        if (!(p.math & 0x800)) {
+        {
           int ksn = ch * C::KSTEPS + s + BD;
-          ksn = ksn >= kperiod ? ksn % kperiod : ksn;
+          ksn = ksn >= kperiod ? ksn - kperiod : ksn;       // BD < KSTEPS <= kperiod: one subtraction wraps
           load_b<C>(bh[(s + BD) % BR], bl[(s + BD) % BR], wpk, ksn, ntn, nt0, lane);
         }
-        if (!(p.math & 0x200))
 #pragma unroll
         for (int m = 0; m < C::MI; ++m) {
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(cur + aoff[m] + toff[s]);
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3
           const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
           const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
           f32x4 v0, v1;
-          finish_piece<KIND>(v0, v1, raw[DEEP ? i : 0], tab, p.a0, p.a1, cx0, nn, gy, gx, c0n, ok);
+          finish_piece<KIND>(v0, v1, raw[DEEP ? i : 0], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), chvn ? c0n : 0, ok);
           store_piece<C>(nxt, pc[i], v0, v1);
         }
       }
@@ -411,8 +411,9 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int
       const int gy = ty0 + q.ly, gx = tx0 + q.lx;
       const bool ok = q.ok && chv && gy < H && gx < W;
       f32x4 raw[NR], v0, v1;
-      issue_piece<KIND>(raw, p.a0, p.a1, cx0, n, gy, gx, c0, ok);
-      finish_piece<KIND>(v0, v1, raw, tab, p.a0, p.a1, cx0, n, gy, gx, c0, ok);
+      const int gyc = clampi(gy, 0, H - 1), gxc = clampi(gx, 0, W - 1), c0c = chv ? c0 : 0;
+      issue_piece<KIND>(raw, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
+      finish_piece<KIND>(v0, v1, raw, tab, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
       store_piece<C>(lds, q, v0, v1);
     }
     bf16x8 bh[C::NI], bl[C::NI];

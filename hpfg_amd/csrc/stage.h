@@ -61,9 +61,13 @@ __device__ __forceinline__ void up_coord(int o, int L, int& i0, int& i1, float& 
 template <int KIND>
 __device__ __forceinline__ void issue_piece(f32x4 (&raw)[RawCount<KIND>::N], const HpfgAct& a, const HpfgAct& u, const ActCtx& cx0, int n, int gy,
                                             int gx, int c0, bool ok) {
+  // Branch-free on the pixel predicate: an out-of-image (halo) pixel is clamped into the image and loaded anyway, finish_piece()
+  // selects zero for it.  Keeps the conv k-loop a single basic block so the compiler can software-pipeline LDS reads and MFMAs.
+  if (KIND == HPFG_KIND_CAT) {      // two sources behind a per-thread branch anyway: keep the predicated form
 #pragma unroll
-  for (int i = 0; i < RawCount<KIND>::N; ++i) raw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (!ok) return;
+    for (int i = 0; i < RawCount<KIND>::N; ++i) raw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!ok) return;
+  }
   if (KIND == HPFG_KIND_PLAIN) {
     if (a.mode == HPFG_ACT_STRIDED) {
       raw[0] = act_load4_mode<HPFG_ACT_STRIDED>(a, cx0, n, gy, gx, c0);
@@ -71,6 +75,7 @@ __device__ __forceinline__ void issue_piece(f32x4 (&raw)[RawCount<KIND>::N], con
     } else {
       const int off = ((n * a.Hs + gy) * a.Ws + gx) * a.pstride + c0;
       raw[0] = ld4(a.z, off);
+      raw[1] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (c0 + 4 < a.C) raw[1] = ld4(a.z, off + 4);
     }
   } else if (KIND == HPFG_KIND_BNACT || (KIND == HPFG_KIND_CAT && c0 < a.C)) {
@@ -118,7 +123,6 @@ __device__ __forceinline__ void finish_piece(f32x4& v0, f32x4& v1, const f32x4 (
                                              const HpfgAct& u, const ActCtx& cx0, int n, int gy, int gx, int c0, bool ok) {
   v0 = f32x4{0.f, 0.f, 0.f, 0.f};
   v1 = v0;
-  if (!ok) return;
   if (KIND == HPFG_KIND_PLAIN) {
     v0 = raw[0];
     v1 = raw[1];
@@ -175,6 +179,11 @@ __device__ __forceinline__ void finish_piece(f32x4& v0, f32x4& v1, const f32x4 (
       v0[j] = t.k1[0][j] * g0 + t.k2[0][j] * raw[0][j] + t.k3[0][j];
       v1[j] = t.k1[1][j] * g1 + t.k2[1][j] * raw[1][j] + t.k3[1][j];
     }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {     // select, not branch: the raw values of a clamped (out-of-image / padding) piece are discarded
+    v0[j] = ok ? v0[j] : 0.f;
+    v1[j] = ok ? v1[j] : 0.f;
   }
 }
 

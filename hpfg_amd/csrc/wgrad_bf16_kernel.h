@@ -88,8 +88,9 @@ __global__ __launch_bounds__(NTHR) void wgrad_bf16x3_kernel(HpfgWgradArgs p, int
       const int gy = ty0 + pix / WP - 1, gx = tx0 + pix % WP - 1;
       const bool ok = cva && gy >= 0 && gy < H && gx >= 0 && gx < W;
       f32x4 raw[RawCount<AK>::N], v0, v1;
-      issue_piece<AK>(raw, p.a0, p.a1, cxa, n, gy, gx, ca, ok);
-      finish_piece<AK>(v0, v1, raw, ta, p.a0, p.a1, cxa, n, gy, gx, ca, ok);
+      const int gyc = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy), gxc = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx), cac = cva ? ca : 0;
+      issue_piece<AK>(raw, p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);
+      finish_piece<AK>(v0, v1, raw, ta, p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);
       bf16x8 hi, lo;
       split8(v0, v1, hi, lo);
       *reinterpret_cast<bf16x8*>(ldsA + pix * 32 + ga * 2) = hi;
@@ -102,8 +103,9 @@ __global__ __launch_bounds__(NTHR) void wgrad_bf16x3_kernel(HpfgWgradArgs p, int
       const int gy = ty0 + pix / TW, gx = tx0 + pix % TW;
       const bool ok = cvg && gy < H && gx < W;
       f32x4 raw[RawCount<GK>::N], v0, v1;
-      issue_piece<GK>(raw, p.g, none, cxg, n, gy, gx, cg, ok);
-      finish_piece<GK>(v0, v1, raw, tg, p.g, none, cxg, n, gy, gx, cg, ok);
+      const int gyc = gy > H - 1 ? H - 1 : gy, gxc = gx > W - 1 ? W - 1 : gx, cgc = cvg ? cg : 0;
+      issue_piece<GK>(raw, p.g, none, cxg, n, gyc, gxc, cgc, ok);
+      finish_piece<GK>(v0, v1, raw, tg, p.g, none, cxg, n, gyc, gxc, cgc, ok);
       bf16x8 hi, lo;
       split8(v0, v1, hi, lo);
       unsigned char* d = ldsG + (gg >> 4) * 2 * G_PLANE + pix * 32 + (gg & 8) * 2;
