@@ -84,15 +84,29 @@ __device__ __forceinline__ void load_b(bf16x8 (&bh)[C::NI], bf16x8 (&bl)[C::NI],
 // Epilogue: acc holds D[cout = (lane>>4)*4 + r][pixel = lane & 15] per (m, j) tile -> one 16-B store per lane.  The BatchNorm
 // partial sums are accumulated per lane in (s1, s2) -- across ALL tiles of a persistent workgroup -- and flushed once.
 template <class C>
-__device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (&acc)[C::MI][C::NI], f32x4 (&s1)[C::NI], f32x4 (&s2)[C::NI], int lane,
-                                                  int wm, int nt0, int n, int ty0, int tx0) {
+__device__ __forceinline__ void conv16_load_bias(const HpfgConvArgs& p, f32x4 (&bias)[C::NI], int lane, int nt0) {
+#pragma unroll
+  for (int j = 0; j < C::NI; ++j) {
+    const int co = (nt0 + j) * 16 + (lane >> 4) * 4;
+    bias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && co < p.CoutPad) bias[j] = ld4(p.bias, co);
+  }
+}
+
+template <class C>
+__device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (&acc)[C::MI][C::NI], f32x4 (&s1)[C::NI], f32x4 (&s2)[C::NI],
+                                                  const f32x4 (&bias)[C::NI], int lane, int wm, int nt0, int n, int ty0, int tx0,
+                                                  bool reload_bias = false) {
   const int H = p.H, W = p.W;
   const bool vec = (p.Cout & 3) == 0 && (p.out_pstride & 3) == 0;
 #pragma unroll
   for (int j = 0; j < C::NI; ++j) {
     const int co = (nt0 + j) * 16 + (lane >> 4) * 4;
-    f32x4 b = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && co < p.CoutPad) b = ld4(p.bias, co);
+    f32x4 b = bias[j];
+    if (reload_bias) {      // register-starved kernels keep no copy across the k-loop
+      b = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias && co < p.CoutPad) b = ld4(p.bias, co);
+    }
 #pragma unroll
     for (int m = 0; m < C::MI; ++m) {
       const int pxl = (wm * C::MI + m) * 16 + (lane & 15);
@@ -160,8 +174,24 @@ __device__ __forceinline__ void conv16_flush_stats(const HpfgConvArgs& p, f32x4 
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BL, AH, ACC, 0, 0, 0); \
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BH, AL, ACC, 0, 0, 0);
 
+// Diagnostics build only (make TRACE=1 -> libhpfg_hip_trace.so, tools/trace_conv.py): with math bit 0x2000 wave 0 of every
+// workgroup writes (id << 56 | s_memtime) stamps to stat_partials + 256 * blockIdx.x (u64), which the tool sizes accordingly.
+#ifdef HPFG_TRACE
+#define HPFG_TR(ID)                                                                                        \
+  if (tr_on && tr_i < 255) {                                                                               \
+    tr_buf[tr_i++] = ((unsigned long long)(ID) << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull); \
+  }
+#define HPFG_TR_REAL(ID)                                                                                   \
+  if (tr_on && tr_i < 255) {                                                                               \
+    tr_buf[tr_i++] = ((unsigned long long)(ID) << 56) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffffffffull); \
+  }
+#else
+#define HPFG_TR(ID)
+#define HPFG_TR_REAL(ID)
+#endif
+
 template <class C, int KIND>
-__global__ __launch_bounds__(256, (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   static_assert(C::TAPS == 9, "persistent kernel is the 3x3 path");
   constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
   constexpr int NR = RawCount<KIND>::N;
@@ -173,6 +203,13 @@ __global__ __launch_bounds__(256, (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3
   const int H = p.H, W = p.W;
   const int ntiles = tiles_x * tiles_y, nwork = ntiles * p.N;
   const ActCtx cx0 = make_ctx(p.a0);
+#ifdef HPFG_TRACE
+  const bool tr_on = (p.math & 0x2000) && tid == 0;
+  unsigned long long* tr_buf = reinterpret_cast<unsigned long long*>(p.stat_partials) + 256 * ((long)blockIdx.y * gridDim.x + blockIdx.x);
+  int tr_i = 0;
+#endif
+  HPFG_TR_REAL(11)
+  HPFG_TR(1)
 
   f32x4 acc[C::MI][C::NI];
 #pragma unroll
@@ -234,7 +271,11 @@ __global__ __launch_bounds__(256, (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3
     s1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     s2[j] = s1[j];
   }
+  constexpr bool TIGHT = C::TAPS == 9 && C::KSTEPS == 5 && C::NI >= 2 && RawCount<KIND>::N >= 4;
+  f32x4 bias[C::NI];       // per-workgroup constant: fetched once, not per tile in the epilogue
+  if (!TIGHT) conv16_load_bias<C>(p, bias, lane, nt0);
   Tab tab;
+  HPFG_TR(2)
   {
     const int c0 = g8;
     const bool chv = c0 < cin_total;
@@ -253,13 +294,18 @@ __global__ __launch_bounds__(256, (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3
   // B-fragment ring: the fragments of k-step g + BD are requested while k-step g computes (BD = ring size - 1 k-steps of latency
   // cover; the ring position of a k-step is static because the ring size divides KSTEPS).  Weights do not depend on the tile, so
   // the k-step sequence is periodic with period nchunks * KSTEPS.
-  constexpr int BR = C::KSTEPS == 5 ? 5 : 3, BD = BR - 1;
+  // vmcnt retires in issue order: a B fragment requested AFTER the tile prefetch of the next chunk would make its consumer wait
+  // for that whole prefetch.  With a ring as deep as a chunk (NI == 1: 8 VGPRs per k-step) every fragment a chunk consumes was
+  // requested during the previous chunk, i.e. before this chunk's prefetch, and the k-loop never waits on it.
+  constexpr int BR = C::KSTEPS == 5 ? 5 : (C::NI == 1 ? 9 : 3), BD = BR - 1;
   static_assert(C::KSTEPS % BR == 0, "ring size must divide the k-steps of a chunk");
   const int kperiod = nchunks * C::KSTEPS;
   bf16x8 bh[BR][C::NI], bl[BR][C::NI];
 #pragma unroll
   for (int d = 0; d < BD; ++d) load_b<C>(bh[d], bl[d], wpk, d % kperiod, ntn, nt0, lane);
+  HPFG_TR(3)
   __syncthreads();
+  HPFG_TR(4)
   int item = 0;
   while (true) {
     for (int ch = 0; ch < nchunks; ++ch, ++item) {
@@ -286,10 +332,13 @@ __global__ __launch_bounds__(256, (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3
       }
       const int c0n = nch * C::KC + g8;
       const bool chvn = more && c0n < cin_total && !(p.math & 0x400);
-      if (more && nchunks > 1) load_tables<KIND>(tab, p.a0, c0n, chvn);
+      const int c0c = c0n < cin_total ? c0n : 0;
+      // No branches from here to the barrier (except the CAT loader's per-thread source select): the tables are reloaded even when
+      // they cannot have changed, so that the whole chunk is one scheduling region with a hand-placed instruction order.
+      if (!TIGHT || (more && nchunks > 1)) load_tables<KIND>(tab, p.a0, c0c, true);
       // Prefetch depth: kinds with few raw loads per piece (PLAIN/BNACT) put ALL pieces of the next item in flight before the
-      // first MFMA and finish them after the last one (a whole item of latency cover); DZ (4 raw float4 + 10 table registers) and POOL/CAT (8 raw float4 per piece) keep the
-      // two-k-step ring to stay inside the register budget.
+      // first MFMA and finish them after the last one (a whole item of latency cover); DZ (4 raw float4 + 10 table registers) and
+      // POOL/CAT (8 raw float4 per piece) keep the two-k-step ring to stay inside the register budget.
       constexpr bool DEEP = NR <= 2 || C::NLD <= 2;
       f32x4 raw[DEEP ? C::NLD : 2][NR];
       if (DEEP) {
@@ -297,53 +346,75 @@ __global__ __launch_bounds__(256, (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3
         for (int i = 0; i < C::NLD; ++i) {
           const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
           const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
-          issue_piece<KIND>(raw[DEEP ? i : 0], p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), chvn ? c0n : 0, ok);
+          issue_piece<KIND>(raw[DEEP ? i : 0], p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
         }
       }
+      HPFG_TR(5)
+      // k-loop as a linear sequence of (k-step, pixel-tile) steps q: the A fragments of step q + AD are read from LDS while step q
+      // multiplies (ring of AD + 1 fragment pairs), so an LDS read has AD - 1 steps of MFMAs to land.  The scheduler is fenced at
+      // every step: left alone it sinks each read down to its use and exposes the LDS latency once per k-step.
+      constexpr int Q = C::KSTEPS * C::MI;
+      constexpr int AD0 = C::NI == 1 ? 4 : (TIGHT ? 0 : 2);   // TIGHT (16x16 tiles x 32 output channels behind a wide loader): no registers for read-ahead
+      constexpr int AD = AD0 < Q ? AD0 : Q;
+      constexpr int AR = AD + 1;
+      constexpr bool FENCE = !TIGHT;   // those three kernels have no registers to spare for a pinned order
+      bf16x8 ah[AR], al[AR];
 #pragma unroll
-      for (int s = 0; s < C::KSTEPS; ++s) {
-        if (!DEEP) {
-          if (s >= 2 && s - 2 < C::NLD) {        // finish the piece issued two k-steps ago and park it in the other LDS buffer
-            const int i = s - 2 < C::NLD ? s - 2 : 0;
-            const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
-            const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            f32x4 v0, v1;       // also on the last item (more == false): the parked piece lands in the unused buffer, no branch
-            finish_piece<KIND>(v0, v1, raw[i & 1], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), chvn ? c0n : 0, ok);
-            store_piece<C>(nxt, pc[i], v0, v1);
-          }
-          if (s < C::NLD) {
-            const int i = s < C::NLD ? s : 0;
-            const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
-            const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            issue_piece<KIND>(raw[i & 1], p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), chvn ? c0n : 0, ok);
-          }
+      for (int q = 0; q < AD; ++q) {
+        ah[q % AR] = *reinterpret_cast<const bf16x8*>(cur + aoff[q % C::MI] + toff[q / C::MI]);
+        al[q % AR] = *reinterpret_cast<const bf16x8*>(cur + aoff[q % C::MI] + toff[q / C::MI] + C::PLANE);
+      }
+      if (FENCE) __builtin_amdgcn_sched_barrier(0x216);   // VALU, SALU, VMEM and DS writes may cross; DS reads and MFMAs may not
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int s = q / C::MI, m = q % C::MI;
+        if (q + AD < Q) {
+          const int q2 = q + AD;
+          ah[q2 % AR] = *reinterpret_cast<const bf16x8*>(cur + aoff[q2 % C::MI] + toff[q2 / C::MI]);
+          al[q2 % AR] = *reinterpret_cast<const bf16x8*>(cur + aoff[q2 % C::MI] + toff[q2 / C::MI] + C::PLANE);
         }
-        {
+        if (m == 0) {
+          if (!DEEP) {
+            if (s >= 2 && s - 2 < C::NLD) {        // finish the piece issued two k-steps ago and park it in the other LDS buffer
+              const int i = s - 2 < C::NLD ? s - 2 : 0;
+              const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
+              const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
+              f32x4 v0, v1;       // also on the last item (more == false): the parked piece lands in the unused buffer, no branch
+              finish_piece<KIND>(v0, v1, raw[i & 1], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
+              store_piece<C>(nxt, pc[i], v0, v1);
+            }
+            if (s < C::NLD) {
+              const int i = s < C::NLD ? s : 0;
+              const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
+              const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
+              issue_piece<KIND>(raw[i & 1], p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
+            }
+          }
           int ksn = ch * C::KSTEPS + s + BD;
           ksn = ksn >= kperiod ? ksn - kperiod : ksn;       // BD < KSTEPS <= kperiod: one subtraction wraps
           load_b<C>(bh[(s + BD) % BR], bl[(s + BD) % BR], wpk, ksn, ntn, nt0, lane);
         }
 #pragma unroll
-        for (int m = 0; m < C::MI; ++m) {
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(cur + aoff[m] + toff[s]);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(cur + aoff[m] + toff[s] + C::PLANE);
-#pragma unroll
-          for (int j = 0; j < C::NI; ++j) { HPFG16_MFMA3(acc[m][j], ah, al, bh[s % BR][j], bl[s % BR][j]) }
-        }
+        for (int j = 0; j < C::NI; ++j) { HPFG16_MFMA3(acc[m][j], ah[q % AR], al[q % AR], bh[s % BR][j], bl[s % BR][j]) }
+        if (FENCE) __builtin_amdgcn_sched_barrier(0x216);   // VALU, SALU, VMEM and DS writes may cross; DS reads and MFMAs may not
       }
-      if (DEEP && more) {
+      HPFG_TR(6)
+      if (DEEP) {      // also on the last item: the pieces land in the unused buffer
 #pragma unroll
         for (int i = 0; i < C::NLD; ++i) {
           const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
           const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
           f32x4 v0, v1;
-          finish_piece<KIND>(v0, v1, raw[DEEP ? i : 0], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), chvn ? c0n : 0, ok);
+          finish_piece<KIND>(v0, v1, raw[DEEP ? i : 0], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
           store_piece<C>(nxt, pc[i], v0, v1);
         }
       }
+      HPFG_TR(7)
       __syncthreads();
+      HPFG_TR(8)
     }
-    conv16_store_tile<C>(p, acc, s1, s2, lane, wm, nt0, n, ty0, tx0);
+    conv16_store_tile<C>(p, acc, s1, s2, bias, lane, wm, nt0, n, ty0, tx0, TIGHT);
+    HPFG_TR(9)
 #pragma unroll
     for (int m = 0; m < C::MI; ++m)
 #pragma unroll
@@ -365,6 +436,8 @@ __global__ __launch_bounds__(256, (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3
     tx0 = txi * C::TW;
   }
   conv16_flush_stats<C>(p, s1, s2, ldsf, tid, lane, wm, wn, cb, (int)blockIdx.x);
+  HPFG_TR(10)
+  HPFG_TR_REAL(12)
 }
 
 // 1x1: one tile per workgroup, K = 32 input channels per MFMA step, no halo.
@@ -433,7 +506,9 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int
     s1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     s2[j] = s1[j];
   }
-  conv16_store_tile<C>(p, acc, s1, s2, lane, wm, nt0, n, ty0, tx0);
+  f32x4 bias[C::NI];       // per-workgroup constant: fetched once, not per tile in the epilogue
+  conv16_load_bias<C>(p, bias, lane, nt0);
+  conv16_store_tile<C>(p, acc, s1, s2, bias, lane, wm, nt0, n, ty0, tx0);
   __syncthreads();
   conv16_flush_stats<C>(p, s1, s2, ldsf, tid, lane, wm, wn, cb, n * (tiles_x * tiles_y) + tile);
 }
@@ -444,12 +519,18 @@ int persistent_grid(const HpfgConvArgs& a) {
   const int tx = (a.W + C::TW - 1) / C::TW, ty = (a.H + C::TH - 1) / C::TH;
   const int lds_bytes = 2 * C::BUF_BYTES + 2 * 4 * C::BN * 4;
   int per_cu = 160 * 1024 / lds_bytes;
-  const int reg_cap = (C::NI >= 2 || RawCount<KIND>::N >= 4) ? 2 : 3;   // matches __launch_bounds__ (waves per SIMD)
+  const int reg_cap = 2;   // matches __launch_bounds__ (waves per SIMD)
   if (per_cu > reg_cap) per_cu = reg_cap;
   if (per_cu < 1) per_cu = 1;
-  long nwork = (long)tx * ty * a.N;
-  long gx = 256L * per_cu;
-  return (int)(gx > nwork ? nwork : gx);
+  // All workgroups (grid.x * grid.y, grid.y = output-channel slices) must be resident at once -- a second round of workgroups
+  // would start cold behind the first -- and should carry the same number of tiles: spread the tiles over as many workgroups as
+  // ceil(tiles / capacity) rounds need, not over the whole capacity.
+  const long nwork = (long)tx * ty * a.N;
+  const long gy = a.CoutPad / C::BN;
+  long cap = 256L * per_cu / (gy > 0 ? gy : 1);
+  if (cap < 1) cap = 1;
+  const long rounds = (nwork + cap - 1) / cap;
+  return (int)((nwork + rounds - 1) / rounds);
 }
 
 template <class C, int KIND>
@@ -483,15 +564,15 @@ int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   }
   if constexpr (TAPS == 9) {
     // 3x3 on sizes that are not multiples of 16 (56, 28, 14, ...): 4x16-pixel tiles.  Same 64 pixels per workgroup as an 8x8 tile
-    // but the LDS image needs no row padding (14 KB instead of 31 KB per buffer), which doubles the resident workgroups per CU --
-    // these channel-rich layers are latency bound, not LDS- or MFMA-bound.  Narrow the output-channel slice until the grid
-    // has >= 3 workgroups per CU.
-    const long nw = (long)a.N * ((a.H + 3) / 4) * ((a.W + 15) / 16);
+    // but the LDS image needs no row padding (14 KB instead of 31 KB per buffer).  Output-channel slice per workgroup: 64 where
+    // it divides (one wave per 16 channels, 4 pixel tiles per wave: every staged input tile and every B fragment feeds 4x the
+    // MFMAs of the 32-wide slice, and the B ring can be a whole chunk deep) -- measured 21 vs 29 us on 128->128 @28, 36 vs 50 us
+    // on 256->128 @28; a 128-wide slice (two channel tiles per wave, shallow B ring) is slower again.
     const char* f = getenv("HPFG_SMALL_BN");
     const int force = f ? atoi(f) : 0;
     if (force != 999) {
-      if (cp % 128 == 0 && (force == 128 || (!force && nw * (cp / 128) >= 768))) return launch_cfg<Cfg<4, 16, 1, 4, 2, TAPS, 32>, KIND>(a, st, rows_only);
-      if (cp % 64 == 0 && (force == 64 || (!force && (nw * (cp / 64) >= 768 || cp % 32 != 0)))) return launch_cfg<Cfg<4, 16, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only);
+      if (cp % 128 == 0 && force == 128) return launch_cfg<Cfg<4, 16, 1, 4, 2, TAPS, 32>, KIND>(a, st, rows_only);
+      if (cp % 64 == 0 && force != 32) return launch_cfg<Cfg<4, 16, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only);
       if (cp % 32 == 0) return launch_cfg<Cfg<4, 16, 2, 2, 1, TAPS, 32>, KIND>(a, st, rows_only);
       return launch_cfg<Cfg<4, 16, 4, 1, 1, TAPS, 32>, KIND>(a, st, rows_only);
     }
