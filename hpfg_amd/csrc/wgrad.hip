@@ -11,6 +11,7 @@
 // private slab; a second kernel sums the slabs in a fixed order (bitwise reproducible, no float atomics) and emits the
 // gradient in PyTorch's [Cout][Cin][k][k] layout.  3x3: three waves, wave w owns kernel row ky = w.  1x1: wave w owns
 // n-tile w.
+#include <cstdlib>
 #include "wgrad_kernel.h"
 #include "wgrad_bf16_kernel.h"
 
@@ -105,10 +106,12 @@ __global__ __launch_bounds__(64) void channel_sum_stage2(const float* __restrict
 extern "C" int hpfg_wgrad_splits(int N, int H, int W, int CinPad, int CoutPad, int taps) {
   (void)taps;
   using namespace hpfg_wg;
-  int nj = pick_nj(CoutPad);
-  long pairs = (long)(CinPad / 16) * (CoutPad / (16 * nj));
+  int ni, nj;                                // workgroup shape of the bf16x3 kernel (the f32 kernel takes whatever S it is given)
+  hpfg_wg16::pick_shape(CinPad, CoutPad, &ni, &nj);
+  long pairs = (long)(CinPad / (16 * ni)) * (CoutPad / (16 * nj));
   long nwork = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-  long target = 640 / pairs;                // aim at ~one resident wave of workgroups (2-3 per CU): fewer, longer slabs
+  static const long resident = getenv("HPFG_WGRAD_TARGET") ? atol(getenv("HPFG_WGRAD_TARGET")) : 512;
+  long target = resident / pairs;           // exactly one resident round of workgroups (bf16x3 kernel: 2 per CU by registers)
   if (target < 1) target = 1;
   if (target > nwork) target = nwork;
   long per_block = (nwork + target - 1) / target;   // work items per workgroup
@@ -129,7 +132,7 @@ extern "C" int hpfg_wgrad(const HpfgWgradArgs* a, void* stream) {
   const int akind = hpfg_kind_of(a->a0, a->a1);
   HPFG_ARG_CHECK(akind >= 0 && akind != HPFG_KIND_DZ, "wgrad: unsupported input source (a0.mode=%d, a1.mode=%d)", a->a0.mode, a->a1.mode);
   int rc;
-  const bool b16 = a->math == HPFG_MATH_BF16X3 && a->taps == 9;
+  const bool b16 = (a->math & 0xff) == HPFG_MATH_BF16X3 && a->taps == 9;
   if (b16 && a->g.mode == HPFG_ACT_DZ) rc = hpfg_wgrad16_launch_dz(*a, akind, st);
   else if (b16 && (a->g.mode == HPFG_ACT_PLAIN || a->g.mode == HPFG_ACT_STRIDED)) rc = hpfg_wgrad16_launch_plain(*a, akind, st);
   else if (a->g.mode == HPFG_ACT_DZ) rc = hpfg_wgrad_launch_dz(*a, akind, st);
