@@ -174,6 +174,13 @@ __device__ __forceinline__ void conv16_flush_stats(const HpfgConvArgs& p, f32x4 
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BL, AH, ACC, 0, 0, 0); \
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BH, AL, ACC, 0, 0, 0);
 
+// Resident workgroups per CU the kernel is compiled for.  The thin 16x16-tile layers behind a cheap loader are HBM-bound: three
+// workgroups per CU keep more tile loads in flight; everything else needs the registers of a two-per-CU budget.
+template <class C, int KIND>
+constexpr int wg_per_cu() {
+  return (C::KSTEPS == 5 && C::NI == 1 && RawCount<KIND>::N <= 2) ? 3 : 2;
+}
+
 // Diagnostics build only (make TRACE=1 -> libhpfg_hip_trace.so, tools/trace_conv.py): with math bit 0x2000 wave 0 of every
 // workgroup writes (id << 56 | s_memtime) stamps to stat_partials + 256 * blockIdx.x (u64), which the tool sizes accordingly.
 #ifdef HPFG_TRACE
@@ -191,7 +198,7 @@ __device__ __forceinline__ void conv16_flush_stats(const HpfgConvArgs& p, f32x4 
 #endif
 
 template <class C, int KIND>
-__global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   static_assert(C::TAPS == 9, "persistent kernel is the 3x3 path");
   constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
   constexpr int NR = RawCount<KIND>::N;
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(HpfgConvArgs p, int
       // multiplies (ring of AD + 1 fragment pairs), so an LDS read has AD - 1 steps of MFMAs to land.  The scheduler is fenced at
       // every step: left alone it sinks each read down to its use and exposes the LDS latency once per k-step.
       constexpr int Q = C::KSTEPS * C::MI;
-      constexpr int AD0 = C::NI == 1 ? 4 : (TIGHT ? 0 : 2);   // TIGHT (16x16 tiles x 32 output channels behind a wide loader): no registers for read-ahead
+      constexpr int AD0 = wg_per_cu<C, KIND>() == 3 ? 2 : (C::NI == 1 ? 4 : (TIGHT ? 0 : 2));   // TIGHT (16x16 tiles x 32 output channels behind a wide loader): no registers for read-ahead
       constexpr int AD = AD0 < Q ? AD0 : Q;
       constexpr int AR = AD + 1;
       constexpr bool FENCE = !TIGHT;   // those three kernels have no registers to spare for a pinned order
@@ -519,7 +526,7 @@ int persistent_grid(const HpfgConvArgs& a) {
   const int tx = (a.W + C::TW - 1) / C::TW, ty = (a.H + C::TH - 1) / C::TH;
   const int lds_bytes = 2 * C::BUF_BYTES + 2 * 4 * C::BN * 4;
   int per_cu = 160 * 1024 / lds_bytes;
-  const int reg_cap = 2;   // matches __launch_bounds__ (waves per SIMD)
+  const int reg_cap = wg_per_cu<C, KIND>();   // matches __launch_bounds__ (waves per SIMD)
   if (per_cu > reg_cap) per_cu = reg_cap;
   if (per_cu < 1) per_cu = 1;
   // All workgroups (grid.x * grid.y, grid.y = output-channel slices) must be resident at once -- a second round of workgroups
