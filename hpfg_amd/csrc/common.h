@@ -81,6 +81,20 @@ __device__ static inline uint32_t keep4(const HpfgAct& s, const ActCtx& cx, uint
          ((h >> 24) >= cx.thresh ? 8u : 0u);
 }
 
+// Dropout of the 4 elements e..e+3 (e % 4 == 0) in place: v[j] = keep_j ? v[j] / (1 - p) : 0.  One word carries the four
+// 8-bit draws (one hash) or the four bytes of an explicit mask; per element that is one byte compare, one select, one multiply.
+__device__ static inline uint32_t drop_word(const HpfgAct& s, const ActCtx& cx, uint32_t e) {
+  if (s.drop_mask) return *reinterpret_cast<const uint32_t*>(s.drop_mask + e);
+  return hpfg_hash32(e >> 2, cx.seed);
+}
+__device__ static inline void drop_apply4(f32x4& v, uint32_t h, uint32_t thr, float inv_keep) {
+  v[0] *= (h & 0xFFu) >= thr ? inv_keep : 0.f;
+  v[1] *= ((h >> 8) & 0xFFu) >= thr ? inv_keep : 0.f;
+  v[2] *= ((h >> 16) & 0xFFu) >= thr ? inv_keep : 0.f;
+  v[3] *= (h >> 24) >= thr ? inv_keep : 0.f;
+}
+__device__ static inline uint32_t drop_thresh(const HpfgAct& s, const ActCtx& cx) { return s.drop_mask ? 1u : cx.thresh; }
+
 // 4 channels [c, c+4) of the virtual activation `s` at image n, virtual pixel (y, x); caller guarantees the pixel is
 // inside the virtual image (H x W).  Channels >= s.C read as zero.
 __device__ static inline f32x4 act_load4(const HpfgAct& s, const ActCtx& cx, int n, int y, int x, int c) {

@@ -44,7 +44,7 @@ struct Cfg {
   static_assert(TAPS == 1 || NLD + 2 <= KSTEPS, "stage pipeline must fit into the k-steps of a chunk");
 };
 
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }   // v_med3_i32
 
 // per-thread, tile-invariant description of staging piece i: local pixel (ly, lx) and LDS byte offset
 struct Piece {
@@ -291,7 +291,8 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
     for (int i = 0; i < C::NLD; ++i) {
       const int gy = ty0 + pc[i].ly, gx = tx0 + pc[i].lx;
       const bool ok = pc[i].ok && chv && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      f32x4 raw[NR], v0, v1;
+      RawPiece<KIND> raw;
+      f32x4 v0, v1;
       const int gyc = clampi(gy, 0, H - 1), gxc = clampi(gx, 0, W - 1), c0c = chv ? c0 : 0;
       issue_piece<KIND>(raw, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
       finish_piece<KIND>(v0, v1, raw, tab, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
       // first MFMA and finish them after the last one (a whole item of latency cover); DZ (4 raw float4 + 10 table registers) and
       // POOL/CAT (8 raw float4 per piece) keep the two-k-step ring to stay inside the register budget.
       constexpr bool DEEP = NR <= 2 || C::NLD <= 2;
-      f32x4 raw[DEEP ? C::NLD : 2][NR];
+      RawPiece<KIND> raw[DEEP ? C::NLD : 2];
       if (DEEP) {
 #pragma unroll
         for (int i = 0; i < C::NLD; ++i) {
@@ -490,7 +491,8 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int
       const Piece q = make_piece<C>(tid, i);
       const int gy = ty0 + q.ly, gx = tx0 + q.lx;
       const bool ok = q.ok && chv && gy < H && gx < W;
-      f32x4 raw[NR], v0, v1;
+      RawPiece<KIND> raw;
+      f32x4 v0, v1;
       const int gyc = clampi(gy, 0, H - 1), gxc = clampi(gx, 0, W - 1), c0c = chv ? c0 : 0;
       issue_piece<KIND>(raw, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
       finish_piece<KIND>(v0, v1, raw, tab, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
@@ -540,14 +542,26 @@ int persistent_grid(const HpfgConvArgs& a) {
   return (int)((nwork + rounds - 1) / rounds);
 }
 
+}  // namespace hpfg_conv16
+#include "conv_ws_kernel.h"
+namespace hpfg_conv16 {
+
 template <class C, int KIND>
 int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   int tx = (a.W + C::TW - 1) / C::TW, ty = (a.H + C::TH - 1) / C::TH;
+  bool ws = false;
+  if constexpr (C::TAPS == 9) ws = ws_enabled<C, KIND>() && a.a0.C + a.a1.C <= WS_CT;
   if (rows_only) {
-    *rows_only = C::TAPS == 9 ? persistent_grid<C, KIND>(a) : tx * ty * a.N;
+    if constexpr (C::TAPS == 9) *rows_only = ws ? ws_grid<C, KIND>(a) : persistent_grid<C, KIND>(a);
+    else *rows_only = tx * ty * a.N;
     return 0;
   }
   if constexpr (C::TAPS == 9) {
+    if (ws) {
+      dim3 grid((unsigned)ws_grid<C, KIND>(a), a.CoutPad / C::BN);
+      hipLaunchKernelGGL((conv_ws_kernel<C, KIND>), grid, dim3(512), 0, st, a, tx, ty);
+      return hpfg_launch_status("conv_ws_kernel");
+    }
     dim3 grid((unsigned)persistent_grid<C, KIND>(a), a.CoutPad / C::BN);
     hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND>), grid, dim3(256), 0, st, a, tx, ty);
   } else {

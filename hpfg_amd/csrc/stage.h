@@ -7,15 +7,26 @@ namespace hpfg_stage {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// x = hi + lo with hi = bf16(x) (round to nearest even), lo = bf16(x - hi): pairs go through v_cvt_pk_bf16_f32, and the packed
+// hi word is widened back with one shift / one mask per pair.
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+  uint32_t hw[4], lw[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    __bf16 h0 = (__bf16)a[j], h1 = (__bf16)b[j];
-    hi[j] = h0;
-    hi[4 + j] = h1;
-    lo[j] = (__bf16)(a[j] - (float)h0);
-    lo[4 + j] = (__bf16)(b[j] - (float)h1);
+  for (int k = 0; k < 4; ++k) {
+    const float x0 = k < 2 ? a[2 * k] : b[2 * k - 4], x1 = k < 2 ? a[2 * k + 1] : b[2 * k - 3];
+    const bf16x2 h = __builtin_convertvector(f32x2{x0, x1}, bf16x2);
+    const uint32_t w = __builtin_bit_cast(uint32_t, h);
+    const f32x2 hf = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
+    const bf16x2 l = __builtin_convertvector(f32x2{x0, x1} - hf, bf16x2);
+    hw[k] = w;
+    lw[k] = __builtin_bit_cast(uint32_t, l);
   }
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  hi = __builtin_bit_cast(bf16x8, (u32x4{hw[0], hw[1], hw[2], hw[3]}));
+  lo = __builtin_bit_cast(bf16x8, (u32x4{lw[0], lw[1], lw[2], lw[3]}));
 }
 
 __device__ __forceinline__ f32x4 ld4(const float* base, int off) { return *reinterpret_cast<const f32x4*>(base + off); }
@@ -24,6 +35,15 @@ __device__ __forceinline__ f32x4 ld4(const float* base, int off) { return *reint
 // ---- producer chain.  Raw loads per piece: PLAIN/BNACT 2, DZ 4 (z + dA), POOL 8 (2x2 pixels), CAT 8 (4 bilinear taps).
 template <int KIND>
 struct RawCount { static constexpr int N = KIND == HPFG_KIND_POOL || KIND == HPFG_KIND_CAT ? 8 : (KIND == HPFG_KIND_DZ ? 4 : 2); };
+
+// Raw (in-flight) data of one staging piece: the float4 loads plus, for the kinds that apply Dropout, the two words of an
+// explicit keep mask (HpfgAct.drop_mask, tests only).  The mask words are requested WITH the data loads: a load inside
+// finish_piece() would sit behind every younger prefetch in the in-order vmcnt queue and drain the whole ring.
+template <int KIND>
+struct RawPiece {
+  f32x4 v[RawCount<KIND>::N];
+  uint32_t dm[2];
+};
 
 struct Tab {   // per-chunk per-channel tables of this thread's 8 channels
   f32x4 sc[2], sh[2], k1[2], k2[2], k3[2];
@@ -59,8 +79,14 @@ __device__ __forceinline__ void up_coord(int o, int L, int& i0, int& i1, float& 
 }
 
 template <int KIND>
-__device__ __forceinline__ void issue_piece(f32x4 (&raw)[RawCount<KIND>::N], const HpfgAct& a, const HpfgAct& u, const ActCtx& cx0, int n, int gy,
+__device__ __forceinline__ void issue_piece(RawPiece<KIND>& rp, const HpfgAct& a, const HpfgAct& u, const ActCtx& cx0, int n, int gy,
                                             int gx, int c0, bool ok) {
+  f32x4 (&raw)[RawCount<KIND>::N] = rp.v;
+  if ((KIND == HPFG_KIND_BNACT || KIND == HPFG_KIND_DZ) && a.drop_mask && a.drop_p > 0.f) {
+    const uint32_t e = (uint32_t)(((n * a.Hs + gy) * a.Ws + gx) * a.C + c0);
+    rp.dm[0] = *reinterpret_cast<const uint32_t*>(a.drop_mask + e);
+    rp.dm[1] = *reinterpret_cast<const uint32_t*>(a.drop_mask + e + 4);
+  }
   // Branch-free on the pixel predicate: an out-of-image (halo) pixel is clamped into the image and loaded anyway, finish_piece()
   // selects zero for it.  Keeps the conv k-loop a single basic block so the compiler can software-pipeline LDS reads and MFMAs.
   if (KIND == HPFG_KIND_CAT) {      // two sources behind a per-thread branch anyway: keep the predicated form
@@ -118,72 +144,89 @@ __device__ __forceinline__ void issue_piece(f32x4 (&raw)[RawCount<KIND>::N], con
   }
 }
 
+// keep test of the four 8-bit draws (or mask bytes) in h against thr: v[j] = keep_j ? v[j] : 0
+__device__ __forceinline__ void keep_select4(f32x4& v, uint32_t h, uint32_t thr) {
+  v[0] = (h & 0xFFu) >= thr ? v[0] : 0.f;
+  v[1] = ((h >> 8) & 0xFFu) >= thr ? v[1] : 0.f;
+  v[2] = ((h >> 16) & 0xFFu) >= thr ? v[2] : 0.f;
+  v[3] = (h >> 24) >= thr ? v[3] : 0.f;
+}
+__device__ __forceinline__ f32x4 lrelu4(const f32x4& y) { return __builtin_elementwise_max(y, y * HPFG_LEAKY); }
+
+// The producer chain on the raw data of one piece.  Written on float4 values so that the multiplies / FMAs pair up into
+// v_pk_fma_f32 / v_pk_mul_f32 (the loaders are VALU-issue bound: instruction count is what matters here).  `ok` = the piece is
+// inside the image and its channel group exists; a piece that is not yields zeros (its loads were clamped to valid addresses).
 template <int KIND>
-__device__ __forceinline__ void finish_piece(f32x4& v0, f32x4& v1, const f32x4 (&raw)[RawCount<KIND>::N], const Tab& t, const HpfgAct& a,
+__device__ __forceinline__ void finish_piece(f32x4& v0, f32x4& v1, const RawPiece<KIND>& rp, const Tab& t, const HpfgAct& a,
                                              const HpfgAct& u, const ActCtx& cx0, int n, int gy, int gx, int c0, bool ok) {
+  const f32x4 (&raw)[RawCount<KIND>::N] = rp.v;
+  bool need_ok = true;
   v0 = f32x4{0.f, 0.f, 0.f, 0.f};
   v1 = v0;
   if (KIND == HPFG_KIND_PLAIN) {
     v0 = raw[0];
     v1 = raw[1];
   } else if (KIND == HPFG_KIND_BNACT || (KIND == HPFG_KIND_CAT && c0 < a.C)) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      v0[j] = lrelu(raw[0][j] * t.sc[0][j] + t.sh[0][j]);
-      v1[j] = lrelu(raw[1][j] * t.sc[1][j] + t.sh[1][j]);
-    }
+    v0 = lrelu4(raw[0] * t.sc[0] + t.sh[0]);
+    v1 = lrelu4(raw[1] * t.sc[1] + t.sh[1]);
     if (KIND == HPFG_KIND_BNACT && a.drop_p > 0.f) {
       const uint32_t e = (uint32_t)(((n * a.Hs + gy) * a.Ws + gx) * a.C + c0);
-      const uint32_t k0 = keep4(a, cx0, e), k1 = keep4(a, cx0, e + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v0[j] = (k0 >> j) & 1u ? v0[j] * cx0.inv_keep : 0.f;
-        v1[j] = (k1 >> j) & 1u ? v1[j] * cx0.inv_keep : 0.f;
+      const uint32_t thr = drop_thresh(a, cx0);
+      uint32_t h0 = a.drop_mask ? rp.dm[0] : hpfg_hash32(e >> 2, cx0.seed);
+      uint32_t h1 = a.drop_mask ? rp.dm[1] : hpfg_hash32((e + 4) >> 2, cx0.seed);
+      if (thr >= 1u) {       // a zero draw is always dropped: fold the in-image predicate into the draws
+        h0 = ok ? h0 : 0u;
+        h1 = ok ? h1 : 0u;
+        need_ok = false;
       }
+      v0 = v0 * cx0.inv_keep;
+      v1 = v1 * cx0.inv_keep;
+      keep_select4(v0, h0, thr);
+      keep_select4(v1, h1, thr);
     }
   } else if (KIND == HPFG_KIND_POOL) {
+    f32x4 m0 = lrelu4(raw[0] * t.sc[0] + t.sh[0]), m1 = lrelu4(raw[1] * t.sc[1] + t.sh[1]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float m0 = lrelu(raw[0][j] * t.sc[0][j] + t.sh[0][j]), m1 = lrelu(raw[1][j] * t.sc[1][j] + t.sh[1][j]);
-#pragma unroll
-      for (int q = 1; q < 4; ++q) {
-        m0 = fmaxf(m0, lrelu(raw[2 * q][j] * t.sc[0][j] + t.sh[0][j]));
-        m1 = fmaxf(m1, lrelu(raw[2 * q + 1][j] * t.sc[1][j] + t.sh[1][j]));
-      }
-      v0[j] = m0;
-      v1[j] = m1;
+    for (int q = 1; q < 4; ++q) {
+      m0 = __builtin_elementwise_max(m0, lrelu4(raw[2 * q] * t.sc[0] + t.sh[0]));
+      m1 = __builtin_elementwise_max(m1, lrelu4(raw[2 * q + 1] * t.sc[1] + t.sh[1]));
     }
+    v0 = m0;
+    v1 = m1;
   } else if (KIND == HPFG_KIND_CAT) {
     int i0, i1;
     float wy1, wx1;
     up_coord(gy, u.Hs, i0, i1, wy1);
     up_coord(gx, u.Ws, i0, i1, wx1);
     const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      v0[j] = wy0 * (wx0 * raw[0][j] + wx1 * raw[2][j]) + wy1 * (wx0 * raw[4][j] + wx1 * raw[6][j]);
-      v1[j] = wy0 * (wx0 * raw[1][j] + wx1 * raw[3][j]) + wy1 * (wx0 * raw[5][j] + wx1 * raw[7][j]);
-    }
+    v0 = wy0 * (wx0 * raw[0] + wx1 * raw[2]) + wy1 * (wx0 * raw[4] + wx1 * raw[6]);
+    v1 = wy0 * (wx0 * raw[1] + wx1 * raw[3]) + wy1 * (wx0 * raw[5] + wx1 * raw[7]);
   } else {   // DZ: k1*g + k2*z + k3, g = dA * dropmask/(1-p) * lrelu'(scale*z+shift)
-    uint32_t k0 = 0xFu, k1 = 0xFu;
+    f32x4 ga = raw[2], gb = raw[3];
     if (a.drop_p > 0.f) {
       const uint32_t e = (uint32_t)(((n * a.Hs + gy) * a.Ws + gx) * a.C + c0);
-      k0 = keep4(a, cx0, e);
-      k1 = keep4(a, cx0, e + 4);
+      const uint32_t thr = drop_thresh(a, cx0);
+      ga = ga * cx0.inv_keep;
+      gb = gb * cx0.inv_keep;
+      keep_select4(ga, a.drop_mask ? rp.dm[0] : hpfg_hash32(e >> 2, cx0.seed), thr);
+      keep_select4(gb, a.drop_mask ? rp.dm[1] : hpfg_hash32((e + 4) >> 2, cx0.seed), thr);
     }
+    const f32x4 ya = raw[0] * t.sc[0] + t.sh[0], yb = raw[1] * t.sc[1] + t.sh[1];
+    const f32x4 la = ga * HPFG_LEAKY, lb = gb * HPFG_LEAKY;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float g0 = (k0 >> j) & 1u ? raw[2][j] * cx0.inv_keep : 0.f, g1 = (k1 >> j) & 1u ? raw[3][j] * cx0.inv_keep : 0.f;
-      g0 = raw[0][j] * t.sc[0][j] + t.sh[0][j] > 0.f ? g0 : HPFG_LEAKY * g0;
-      g1 = raw[1][j] * t.sc[1][j] + t.sh[1][j] > 0.f ? g1 : HPFG_LEAKY * g1;
-      v0[j] = t.k1[0][j] * g0 + t.k2[0][j] * raw[0][j] + t.k3[0][j];
-      v1[j] = t.k1[1][j] * g1 + t.k2[1][j] * raw[1][j] + t.k3[1][j];
+      ga[j] = ya[j] > 0.f ? ga[j] : la[j];
+      gb[j] = yb[j] > 0.f ? gb[j] : lb[j];
     }
+    v0 = t.k1[0] * ga + (t.k2[0] * raw[0] + t.k3[0]);
+    v1 = t.k1[1] * gb + (t.k2[1] * raw[1] + t.k3[1]);
   }
+  if (need_ok) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {     // select, not branch: the raw values of a clamped (out-of-image / padding) piece are discarded
-    v0[j] = ok ? v0[j] : 0.f;
-    v1[j] = ok ? v1[j] : 0.f;
+    for (int j = 0; j < 4; ++j) {     // select, not branch: the raw values of a clamped (out-of-image / padding) piece are discarded
+      v0[j] = ok ? v0[j] : 0.f;
+      v1[j] = ok ? v1[j] : 0.f;
+    }
   }
 }
 

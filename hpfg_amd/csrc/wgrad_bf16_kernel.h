@@ -137,7 +137,8 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
     pg[i].lx = (short)(pix % TW);
     pg[i].lds = (gg >> 4) * 2 * G_PLANE + pix * 32 + (gg & 8) * 2;
   }
-  f32x4 rawA[PREA ? NA : 1][NRA], rawG[GB][NRG];
+  RawPiece<AK> rawA[PREA ? NA : 1];
+  RawPiece<GK> rawG[GB];
 
 #define HPFG_WG_A_COORD(I)                                                                            \
   const int gy = ty0 + pa[I].ly, gx = tx0 + pa[I].lx;                                                 \
