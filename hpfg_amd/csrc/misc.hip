@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const HpfgPackDesc* _
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     int ks = (int)(i & 3), lane = (int)((i >> 2) & 63);
     long r = i >> 8;
-    {
+    if (d.wpk_fwd) {
       int nt = (int)(r % nt_f), ch = (int)((r / nt_f) % nch_f), tap = (int)(r / ((long)nt_f * nch_f));
       int co = nt * 16 + (lane & 15), ci = ch * 16 + ks * 4 + (lane >> 4);
       d.wpk_fwd[i] = (co < d.Cout && ci < d.Cin) ? d.w_oihw[((long)co * d.Cin + ci) * d.taps + tap] : 0.f;
@@ -112,6 +112,10 @@ __global__ __launch_bounds__(256) void pool_scatter_kernel(HpfgAct s, const floa
 #pragma unroll
     for (int k = 0; k < 4; ++k) zz[k] = *reinterpret_cast<const f32x4*>(s.z + pos[k] * s.pstride + c);
     f32x4 g = *reinterpret_cast<const f32x4*>(dP + pp * dp_ps + c);
+    // whole-window read-modify-write in float4s (coalesced); a scalar update of only the argmax element touches the same sectors
+    f32x4 da[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) da[k] = *reinterpret_cast<const f32x4*>(dA + pos[k] * da_ps + c);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float best = lrelu(zz[0][j] * sc[j] + sh[j]);
@@ -124,9 +128,11 @@ __global__ __launch_bounds__(256) void pool_scatter_kernel(HpfgAct s, const floa
           bi = k;
         }
       }
-      long dst = (bi == 0 ? pos[0] : bi == 1 ? pos[1] : bi == 2 ? pos[2] : pos[3]) * da_ps + c + j;
-      dA[dst] += g[j];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) da[k][j] += bi == k ? g[j] : 0.f;
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(dA + pos[k] * da_ps + c) = da[k];
   }
 }
 

@@ -103,15 +103,7 @@ class UNetEngine:
                         for s in self.packed}
         self.wpk16_d = {s.name: torch.empty(self.lib.hpfg_wpk16_elems(s.cout, s.cin_pad, s.taps, self.kc[s.name]), dtype=torch.bfloat16, device=device)
                         for s in self.packed}
-        descs = (L.PackDesc * len(self.packed))()
-        for d, s in zip(descs, self.packed):
-            d.w_oihw, d.b = L.ptr(params[f"{s.name}.weight"]), L.ptr(params[f"{s.name}.bias"])
-            d.wpk_fwd, d.wpk_dgrad, d.bias_pad = L.ptr(self.wpk_f[s.name]), L.ptr(self.wpk_d[s.name]), L.ptr(self.bias_pad[s.name])
-            d.wpk16_fwd, d.wpk16_dgrad, d.kc = L.ptr(self.wpk16_f[s.name]), L.ptr(self.wpk16_d[s.name]), self.kc[s.name]
-            d.Cout, d.Cin, d.CoutPad, d.CinPad, d.taps = s.cout, s.cin, s.cout_pad, s.cin_pad, s.taps
-        self._pack_host = descs
-        raw = bytes(descs)
-        self._pack_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self._pack_tables: Dict[tuple, tuple] = {}   # (math, with_dgrad) -> (host descriptors, device copy), built on first use
         self.seed_dev = torch.zeros(1, dtype=torch.int32, device=device)   # run-time dropout seed word
         self.base_seed = 0x1234567
         self.train_stats = True
@@ -192,8 +184,29 @@ class UNetEngine:
         return skip, up
 
     # ---------------------------------------------------------------------------------------------------------
-    def pack(self):
-        L.check(self.lib.hpfg_pack_weights(self._pack_dev.data_ptr(), self._pack_host, len(self.packed), self._stream()), "pack_weights")
+    def _pack_table(self, math: int, with_dgrad: bool):
+        """Descriptor table for hpfg_pack_weights: only the fragment layouts this math mode / pass consumes are produced (the
+        fp32 fragments in exact-fp32 mode, the split-bf16 ones in bf16x3 mode; the dgrad transposes only if a backward follows)."""
+        key = (math, with_dgrad)
+        if key not in self._pack_tables:
+            b16 = math == L.MATH_BF16X3
+            descs = (L.PackDesc * len(self.packed))()
+            for d, s in zip(descs, self.packed):
+                d.w_oihw, d.b = L.ptr(self.params[f"{s.name}.weight"]), L.ptr(self.params[f"{s.name}.bias"])
+                d.bias_pad = L.ptr(self.bias_pad[s.name])
+                d.wpk_fwd = None if b16 else L.ptr(self.wpk_f[s.name])
+                d.wpk_dgrad = None if (b16 or not with_dgrad) else L.ptr(self.wpk_d[s.name])
+                d.wpk16_fwd = L.ptr(self.wpk16_f[s.name]) if b16 else None
+                d.wpk16_dgrad = L.ptr(self.wpk16_d[s.name]) if (b16 and with_dgrad) else None
+                d.kc = self.kc[s.name]
+                d.Cout, d.Cin, d.CoutPad, d.CinPad, d.taps = s.cout, s.cin, s.cout_pad, s.cin_pad, s.taps
+            dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.dev)
+            self._pack_tables[key] = (descs, dev)
+        return self._pack_tables[key]
+
+    def pack(self, with_dgrad: bool = True):
+        host, dev = self._pack_table(self.math, with_dgrad)
+        L.check(self.lib.hpfg_pack_weights(dev.data_ptr(), host, len(self.packed), self._stream()), "pack_weights")
 
     def _finalize_bn(self, s: ConvSpec, nblk: int, track: bool):
         st = self._stream()
@@ -221,7 +234,7 @@ class UNetEngine:
         self.dropout_on = train if dropout is None else dropout
         if seed_step is not None:
             self.seed_dev.fill_(int(seed_step) & 0x7FFFFFFF)
-        self.pack()
+        self.pack(with_dgrad=bool(train and needs_grad))
         logits = torch.empty(self.N, self.H, self.W, self.ncls, dtype=torch.float32, device=self.dev)
         for s in self.order:
             a0, a1 = self.input_acts(s.name)

@@ -93,7 +93,7 @@ typedef struct HpfgSlabDesc {   /* one layer of hpfg_slab_reduce_multi: dw_oihw[
 typedef struct HpfgPackDesc {   /* one conv layer for hpfg_pack_weights (device array of these) */
   const float* w_oihw;  /* [Cout][Cin][k][k] (nn.Conv2d.weight, unet.py:18,22,50,99) */
   const float* b;       /* [Cout] */
-  float* wpk_fwd;       /* [taps][CinPad/16][CoutPad/16][64][4]: B fragments of mfma_f32_16x16x4f32, k = input channel */
+  float* wpk_fwd;       /* [taps][CinPad/16][CoutPad/16][64][4]: B fragments of mfma_f32_16x16x4f32, k = input channel; may be NULL */
   float* wpk_dgrad;     /* [taps][CoutPad/16][CinPad/16][64][4]: transposed + tap-flipped weights for dgrad; may be NULL */
   float* bias_pad;      /* [CoutPad] */
   void* wpk16_fwd;      /* bf16x3 B fragments [k-step][CoutPad/16][hi|lo][64][8] (hpfg_wpk16_elems() bf16 values), or NULL */
