@@ -87,6 +87,8 @@ PROTOTYPES = {
     "hpfg_wgrad_splits": (_i, [_i, _i, _i, _i, _i, _i]),
     "hpfg_wgrad_slab_floats": (_l, [_i, _i, _i, _i, _i, _i]),
     "hpfg_channel_sum": (_i, [_p, _i, _l, _i, _p, _p, _p]),
+    "hpfg_channel_sum_partials": (_i, [_p, _i, _l, _i, _p, _p]),
+    "hpfg_channel_sum_blocks": (_i, [_l, _i]),
     "hpfg_pool_scatter_add": (_i, [C.POINTER(Act), _p, _i, _p, _i, _i, _i, _i, _p]),
     "hpfg_upsample2x_bwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "hpfg_loss_blocks": (_i, [_i, _i, _i]),

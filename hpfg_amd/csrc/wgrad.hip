@@ -161,6 +161,19 @@ extern "C" int hpfg_slab_reduce_multi(const HpfgSlabDesc* table_dev, const HpfgS
   return hpfg_launch_status("slab_reduce_multi_kernel");
 }
 
+extern "C" int hpfg_channel_sum_blocks(long npix, int C) {
+  if (C < 1 || C > 256 || npix < 1) return 0;
+  const int PL = 256 / C;
+  const long want = (npix + PL - 1) / PL;
+  return (int)(want < 512 ? want : 512);
+}
+
+extern "C" int hpfg_channel_sum_partials(const float* g, int pstride, long npix, int C, float* partials, void* stream) {
+  HPFG_ARG_CHECK(g && partials && C >= 1 && C <= 256 && npix > 0, "channel_sum_partials: bad args");
+  hipLaunchKernelGGL(channel_sum_stage1, dim3(hpfg_channel_sum_blocks(npix, C)), dim3(256), 0, (hipStream_t)stream, g, pstride, npix, C, partials);
+  return hpfg_launch_status("channel_sum_stage1");
+}
+
 extern "C" int hpfg_channel_sum(const float* g, int pstride, long npix, int C, float* out, float* scratch, void* stream) {
   HPFG_ARG_CHECK(g && out && scratch && C >= 1 && C <= 256 && npix > 0, "channel_sum: bad args");
   int PL = 256 / C;

@@ -312,16 +312,24 @@ class UNetEngine:
         sizes = [self.lib.hpfg_wgrad_slab_floats(N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps) for s in self.order]
         self.slab_all = torch.empty(sum(sizes), **f32)
         self.slab_of, off = {}, 0
-        descs = (L.SlabDesc * len(self.order))()
+        # bias gradients of the convs without BatchNorm (1x1 convs, out_conv): their per-block channel sums are summed by the same
+        # launch, as pseudo layers {taps 1, Cin 1} (one kernel less per bias)
+        self.bias_layers = [s for s in self.order if not s.bn]
+        self.csum_part = {s.name: torch.empty(self.lib.hpfg_channel_sum_blocks(N * s.h * s.w, s.cout) * s.cout, **f32) for s in self.bias_layers}
+        descs = (L.SlabDesc * (len(self.order) + len(self.bias_layers)))()
         for d, s, sz in zip(descs, self.order, sizes):
             self.slab_of[s.name] = self.slab_all[off:off + sz]
             off += sz
             d.slab, d.dw_oihw = L.ptr(self.slab_of[s.name]), L.ptr(self.grads[f"{s.name}.weight"])
             d.S = self.lib.hpfg_wgrad_splits(N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps)
             d.taps, d.Cin, d.CinPad, d.Cout, d.CoutPad = s.taps, s.cin, s.cin_pad, s.cout, s.cout_pad
+        for j, s in enumerate(self.bias_layers):
+            d = descs[len(self.order) + j]
+            d.slab, d.dw_oihw = L.ptr(self.csum_part[s.name]), L.ptr(self.grads[f"{s.name}.bias"])
+            d.S = self.lib.hpfg_channel_sum_blocks(N * s.h * s.w, s.cout)
+            d.taps, d.Cin, d.CinPad, d.Cout, d.CoutPad = 1, 1, 1, s.cout, s.cout
         self._slab_host = descs
         self._slab_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.dev)
-        self.csum_scratch = torch.empty(512 * 256, **f32)
         self._bwd_alloc = True
 
     def _bn_backward(self, s: ConvSpec):
@@ -392,8 +400,8 @@ class UNetEngine:
         s = sp["decoder.out_conv"]
         g = self._act_plain(dlogits, self.ncls, s.h, s.w)
         self._wgrad(s, g)
-        L.check(self.lib.hpfg_channel_sum(L.ptr(dlogits), self.ncls, N * s.h * s.w, self.ncls, L.ptr(self.grads[f"{s.name}.bias"]),
-                                          L.ptr(self.csum_scratch), st), "channel_sum")
+        L.check(self.lib.hpfg_channel_sum_partials(L.ptr(dlogits), self.ncls, N * s.h * s.w, self.ncls, L.ptr(self.csum_part[s.name]), st),
+                "channel_sum_partials")
         self._dgrad(s, g, self.dA["decoder.up4.conv.conv_conv.4"])
         # ---- decoder blocks, last to first
         for k in range(4, 0, -1):
@@ -410,8 +418,8 @@ class UNetEngine:
             L.check(self.lib.hpfg_upsample2x_bwd(L.ptr(dup), 2 * c2, L.ptr(self.dU[k]), N, su.h, su.w, c2, st), "upsample2x_bwd")
             gu = self._act_plain(self.dU[k], c2, su.h, su.w)
             self._wgrad(su, gu)
-            L.check(self.lib.hpfg_channel_sum(L.ptr(self.dU[k]), c2, N * su.h * su.w, c2, L.ptr(self.grads[f"{su.name}.bias"]),
-                                              L.ptr(self.csum_scratch), st), "channel_sum")
+            L.check(self.lib.hpfg_channel_sum_partials(L.ptr(self.dU[k]), c2, N * su.h * su.w, c2, L.ptr(self.csum_part[su.name]), st),
+                    "channel_sum_partials")
             prev = enc_prefix(4) + ".4" if k == 1 else f"decoder.up{k - 1}.conv.conv_conv.4"
             self._dgrad(su, gu, self.dA[prev])
         if dfeat4 is not None:
@@ -435,5 +443,5 @@ class UNetEngine:
         if self._side_used:
             torch.cuda.current_stream(self.dev).wait_stream(self._side)
             self._side_used = False
-        L.check(self.lib.hpfg_slab_reduce_multi(self._slab_dev.data_ptr(), self._slab_host, len(self.order), st), "slab_reduce_multi")
+        L.check(self.lib.hpfg_slab_reduce_multi(self._slab_dev.data_ptr(), self._slab_host, len(self._slab_host), st), "slab_reduce_multi")
         self.bwd_ready = False

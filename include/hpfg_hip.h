@@ -145,6 +145,10 @@ long hpfg_wgrad_slab_floats(int N, int H, int W, int CinPad, int CoutPad, int ta
 /* first-layer wgrad: dW[co][ci][tap] for Cin<=4 from the strided input */
 /* bias gradient of a conv without BN: db[c] = sum over pixels of g[p][c] (conv1x1 / out_conv) */
 int hpfg_channel_sum(const float* g, int pstride, long npix, int C, float* out, float* scratch, void* stream);
+/* first stage only: partials [hpfg_channel_sum_blocks(npix, C)][C]; the caller sums the rows later, e.g. as one more "layer"
+ * {slab = partials, S = blocks, taps = 1, Cin = CinPad = 1, Cout = CoutPad = C, dw_oihw = db} of hpfg_slab_reduce_multi */
+int hpfg_channel_sum_partials(const float* g, int pstride, long npix, int C, float* partials, void* stream);
+int hpfg_channel_sum_blocks(long npix, int C);
 /* MaxPool2d(2) backward: dA[argmax position] += dP, recomputing the arg-max from the producer's raw output */
 int hpfg_pool_scatter_add(const HpfgAct* src /* BNACT view of the pooled tensor's producer */, const float* dP, int dp_pstride,
                           float* dA, int da_pstride, int N, int Hp, int Wp, void* stream);
