@@ -20,69 +20,90 @@ namespace {
 inline bool tile_is_big(int H, int W) { return (H % 16 == 0) && (W % 16 == 0); }
 
 // ---- first layer: Cin <= 4, direct fp32 FMA (K = 9*Cin is too small for the matrix cores) --------------------------
+// Persistent: a workgroup walks tiles w = blockIdx.x, + gridDim.x, ...; the BatchNorm partial sums stay in registers across its
+// tiles and are reduced once (the per-tile wave butterfly of 32 values used to cost more than the 144 FMAs of the convolution),
+// so the layer also hands only gridDim.x rows to the finalize instead of one per tile.
 __global__ __launch_bounds__(256) void conv_first_kernel(HpfgAct x, const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ out, float* __restrict__ stat, int N, int H, int W,
                                                          int Cin, int tiles_x, int tiles_y) {
   constexpr int T = 16, TP = T + 2, CO = 16;
   __shared__ float tin[4][TP * TP];
-  __shared__ float wl[9 * 4 * CO];
+  __shared__ __attribute__((aligned(16))) float wl[9 * 4 * CO];
   __shared__ float red[2][4][CO];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x, n = blockIdx.y;
-  const int ty0 = (tile / tiles_x) * T, tx0 = (tile % tiles_x) * T;
+  const int ntiles = tiles_x * tiles_y, nwork = ntiles * N;
   for (int i = tid; i < 9 * Cin * CO; i += 256) {   // wl[(tap*Cin+ci)*16+co] = w[co][ci][tap]
     int co = i % CO, r = i / CO, ci = r % Cin, tap = r / Cin;
     wl[i] = w[(co * Cin + ci) * 9 + tap];
   }
-  for (int i = tid; i < Cin * TP * TP; i += 256) {
-    int ci = i / (TP * TP), pix = i % (TP * TP);
-    int gy = ty0 + pix / TP - 1, gx = tx0 + pix % TP - 1;
-    float v = 0.f;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = x.z[(long)n * x.sn + (long)ci * x.sc + (long)gy * x.sy + (long)gx * x.sx];
-    tin[ci][pix] = v;
+  f32x4 bq[4], s1[4], s2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    bq[q] = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+    s1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s2[q] = s1[q];
   }
-  __syncthreads();
   const int ly = tid / T, lx = tid % T;
-  float acc[CO];
-#pragma unroll
-  for (int co = 0; co < CO; ++co) acc[co] = bias[co];
-  for (int ci = 0; ci < Cin; ++ci)
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      float a = tin[ci][(ly + tap / 3) * TP + lx + tap % 3];
-      const float* wr = wl + (tap * Cin + ci) * CO;
-#pragma unroll
-      for (int co = 0; co < CO; ++co) acc[co] = fmaf(a, wr[co], acc[co]);
+  for (int wk = blockIdx.x; wk < nwork; wk += gridDim.x) {
+    const int n = wk / ntiles, tile = wk % ntiles;
+    const int ty0 = (tile / tiles_x) * T, tx0 = (tile % tiles_x) * T;
+    __syncthreads();          // previous tile's reads of tin are done (and wl is complete before the first use)
+    for (int i = tid; i < Cin * TP * TP; i += 256) {
+      int ci = i / (TP * TP), pix = i % (TP * TP);
+      int gy = ty0 + pix / TP - 1, gx = tx0 + pix % TP - 1;
+      float v = 0.f;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = x.z[(long)n * x.sn + (long)ci * x.sc + (long)gy * x.sy + (long)gx * x.sx];
+      tin[ci][pix] = v;
     }
-  const int gy = ty0 + ly, gx = tx0 + lx;
-  const bool valid = gy < H && gx < W;
-  if (valid) {
-    f32x4* o = reinterpret_cast<f32x4*>(out + ((long)(n * H + gy) * W + gx) * CO);
+    __syncthreads();
+    f32x4 acc[4] = {bq[0], bq[1], bq[2], bq[3]};
+    for (int ci = 0; ci < Cin; ++ci)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+      for (int tap = 0; tap < 9; ++tap) {
+        const float a = tin[ci][(ly + tap / 3) * TP + lx + tap % 3];
+        const f32x4* wr = reinterpret_cast<const f32x4*>(wl + (tap * Cin + ci) * CO);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += a * wr[q];
+      }
+    const int gy = ty0 + ly, gx = tx0 + lx;
+    if (gy < H && gx < W) {
+      f32x4* o = reinterpret_cast<f32x4*>(out + ((long)(n * H + gy) * W + gx) * CO);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        o[q] = acc[q];
+        s1[q] += acc[q];
+        s2[q] += acc[q] * acc[q];
+      }
+    }
   }
   if (stat) {
 #pragma unroll
-    for (int co = 0; co < CO; ++co) {
-      float v = valid ? acc[co] : 0.f, v2 = v * v;
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        v += __shfl_xor(v, o);
-        v2 += __shfl_xor(v2, o);
+      for (int j = 0; j < 4; ++j) {
+        float v = s1[q][j], v2 = s2[q][j];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+          v += __shfl_xor(v, o);
+          v2 += __shfl_xor(v2, o);
+        }
+        if (lane == 0) {
+          red[0][wave][4 * q + j] = v;
+          red[1][wave][4 * q + j] = v2;
+        }
       }
-      if (lane == 0) {
-        red[0][wave][co] = v;
-        red[1][wave][co] = v2;
-      }
-    }
     __syncthreads();
     if (tid < 2 * CO) {
       int which = tid / CO, co = tid % CO;
       float t = red[which][0][co] + red[which][1][co] + red[which][2][co] + red[which][3][co];
-      long blk = (long)n * (tiles_x * tiles_y) + tile;
-      stat[(blk * 2 + which) * CO + co] = t;
+      stat[((long)blockIdx.x * 2 + which) * CO + co] = t;
     }
   }
+}
+
+inline int conv_first_grid(int N, int H, int W) {
+  const long nwork = (long)N * ((H + 15) / 16) * ((W + 15) / 16);
+  return (int)(nwork < 1024 ? nwork : 1024);
 }
 
 }  // namespace
@@ -92,6 +113,8 @@ extern "C" int hpfg_conv_stat_blocks(int N, int H, int W) {
   const int a = N * ((H + 7) / 8) * ((W + 7) / 8), b = N * ((H + 3) / 4) * ((W + 15) / 16);   // 8x8 (fp32 path) / 4x16 (bf16x3 3x3 path)
   return a > b ? a : b;
 }
+
+extern "C" int hpfg_conv_first_rows(int N, int H, int W) { return conv_first_grid(N, H, W); }
 
 static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only);
 
@@ -150,7 +173,7 @@ extern "C" int hpfg_conv3x3_first_fwd(const HpfgAct* x, const float* w_oihw, con
   int tx = (W + 15) / 16, ty = (H + 15) / 16;
   // stat partial layout must match hpfg_conv_stat_blocks(): 16x16 tiles only when H,W are multiples of 16
   HPFG_ARG_CHECK(stat_partials == nullptr || tile_is_big(H, W), "conv_first: BN partials need H,W multiples of 16 (got %dx%d)", H, W);
-  hipLaunchKernelGGL(conv_first_kernel, dim3(tx * ty, N), dim3(256), 0, (hipStream_t)stream, *x, w_oihw, bias, out, stat_partials, N, H, W,
-                     Cin, tx, ty);
+  hipLaunchKernelGGL(conv_first_kernel, dim3(conv_first_grid(N, H, W)), dim3(256), 0, (hipStream_t)stream, *x, w_oihw, bias, out, stat_partials,
+                     N, H, W, Cin, tx, ty);
   return hpfg_launch_status("conv_first_kernel");
 }

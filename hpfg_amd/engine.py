@@ -245,6 +245,7 @@ class UNetEngine:
                 L.check(self.lib.hpfg_conv3x3_first_fwd(C.byref(a0), L.ptr(self.params[f"{s.name}.weight"]), L.ptr(self.params[f"{s.name}.bias"]),
                                                         L.ptr(out), L.ptr(self.partials) if want_stats else None, self.N, s.h, s.w, s.cin, s.cout, st),
                         "conv3x3_first_fwd")
+                nblk = self.lib.hpfg_conv_first_rows(self.N, s.h, s.w)
             else:
                 ca = L.ConvArgs()
                 ca.a0, ca.a1 = a0, a1

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 104
+#define HPFG_VERSION 105
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -110,6 +110,7 @@ const char* hpfg_last_error(void);
 /* nn.Conv2d(Cin<=4 -> 16, k3, p1) on the network input + BN partial sums (encoder.in_conv, unet.py:18-19,72). */
 int hpfg_conv3x3_first_fwd(const HpfgAct* x, const float* w_oihw, const float* bias, float* out, float* stat_partials,
                            int N, int H, int W, int Cin, int Cout, void* stream);
+int hpfg_conv_first_rows(int N, int H, int W);            /* rows of stat_partials hpfg_conv3x3_first_fwd writes (persistent grid) */
 /* nn.Conv2d k3/k1 (+ fused producer BN/LeakyReLU/Dropout/MaxPool/Upsample/cat on load) + BN partial sums.
  * Also serves dgrad: a0 = dZ (mode DZ/PLAIN), wpk = wpk_dgrad. */
 int hpfg_conv_fwd(const HpfgConvArgs* args, void* stream);

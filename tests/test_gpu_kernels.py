@@ -206,7 +206,7 @@ def test_first_conv_and_channel_sum():
         a.z, a.mode, a.C, a.Hs, a.Ws = L.ptr(xd), L.ACT_STRIDED, cin, H, W
         a.sn, a.sc, a.sy, a.sx = xd.stride()
         out = torch.empty(N, H, W, 16, device=DEV)
-        nblk = lib.hpfg_conv_stat_blocks(N, H, W)
+        nblk = lib.hpfg_conv_first_rows(N, H, W)
         part = torch.empty(nblk * 2 * 16, device=DEV)
         L.check(lib.hpfg_conv3x3_first_fwd(C.byref(a), L.ptr(wd), L.ptr(bd), L.ptr(out), L.ptr(part), N, H, W, cin, 16, stream(DEV)), "first")
         ref = F.conv2d(x, w, b, padding=1)
