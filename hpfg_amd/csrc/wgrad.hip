@@ -131,9 +131,12 @@ extern "C" int hpfg_wgrad(const HpfgWgradArgs* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int akind = hpfg_kind_of(a->a0, a->a1);
   HPFG_ARG_CHECK(akind >= 0 && akind != HPFG_KIND_DZ, "wgrad: unsupported input source (a0.mode=%d, a1.mode=%d)", a->a0.mode, a->a1.mode);
-  int rc;
+  int rc = 1;
   const bool b16 = (a->math & 0xff) == HPFG_MATH_BF16X3 && a->taps == 9;
-  if (b16 && a->g.mode == HPFG_ACT_DZ) rc = hpfg_wgrad16_launch_dz(*a, akind, st);
+  if ((a->math & 0xff) == HPFG_MATH_BF16X3 && a->taps == 1 && (a->g.mode == HPFG_ACT_PLAIN || a->g.mode == HPFG_ACT_STRIDED) && a->g.C % 4 == 0)
+    rc = hpfg_wgrad16_launch_1x1(*a, akind, st);          // 1 = kind not covered, use the fp32 kernel below
+  if (rc != 1) {
+  } else if (b16 && a->g.mode == HPFG_ACT_DZ) rc = hpfg_wgrad16_launch_dz(*a, akind, st);
   else if (b16 && (a->g.mode == HPFG_ACT_PLAIN || a->g.mode == HPFG_ACT_STRIDED)) rc = hpfg_wgrad16_launch_plain(*a, akind, st);
   else if (a->g.mode == HPFG_ACT_DZ) rc = hpfg_wgrad_launch_dz(*a, akind, st);
   else if (a->g.mode == HPFG_ACT_PLAIN || a->g.mode == HPFG_ACT_STRIDED) rc = hpfg_wgrad_launch_plain(*a, akind, st);

@@ -27,15 +27,20 @@ using namespace hpfg_stage;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TH = 8, TW = 16;
-constexpr int HP = TH + 2, WP = TW + 2;
-constexpr int A_SLOTS = HP * WP;               // 180 pixel slots of 32 B
-constexpr int A_PLANE = A_SLOTS * 32;          // bytes per hi / lo plane of one input-channel tile
 constexpr int G_PLANE = TH * TW * 32;          // bytes per hi / lo plane of one output-channel tile
 constexpr int NTHR = 256;
 
-template <int NI, int NJ>
+template <int TAPS>
+struct Geo {                                   // A tile: 3x3 with a 1-pixel halo, 1x1 without
+  static constexpr int HALO = TAPS == 9 ? 1 : 0;
+  static constexpr int HP = TH + 2 * HALO, WP = TW + 2 * HALO;
+  static constexpr int A_SLOTS = HP * WP;      // pixel slots of 32 B (180 / 128)
+  static constexpr int A_PLANE = A_SLOTS * 32; // bytes per hi / lo plane of one input-channel tile
+};
+
+template <int NI, int NJ, int TAPS>
 struct Lds {
-  static constexpr int A_BYTES = NI * 2 * A_PLANE;
+  static constexpr int A_BYTES = NI * 2 * Geo<TAPS>::A_PLANE;
   static constexpr int G_BYTES = NJ * 2 * G_PLANE;
   static constexpr int BYTES = A_BYTES + G_BYTES;
 };
@@ -71,9 +76,10 @@ struct WPiece {
   bool real;
 };
 
-template <int NI, int NJ, int AK, int GK>
+template <int NI, int NJ, int AK, int GK, int TAPS = 9>
 __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, int tiles_x, int tiles_y) {
-  using L = Lds<NI, NJ>;
+  using L = Lds<NI, NJ, TAPS>;
+  constexpr int HALO = Geo<TAPS>::HALO, WP = Geo<TAPS>::WP, A_SLOTS = Geo<TAPS>::A_SLOTS, A_PLANE = Geo<TAPS>::A_PLANE;
   __shared__ __attribute__((aligned(16))) unsigned char lds[L::BYTES];
   unsigned char* ldsA = lds;
   unsigned char* ldsG = lds + L::A_BYTES;
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
   HPFG_WTR(1)
 
   constexpr int TSTR = 4 / (NI * NJ);               // tap stride between the taps of one wave
-  constexpr int NT = (9 + TSTR - 1) / TSTR;         // taps per wave (padded)
+  constexpr int NT = (TAPS + TSTR - 1) / TSTR;      // taps per wave (padded)
   const int wi = wave % NI, wj = (wave / NI) % NJ, wt0 = wave / (NI * NJ);
   f32x4 acc[NT];
 #pragma unroll
@@ -124,8 +130,8 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
     const int idx = tid + i * NTHR;
     const int pix = idx / GA < A_SLOTS ? idx / GA : A_SLOTS - 1;
     pa[i].real = idx < A_SLOTS * GA;
-    pa[i].ly = (short)(pix / WP - 1);
-    pa[i].lx = (short)(pix % WP - 1);
+    pa[i].ly = (short)(pix / WP - HALO);
+    pa[i].lx = (short)(pix % WP - HALO);
     pa[i].lds = (ga >> 4) * 2 * A_PLANE + pix * 32 + (ga & 8) * 2;
   }
 #pragma unroll
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
       const bf16x8 gl = tr_read8(b + G_PLANE, b + G_PLANE + TW * 32);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int tap = wt0 + t * TSTR < 9 ? wt0 + t * TSTR : 8;
+        const int tap = wt0 + t * TSTR < TAPS ? wt0 + t * TSTR : TAPS - 1;
         const int ky = tap / 3, kx = tap - 3 * ky;
         const unsigned char* a = ldsA + wi * 2 * A_PLANE + ((r0 + ky) * WP + xoff + kx) * 32 + pp * 8;
         const bf16x8 ah = tr_read8(a, a + WP * 32);
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int tap = wt0 + t * TSTR;
-    if (tap < 9) {
+    if (tap < TAPS) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ci = ci0 + wi * 16 + (lane >> 4) * 4 + r, co = co0 + wj * 16 + (lane & 15);
@@ -295,20 +301,26 @@ inline void pick_shape(int CinPad, int CoutPad, int* ni, int* nj) {
   }
 }
 
-template <int AK, int GK>
-int launch_wgrad16(const HpfgWgradArgs& a, hipStream_t st) {
+template <int AK, int GK, int TAPS>
+int launch_wgrad16_taps(const HpfgWgradArgs& a, hipStream_t st) {
   int ni, nj;
   pick_shape(a.CinPad, a.CoutPad, &ni, &nj);
   const int tx = (a.W + TW - 1) / TW, ty = (a.H + TH - 1) / TH;
   dim3 grid(a.S, a.CinPad / (16 * ni), a.CoutPad / (16 * nj));
-  if (ni == 2) hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 2, AK, GK>), grid, dim3(NTHR), 0, st, a, tx, ty);
-  else if (nj == 4) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 4, AK, GK>), grid, dim3(NTHR), 0, st, a, tx, ty);
-  else if (nj == 2) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 2, AK, GK>), grid, dim3(NTHR), 0, st, a, tx, ty);
-  else hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 1, AK, GK>), grid, dim3(NTHR), 0, st, a, tx, ty);
+  if (ni == 2) hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 2, AK, GK, TAPS>), grid, dim3(NTHR), 0, st, a, tx, ty);
+  else if (nj == 4) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 4, AK, GK, TAPS>), grid, dim3(NTHR), 0, st, a, tx, ty);
+  else if (nj == 2) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 2, AK, GK, TAPS>), grid, dim3(NTHR), 0, st, a, tx, ty);
+  else hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 1, AK, GK, TAPS>), grid, dim3(NTHR), 0, st, a, tx, ty);
   return hpfg_launch_status("wgrad_bf16x3_kernel");
+}
+
+template <int AK, int GK>
+int launch_wgrad16(const HpfgWgradArgs& a, hipStream_t st) {
+  return launch_wgrad16_taps<AK, GK, 9>(a, st);
 }
 
 }  // namespace hpfg_wg16
 
 int hpfg_wgrad16_launch_dz(const HpfgWgradArgs& a, int akind, hipStream_t st);
 int hpfg_wgrad16_launch_plain(const HpfgWgradArgs& a, int akind, hipStream_t st);
+int hpfg_wgrad16_launch_1x1(const HpfgWgradArgs& a, int akind, hipStream_t st);   // 1x1 convs: dZ is a plain gradient tensor
