@@ -159,26 +159,43 @@ __device__ inline void up_taps(int lo, int L, int* idx, float* wgt, int& cnt) {
   }
 }
 
+// The tap lists depend only on the low-res row / column: every workgroup builds both tables in LDS once (one table entry per
+// thread) instead of every thread re-deriving them for its pixel (that was ~170 VALU instructions per output float4).
+constexpr int UPB_MAXDIM = 512, UPB_TAPS = 6;
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dUp, int dup_ps, float* __restrict__ dU, int N, int Hl, int Wl,
                                                            int C) {
+  __shared__ short t_idx[UPB_MAXDIM][UPB_TAPS];
+  __shared__ float t_w[UPB_MAXDIM][UPB_TAPS];
+  __shared__ unsigned char t_cnt[UPB_MAXDIM];
+  for (int e = threadIdx.x; e < Hl + Wl; e += 256) {
+    int idx[8], cnt;
+    float wgt[8];
+    if (e < Hl) up_taps(e, Hl, idx, wgt, cnt);
+    else up_taps(e - Hl, Wl, idx, wgt, cnt);
+    if (cnt > UPB_TAPS) cnt = UPB_TAPS;      // cannot happen for a x2 align-corners map (at most 3 + 3 outputs reach one source)
+    t_cnt[e] = (unsigned char)cnt;
+    for (int k = 0; k < cnt; ++k) {
+      t_idx[e][k] = (short)idx[k];
+      t_w[e][k] = wgt[k];
+    }
+  }
+  __syncthreads();
   const int Q = C / 4, Ho = 2 * Hl, Wo = 2 * Wl;
   const long total = (long)N * Hl * Wl * Q;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     int q = (int)(i % Q);
     long pp = i / Q;
     int xl = (int)(pp % Wl), yl = (int)((pp / Wl) % Hl), n = (int)(pp / ((long)Wl * Hl));
-    int yi[8], xi[8], ny, nx;
-    float yw[8], xw[8];
-    up_taps(yl, Hl, yi, yw, ny);
-    up_taps(xl, Wl, xi, xw, nx);
+    const int ny = t_cnt[yl], nx = t_cnt[Hl + xl];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int a = 0; a < ny; ++a)
+    for (int a = 0; a < ny; ++a) {
+      const float* row = dUp + ((long)(n * Ho + t_idx[yl][a]) * Wo) * dup_ps + q * 4;
+      const float wy = t_w[yl][a];
       for (int b = 0; b < nx; ++b) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(dUp + ((long)(n * Ho + yi[a]) * Wo + xi[b]) * dup_ps + q * 4);
-        float w = yw[a] * xw[b];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += w * v[j];
+        f32x4 v = *reinterpret_cast<const f32x4*>(row + (long)t_idx[Hl + xl][b] * dup_ps);
+        acc += (wy * t_w[Hl + xl][b]) * v;
       }
+    }
     *reinterpret_cast<f32x4*>(dU + pp * C + q * 4) = acc;
   }
 }
@@ -279,7 +296,7 @@ extern "C" int hpfg_pool_scatter_add(const HpfgAct* src, const float* dP, int dp
 }
 
 extern "C" int hpfg_upsample2x_bwd(const float* dUp, int dup_pstride, float* dU, int N, int Hl, int Wl, int C, void* stream) {
-  HPFG_ARG_CHECK(dUp && dU && C % 4 == 0 && N > 0 && Hl > 0 && Wl > 0, "upsample2x_bwd: bad args");
+  HPFG_ARG_CHECK(dUp && dU && C % 4 == 0 && N > 0 && Hl > 0 && Wl > 0 && Hl + Wl <= UPB_MAXDIM, "upsample2x_bwd: bad args");
   long total = (long)N * Hl * Wl * (C / 4);
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dUp, dup_pstride, dU, N, Hl, Wl, C);
   return hpfg_launch_status("upsample_bwd_kernel");
