@@ -250,7 +250,7 @@ class UNet(nn.Module):
         eng.base_seed = self.dropout_seed
         eng.math = L.MATH_BF16X3 if self.math == "bf16x3" else L.MATH_F32
         eng.ext_masks = self.external_dropout_masks or {}
-        if self.dp is not None:
+        if self.dp is not None and getattr(self.dp, "sync_bn", True):
             eng.world, eng.allreduce = self.dp.world_size, self.dp.allreduce_sum
             eng.force_sync = bool(getattr(self.dp, "force_sync", False))
         return eng

@@ -8,6 +8,11 @@ The reference is single-process / single-device (main.py:44 says so); sharding i
   3. gradients: ONE all-reduce (SUM, the loss is already normalised by the global counts) of the flat fp32 gradient buffer
      per trainable model (7.26 MB U-Net / 14.65 MB U-Net+), issued right after backward.
 EMA, SGD and the LR/ramp-up scalars stay per rank (parameters are bit-identical after the reduced step).
+
+`sync_bn=False` selects the usual DistributedDataParallel semantics instead: BatchNorm statistics and the loss are per rank
+(every rank sees exactly what the single-GPU reference run sees: its own 8+8 batch), and the only exchange is the gradient
+all-reduce, averaged over ranks.  That removes the ~90 latency-bound 2*C-element collectives per step, which cannot be captured
+into a hipGraph here (the RCCL watchdog rejects stream capture) and bound the multi-GPU step; bench.py uses it for N > 1.
 """
 from __future__ import annotations
 
@@ -25,6 +30,7 @@ class DataParallelContext:
         self.rank = dist.get_rank(group)
         self.device = device
         self.force_sync = False     # tests: issue the collectives (and the sync code path of the engines) even with one rank
+        self.sync_bn = True         # False: per-rank BatchNorm statistics and loss, gradients averaged (DDP semantics)
 
     def allreduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         if self.world_size > 1 or self.force_sync:

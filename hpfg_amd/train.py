@@ -108,6 +108,13 @@ class _StepBase:
             for m in models:
                 self.dp.allreduce_sum(m.flat_grads)
 
+    def _set_grad_scale(self, *optimizers):
+        """sync_bn=False: the per-rank losses are means over the local batch, so the summed gradient is averaged over ranks
+        (folded into the SGD kernel's gradient scale: no extra pass over the gradients)."""
+        if self.dp is not None and not getattr(self.dp, "sync_bn", True):
+            for o in optimizers:
+                o.grad_scale = 1.0 / self.dp.world_size
+
     @staticmethod
     def _lr(opt):
         return float(opt.param_groups[0]["lr"])
@@ -121,6 +128,7 @@ class SupervisedStep(_StepBase):
         self.optimizer = build_optimizer(args=args, model=model)
         self.lr_scheduler = build_lr_scheduler(args=args, optimizer=self.optimizer)
         self.optimizer._lr_dev = self.sc.view(S_LR1)
+        self._set_grad_scale(self.optimizer)
         self.sc.host[S_COEF_A:S_COEF_A + 2] = torch.tensor([0.5, 0.5])
 
     def host_scalars(self, cur_itrs):
@@ -155,6 +163,7 @@ class MeanTeacherStep(_StepBase):
         self.optimizer = build_optimizer(args=args, model=model)
         self.lr_scheduler = build_lr_scheduler(args=args, optimizer=self.optimizer)
         self.optimizer._lr_dev = self.sc.view(S_LR1)
+        self._set_grad_scale(self.optimizer)
 
     def host_scalars(self, cur_itrs, cons_w=None):
         a = self.args
@@ -165,7 +174,8 @@ class MeanTeacherStep(_StepBase):
         h[S_COEF_A:S_COEF_A + 5] = torch.tensor([0.5, 0.5, 0.0, 0.0, w])
         return w
 
-    def device_step(self, label_img, target_label, unlabel_img):
+    def device_fwd_bwd(self, label_img, target_label, unlabel_img):
+        """Everything up to (not including) the gradient exchange."""
         nl = label_img.shape[0]
         x = torch.cat([label_img, unlabel_img], 0)
         t_out = self._teacher_forward(self.ema_model, x)
@@ -174,10 +184,20 @@ class MeanTeacherStep(_StepBase):
         res = seg_loss(out, target_label, nl, coef=self.sc.view(S_COEF_A, 8), teacher_logits=t_out, dp=self.dp)
         self.optimizer.zero_grad()
         res[0].backward()
+        return {"loss": res[0].detach(), "parts": res.detach(), "logits": out.detach(), "t_logits": t_out}
+
+    def exchange(self):
         self._reduce_grads(self.model)
+
+    def device_update(self):
         self.optimizer.step(push_lr=False)
         update_ema_variables(self.model, self.ema_model, self.args.ema_decay, 0, alpha_dev=self.sc.view(S_ALPHA))
-        return {"loss": res[0].detach(), "parts": res.detach(), "logits": out.detach(), "t_logits": t_out}
+
+    def device_step(self, label_img, target_label, unlabel_img):
+        r = self.device_fwd_bwd(label_img, target_label, unlabel_img)
+        self.exchange()
+        self.device_update()
+        return r
 
     def after(self):
         self.lr_scheduler.step()
@@ -202,6 +222,7 @@ class CPSStep(_StepBase):
         self.lr_scheduler2 = build_lr_scheduler(args=args.model2, optimizer=self.optimizer2)
         self.optimizer1._lr_dev = self.sc.view(S_LR1)
         self.optimizer2._lr_dev = self.sc.view(S_LR2)
+        self._set_grad_scale(self.optimizer1, self.optimizer2)
 
     def host_scalars(self, cur_itrs, cons_w=None):
         a = self.args
@@ -255,6 +276,7 @@ class HPFGStep(_StepBase):
         self.lr_scheduler2 = build_lr_scheduler(args=args.model2, optimizer=self.optimizer2)
         self.optimizer1._lr_dev = self.sc.view(S_LR1)
         self.optimizer2._lr_dev = self.sc.view(S_LR2)
+        self._set_grad_scale(self.optimizer1, self.optimizer2)
         self.dense_loss = Dense_Loss(args.batch_size + args.unlabel_batch_size, self.dev)
         self.mask_generator = BoxMaskGenerator(prop_range=(0.25, 0.5), n_boxes=4, random_aspect_ratio=True, prop_by_area=True,
                                                within_bounds=True, invert=True)          # main.py:94-115
@@ -321,9 +343,12 @@ class GraphedStep:
     Host scalars keep flowing through the pinned block (the captured copy node re-reads it at every replay); dropout masks
     change per replay through the engines' device seed word."""
 
-    def __init__(self, step_obj, example_inputs, warmup: int = 3):
+    def __init__(self, step_obj, example_inputs, warmup: int = 3, alias_inputs: bool = False):
+        """alias_inputs: the graph reads ``example_inputs`` themselves (the caller refills those tensors in place, or they never
+        change) instead of private copies that every step() would have to refresh with one copy kernel per input."""
         self.s = step_obj
-        self.static = [t.clone() for t in example_inputs]
+        self.alias = bool(alias_inputs)
+        self.static = list(example_inputs) if self.alias else [t.clone() for t in example_inputs]
         self.graph = torch.cuda.CUDAGraph()
         self._seed_words = []
         side = torch.cuda.Stream()
@@ -337,9 +362,23 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._freeze_seed_updates(True)
-        with torch.cuda.graph(self.graph):
-            self.s.sc.push()
-            self.out = self.s.device_step(*self.static)
+        # thread_local: another thread's HIP calls (the RCCL watchdog polling its events) must not invalidate this capture
+        dp = getattr(step_obj, "dp", None)
+        self.split = bool(dp is not None and not getattr(dp, "sync_bn", True) and (dp.world_size > 1 or dp.force_sync)
+                          and hasattr(step_obj, "device_fwd_bwd"))
+        if self.split:
+            # per-rank BatchNorm (DDP semantics): the only collective of the step is the gradient all-reduce.  Capture the work before
+            # and after it as two graphs and issue the RCCL call eagerly in between -- no collective node inside a hipGraph.
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.s.sc.push()
+                self.out = self.s.device_fwd_bwd(*self.static)
+            with torch.cuda.graph(self.graph_b, capture_error_mode="thread_local"):
+                self.s.device_update()
+        else:
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.s.sc.push()
+                self.out = self.s.device_step(*self.static)
         self._freeze_seed_updates(False)
 
     def _models(self):
@@ -351,11 +390,15 @@ class GraphedStep:
 
     def step(self, inputs, cur_itrs, **kw):
         for dst, src in zip(self.static, inputs):
-            dst.copy_(src, non_blocking=True)
+            if dst is not src:
+                dst.copy_(src, non_blocking=True)
         self.s.host_scalars(cur_itrs, **kw)
         for m in self._models():
             m.bump_graph_seed()
         self.graph.replay()
+        if self.split:
+            self.s.exchange()
+            self.graph_b.replay()
         self.s.after()
         return self.out
 

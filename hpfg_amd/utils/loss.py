@@ -51,6 +51,8 @@ class _SegLossFn(torch.autograd.Function):
         a.logits, a.t_logits, a.labels0, a.labels1 = L.ptr(x), L.ptr(t), L.ptr(labels0), L.ptr(labels1)
         a.coef, a.partials, a.sums, a.out, a.dlogits = L.ptr(coef), L.ptr(partials), L.ptr(sums), L.ptr(out), None
         a.N, a.n_lab, a.H, a.W, a.C = N, n_lab, H, W, Cc
+        if dp is not None and not getattr(dp, "sync_bn", True):
+            dp = None                     # per-rank loss (DDP semantics): no exchange of the partial sums
         a.world = dp.world_size if dp is not None else 1
         a.input_is_prob = 1 if is_prob else 0
         st = torch.cuda.current_stream(dev).cuda_stream

@@ -62,6 +62,42 @@ def test_sync_path_equals_local_path(dp):
     assert maxerr(p0.cpu(), p1.cpu()) < 1e-5
 
 
+def test_local_bn_mode_is_the_single_gpu_path_plus_one_gradient_allreduce(dp):
+    """sync_bn=False (DDP semantics, what bench.py runs for N > 1): per-rank BatchNorm and loss, only the flat gradient crosses
+    ranks and the SGD kernel averages it -> on one rank the trajectory is bit-identical to the path without a process group."""
+    l0, p0 = _run(None)
+    dp.sync_bn = False
+    try:
+        l1, p1 = _run(dp)
+    finally:
+        dp.sync_bn = True
+    assert l0 == l1 and torch.equal(p0, p1)
+
+
+def test_local_bn_mode_split_graph(dp):
+    """What bench.py runs for N > 1: forward+backward and the update captured as two hipGraphs around an eager RCCL all-reduce."""
+    dp.sync_bn = False
+    try:
+        l_eager, p_eager = _run(dp, steps=3)
+        torch.manual_seed(7)
+        m = UNet(1, 4).to(DEV)
+        ema = deepcopy(m)
+        for p in ema.parameters():
+            p.requires_grad = False
+        m.train()
+        ema.train()
+        st = MeanTeacherStep(m, ema, _args(), dp)
+        xl, yl = synth_batch(1, 2, 64, 64, 1, 4, 8)
+        xu, _ = synth_batch(2, 2, 64, 64, 1, 4, 8)
+        xl, yl, xu = xl.to(DEV), yl.to(DEV), xu.to(DEV)
+        g = GraphedStep(st, [xl, yl, xu], warmup=1, alias_inputs=True)
+        assert g.split
+        losses = [float(g.step([xl, yl, xu], k, cons_w=0.05)["loss"]) for k in range(2, 5)]
+        assert all(x == x and abs(x) < 10 for x in losses)
+    finally:
+        dp.sync_bn = True
+
+
 def test_sync_path_captures_into_a_graph(dp):
     """RCCL collectives inside the captured step (what bench.py does for N > 1 when HPFG_DP_GRAPH=1)."""
     lg, _ = _run(dp, graphed=True, steps=2)

@@ -133,3 +133,25 @@ def test_dropout_rng_law_statistics_and_determinism():
         assert not np.array_equal(m, rng_ref.keep_mask_nhwc(400000, p, 12346))
     m = rng_ref.keep_mask_nchw(2, 16, 8, 8, 0.3, 7)
     assert m.shape == (2, 16, 8, 8)
+
+
+def test_local_bn_mode_averages_the_summed_gradient():
+    """sync_bn=False: ranks keep their own BatchNorm statistics and loss; the SUM all-reduce of the gradients is turned into the
+    mean by the SGD kernel's gradient scale (no extra pass)."""
+    from hpfg_amd.train import _StepBase
+
+    class _DP:
+        world_size, force_sync, sync_bn = 4, False, False
+
+    class _Opt:
+        grad_scale = 1.0
+
+    s = _StepBase.__new__(_StepBase)
+    s.dp = _DP()
+    o1, o2 = _Opt(), _Opt()
+    s._set_grad_scale(o1, o2)
+    assert o1.grad_scale == 0.25 and o2.grad_scale == 0.25
+    s.dp.sync_bn = True
+    o3 = _Opt()
+    s._set_grad_scale(o3)
+    assert o3.grad_scale == 1.0
