@@ -221,6 +221,22 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
   }
 }
 
+// Evaluation (val.py:376-387): class-confusion counts of a predicted and a true label volume, counts[gt * C + pred] (integer
+// atomics: exact and order independent).  A workgroup first counts in LDS.
+__global__ __launch_bounds__(256) void confusion_kernel(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ gt, long n, int C,
+                                                        unsigned long long* __restrict__ counts) {
+  __shared__ unsigned int h[16 * 16];
+  for (int i = threadIdx.x; i < C * C; i += 256) h[i] = 0;
+  __syncthreads();
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int p = pred[i], g = gt[i];
+    if (p < C && g < C) atomicAdd(&h[g * C + p], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * C; i += 256)
+    if (h[i]) atomicAdd(&counts[i], (unsigned long long)h[i]);
+}
+
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom, long n,
                                                   const float* __restrict__ lr_dev, float momentum, float wd, float gscale) {
   const float lr = *lr_dev;
@@ -315,6 +331,12 @@ extern "C" int hpfg_argmax_labels(const float* logits, int N, int H, int W, int 
   long npix = (long)N * H * W;
   hipLaunchKernelGGL(argmax_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, logits, npix, C, mix_labels, mix_mask, out);
   return hpfg_launch_status("argmax_kernel");
+}
+
+extern "C" int hpfg_confusion_counts(const uint8_t* pred, const uint8_t* gt, long n, int C, unsigned long long* counts, void* stream) {
+  HPFG_ARG_CHECK(pred && gt && counts && n > 0 && C >= 1 && C <= 16, "confusion_counts: bad args (C <= 16)");
+  hipLaunchKernelGGL(confusion_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, pred, gt, n, C, counts);
+  return hpfg_launch_status("confusion_kernel");
 }
 
 extern "C" int hpfg_sgd_step(float* p, const float* g, float* mom, long n, const float* lr_dev, float momentum, float weight_decay, float grad_scale,

@@ -179,6 +179,9 @@ int hpfg_seg_loss_bwd(const HpfgLossArgs* a, const float* grad_scale_dev /* NULL
 /* pseudo-labels: argmax over classes of teacher logits, optionally CutMix-blended with labels (main.py:177-178) */
 int hpfg_argmax_labels(const float* logits, int N, int H, int W, int C, const uint8_t* mix_labels, const float* mix_mask,
                        uint8_t* out, void* stream);
+/* evaluation (val.py:376-387, medpy binary dc): counts[gt*C + pred] += 1 over n voxels (labels >= C are ignored); the caller
+ * zeroes `counts` (C*C uint64) and derives per-class Dice = 2*n(A&B) / (n(A) + n(B)) from rows / columns */
+int hpfg_confusion_counts(const uint8_t* pred, const uint8_t* gt, long n, int C, unsigned long long* counts, void* stream);
 /* CutMix image blend x1*(1-M)+xu*M (main.py:149) */
 int hpfg_cutmix_blend(const float* a, const float* b, const float* mask, float* out, long n, void* stream);
 

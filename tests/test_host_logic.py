@@ -155,3 +155,18 @@ def test_local_bn_mode_averages_the_summed_gradient():
     o3 = _Opt()
     s._set_grad_scale(o3)
     assert o3.grad_scale == 1.0
+
+
+def test_eval_zoom_index_is_scipys_mapping():
+    """hpfg_amd.val resizes through an index map taken from scipy.ndimage.zoom(order=0) itself (val.py:274,280 semantics)."""
+    import numpy as np
+    from scipy.ndimage import zoom
+    from hpfg_amd import val as V
+
+    g = np.random.default_rng(0)
+    for (h, w), (H, W) in (((40, 36), (32, 32)), ((32, 32), (50, 44)), ((17, 23), (64, 48)), ((32, 32), (32, 32))):
+        a = g.standard_normal((h, w)).astype(np.float32)
+        idx = V._zoom_index((h, w), (H, W))
+        assert np.array_equal(a.reshape(-1)[idx].reshape(H, W), zoom(a, (H / h, W / w), order=0))
+    cm = np.array([[5, 1, 0], [2, 4, 0], [1, 1, 0]])
+    assert V.dice_from_counts(cm, 1) == 2 * 4 / (6 + 6) and V.dice_from_counts(cm, 2) == 0.0
