@@ -91,6 +91,7 @@ PROTOTYPES = {
     "hpfg_channel_sum_blocks": (_i, [_l, _i]),
     "hpfg_conv_first_rows": (_i, [_i, _i, _i]),
     "hpfg_confusion_counts": (_i, [_p, _p, _l, _i, _p, _p]),
+    "hpfg_box_masks": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "hpfg_pool_scatter_add": (_i, [C.POINTER(Act), _p, _i, _p, _i, _i, _i, _i, _p]),
     "hpfg_upsample2x_bwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "hpfg_loss_blocks": (_i, [_i, _i, _i]),

@@ -221,6 +221,21 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
   }
 }
 
+// CutMix box masks (utils/utils.py:165-173): mask = invert ? 0 : 1, flipped once per box that covers the pixel
+__global__ __launch_bounds__(256) void box_masks_kernel(const int* __restrict__ rects, int n, int nb, int H, int W, int invert,
+                                                        float* __restrict__ out) {
+  const long total = (long)n * H * W;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), m = (int)(i / ((long)W * H));
+    int flips = 0;
+    for (int b = 0; b < nb; ++b) {
+      const int* r = rects + ((long)m * nb + b) * 4;      // y0, y1, x0, x1 (already normalised like a Python slice)
+      flips += (y >= r[0] && y < r[1] && x >= r[2] && x < r[3]) ? 1 : 0;
+    }
+    out[i] = (float)((invert ? 0 : 1) ^ (flips & 1));
+  }
+}
+
 // Evaluation (val.py:376-387): class-confusion counts of a predicted and a true label volume, counts[gt * C + pred] (integer
 // atomics: exact and order independent).  A workgroup first counts in LDS.
 __global__ __launch_bounds__(256) void confusion_kernel(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ gt, long n, int C,
@@ -331,6 +346,12 @@ extern "C" int hpfg_argmax_labels(const float* logits, int N, int H, int W, int 
   long npix = (long)N * H * W;
   hipLaunchKernelGGL(argmax_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, logits, npix, C, mix_labels, mix_mask, out);
   return hpfg_launch_status("argmax_kernel");
+}
+
+extern "C" int hpfg_box_masks(const int* rects, int n, int n_boxes, int H, int W, int invert, float* out, void* stream) {
+  HPFG_ARG_CHECK(rects && out && n > 0 && n_boxes > 0 && H > 0 && W > 0, "box_masks: bad args");
+  hipLaunchKernelGGL(box_masks_kernel, dim3(grid_for((long)n * H * W)), dim3(256), 0, (hipStream_t)stream, rects, n, n_boxes, H, W, invert, out);
+  return hpfg_launch_status("box_masks_kernel");
 }
 
 extern "C" int hpfg_confusion_counts(const uint8_t* pred, const uint8_t* gt, long n, int C, unsigned long long* counts, void* stream) {

@@ -294,7 +294,10 @@ class HPFGStep(_StepBase):
         self._w = w
         return w
 
-    def make_cutmix_mask(self, n, shape, rng=None):
+    def make_cutmix_mask(self, n, shape, rng=None, device=None):
+        """Host numpy masks (reference behaviour) or, with ``device``, the same masks rasterised on the GPU."""
+        if device is not None:
+            return self.mask_generator.generate_params_device(n_masks=n, mask_shape=shape, device=device, rng=rng)
         m = self.mask_generator.generate_params(n_masks=n, mask_shape=shape, rng=rng)
         return torch.tensor(m, dtype=torch.float)
 
@@ -486,7 +489,7 @@ def HPFG(model1, model2, ema_model, label_loader, unlabel_loader, test_loader, a
             label_img1, target_label1 = next(it_b)
             nl, nu = label_img.shape[0], img_unlabel.shape[0]
             rep = nu // nl
-            cm = st.make_cutmix_mask(nu, (args.train_crop_size[0], args.train_crop_size[1]))
+            cm = st.make_cutmix_mask(nu, (args.train_crop_size[0], args.train_crop_size[1]), device=torch.device(args.device))
             r = st.step(label_img.to(args.device).float(), target_label.to(args.device),
                         label_img1.repeat(rep, 1, 1, 1).to(args.device).float(), target_label1.repeat(rep, 1, 1).to(args.device),
                         img_unlabel.to(args.device).float(), cm.to(args.device), cur_itrs)

@@ -126,7 +126,8 @@ class BoxMaskGenerator(object):
         self.random_aspect_ratio, self.prop_by_area = random_aspect_ratio, prop_by_area
         self.within_bounds, self.invert = within_bounds, invert
 
-    def generate_params(self, n_masks, mask_shape, rng=None):
+    def draw_rects(self, n_masks, mask_shape, rng=None):
+        """The random part: box corners [n_masks, n_boxes, (y0, x0, y1, x1)] in the reference's draw order."""
         rng = np.random if rng is None else rng
         lo, hi = self.prop_range
         nb = self.n_boxes
@@ -158,12 +159,39 @@ class BoxMaskGenerator(object):
         else:
             cen = np.round(shape * rng.uniform(low=0.0, high=1.0, size=sizes.shape))
             rects = np.append(cen - sizes * 0.5, cen + sizes * 0.5, axis=2)
+        return rects
+
+    def generate_params(self, n_masks, mask_shape, rng=None):
+        rects = self.draw_rects(n_masks, mask_shape, rng)
         masks = np.zeros((n_masks, 1) + tuple(mask_shape)) if self.invert else np.ones((n_masks, 1) + tuple(mask_shape))
         for i, sample in enumerate(rects):
             for y0, x0, y1, x1 in sample:
                 sl = (i, 0, slice(int(y0), int(y1)), slice(int(x0), int(x1)))
                 masks[sl] = 1 - masks[sl]
         return masks
+
+    def generate_params_device(self, n_masks, mask_shape, device, rng=None):
+        """Same draws, same masks, rasterised on the device: 16 integers per mask cross the bus instead of
+        H*W floats.  Box bounds go through Python's slice normalisation on the host so that the kernel reproduces numpy's
+        slicing exactly (negative / out-of-range bounds when within_bounds=False)."""
+        import ctypes as C
+
+        import torch
+
+        from .. import _lib as L
+        rects = self.draw_rects(n_masks, mask_shape, rng)
+        H, W = int(mask_shape[0]), int(mask_shape[1])
+        norm = np.zeros((n_masks, self.n_boxes, 4), dtype=np.int32)
+        for i, sample in enumerate(rects):
+            for b, (y0, x0, y1, x1) in enumerate(sample):
+                ys, ye, _ = slice(int(y0), int(y1)).indices(H)
+                xs, xe, _ = slice(int(x0), int(x1)).indices(W)
+                norm[i, b] = (ys, max(ye, ys), xs, max(xe, xs))
+        r = torch.from_numpy(norm).to(device, non_blocking=True)
+        out = torch.empty(n_masks, 1, H, W, dtype=torch.float32, device=device)
+        L.check(L.load().hpfg_box_masks(L.ptr(r), n_masks, self.n_boxes, H, W, 1 if self.invert else 0, L.ptr(out),
+                                        torch.cuda.current_stream(device).cuda_stream), "box_masks")
+        return out
 
     def torch_masks_from_params(self, t_params, mask_shape, torch_device):
         return t_params

@@ -182,6 +182,9 @@ int hpfg_argmax_labels(const float* logits, int N, int H, int W, int C, const ui
 /* evaluation (val.py:376-387, medpy binary dc): counts[gt*C + pred] += 1 over n voxels (labels >= C are ignored); the caller
  * zeroes `counts` (C*C uint64) and derives per-class Dice = 2*n(A&B) / (n(A) + n(B)) from rows / columns */
 int hpfg_confusion_counts(const uint8_t* pred, const uint8_t* gt, long n, int C, unsigned long long* counts, void* stream);
+/* CutMix box masks (utils/utils.py:115-173 BoxMaskGenerator.generate_params): rects int32 [n][n_boxes][y0,y1,x0,x1] (bounds already
+ * normalised like Python slices), out float [n][1][H][W] = (invert ? 0 : 1) flipped once per covering box */
+int hpfg_box_masks(const int* rects, int n, int n_boxes, int H, int W, int invert, float* out, void* stream);
 /* CutMix image blend x1*(1-M)+xu*M (main.py:149) */
 int hpfg_cutmix_blend(const float* a, const float* b, const float* mask, float* out, long n, void* stream);
 

@@ -217,3 +217,17 @@ def test_first_conv_and_channel_sum():
         scratch = torch.empty(512 * 256, device=DEV)
         L.check(lib.hpfg_channel_sum(L.ptr(out), 16, N * H * W, 16, L.ptr(cs), L.ptr(scratch), stream(DEV)), "csum")
         assert maxerr(cs.cpu(), ref.sum((0, 2, 3))) < 1e-2
+
+
+def test_box_masks_device_equals_host():
+    """CutMix masks rasterised on the device are the host (reference-law) masks for the same draws, incl. numpy's slice semantics
+    for out-of-range boxes (within_bounds=False)."""
+    import numpy as np
+    from hpfg_amd.utils.utils import BoxMaskGenerator
+    for kw in (dict(prop_range=(0.25, 0.5), n_boxes=4, random_aspect_ratio=True, prop_by_area=True, within_bounds=True, invert=True),
+               dict(prop_range=(0.1, 0.9), n_boxes=3, random_aspect_ratio=True, prop_by_area=False, within_bounds=False, invert=False)):
+        gen = BoxMaskGenerator(**kw)
+        for shape in ((224, 224), (37, 53)):
+            host = gen.generate_params(6, shape, rng=np.random.RandomState(11))
+            dev = gen.generate_params_device(6, shape, DEV, rng=np.random.RandomState(11))
+            assert dev.shape == host.shape and np.array_equal(dev.cpu().numpy(), host.astype(np.float32))
