@@ -174,11 +174,32 @@ __device__ __forceinline__ void conv16_flush_stats(const HpfgConvArgs& p, f32x4 
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BL, AH, ACC, 0, 0, 0); \
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BH, AL, ACC, 0, 0, 0);
 
+// Concat loader (KIND == CAT), upsampled half: the bilinear x2 taps of a tile come from a (TH/2+3) x (TW/2+3) patch of the
+// low-resolution 1x1-conv output.  That patch is fetched ONCE per chunk (at most one 8-channel piece per thread, two float4:
+// prefetched a chunk ahead like the cheap loaders), parked in LDS as fp32, and every output piece interpolates its four taps
+// from LDS -- instead of 8 float4 global loads per output piece (24 per thread and chunk), whose registers forced a
+// two-k-step pipeline that exposed one memory latency per piece.  Skip-half chunks are plain BN + LeakyReLU pieces.
+template <class C>
+struct UpGeo {
+  static constexpr int SH = C::TH / 2 + 3, SW = C::TW / 2 + 3;
+  static constexpr int NPIECE = SH * SW * C::NG;
+  static constexpr int BYTES = SH * SW * C::KC * 4;
+  static_assert(NPIECE <= 256, "one source piece per thread");
+};
+template <int KIND>
+constexpr int eff_nr() { return KIND == HPFG_KIND_CAT ? 2 : RawCount<KIND>::N; }   // float4 loads in flight per piece
+
+// first low-res row / column a tile (with its halo) touches: source index of output coordinate max(o0, 0)
+__device__ __forceinline__ int up_base(int o0, int L) {
+  const float r = L > 1 ? (float)(L - 1) / (float)(2 * L - 1) : 0.f;
+  return (int)(r * (float)(o0 < 0 ? 0 : o0));
+}
+
 // Resident workgroups per CU the kernel is compiled for.  The thin 16x16-tile layers behind a cheap loader are HBM-bound: three
 // workgroups per CU keep more tile loads in flight; everything else needs the registers of a two-per-CU budget.
 template <class C, int KIND>
 constexpr int wg_per_cu() {
-  return (C::KSTEPS == 5 && C::NI == 1 && RawCount<KIND>::N <= 2) ? 3 : 2;
+  return (C::KSTEPS == 5 && C::NI == 1 && RawCount<KIND>::N <= 2) ? 3 : 2;      // (the concat kernel would spill at 168 VGPRs)
 }
 
 // Diagnostics build only (make TRACE=1 -> libhpfg_hip_trace.so, tools/trace_conv.py): with math bit 0x2000 wave 0 of every
@@ -201,9 +222,13 @@ template <class C, int KIND>
 __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   static_assert(C::TAPS == 9, "persistent kernel is the 3x3 path");
   constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
-  constexpr int NR = RawCount<KIND>::N;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * C::BUF_BYTES + STAT_BYTES];
+  constexpr int NR = eff_nr<KIND>();
+  constexpr bool CATK = KIND == HPFG_KIND_CAT;
+  constexpr int UP_BYTES = CATK ? UpGeo<C>::BYTES : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * C::BUF_BYTES + STAT_BYTES + UP_BYTES];
   float* ldsf = reinterpret_cast<float*>(lds + 2 * C::BUF_BYTES);
+  float* ldsU = reinterpret_cast<float*>(lds + 2 * C::BUF_BYTES + STAT_BYTES);      // low-res source patch of an upsampled chunk
+  (void)ldsU;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % C::WM, wn = wave / C::WM;
   const int cb = blockIdx.y;
@@ -278,7 +303,7 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
     s1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     s2[j] = s1[j];
   }
-  constexpr bool TIGHT = C::TAPS == 9 && C::KSTEPS == 5 && C::NI >= 2 && RawCount<KIND>::N >= 4;
+  constexpr bool TIGHT = C::TAPS == 9 && C::KSTEPS == 5 && C::NI >= 2 && eff_nr<KIND>() >= 4;
   f32x4 bias[C::NI];       // per-workgroup constant: fetched once, not per tile in the epilogue
   if (!TIGHT) conv16_load_bias<C>(p, bias, lane, nt0);
   Tab tab;
@@ -348,13 +373,28 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
       // first MFMA and finish them after the last one (a whole item of latency cover); DZ (4 raw float4 + 10 table registers) and
       // POOL/CAT (8 raw float4 per piece) keep the two-k-step ring to stay inside the register budget.
       constexpr bool DEEP = NR <= 2 || C::NLD <= 2;
-      RawPiece<KIND> raw[DEEP ? C::NLD : 2];
-      if (DEEP) {
+      // concat: a chunk is entirely skip half (BN + LeakyReLU pieces, like BNACT) or entirely upsampled half (a0.C % KC == 0)
+      constexpr int SK = CATK ? HPFG_KIND_BNACT : KIND;        // loader kind of the per-pixel pieces held in `raw`
+      RawPiece<SK> raw[DEEP ? C::NLD : 2];
+      const bool up_next = CATK && nch * C::KC >= p.a0.C;       // workgroup-uniform
+      f32x4 rawU[2];
+      int sy_base = 0, sx_base = 0;
+      if (CATK && up_next) {
+        using UG = UpGeo<C>;
+        sy_base = up_base(nty - 1, p.a1.Hs);
+        sx_base = up_base(ntx - 1, p.a1.Ws);
+        const int pix = tid / C::NG;
+        const int sy = clampi(sy_base + pix / UG::SW, 0, p.a1.Hs - 1), sx = clampi(sx_base + pix % UG::SW, 0, p.a1.Ws - 1);
+        const int cu = (c0n < cin_total ? c0n : p.a0.C) - p.a0.C;                 // channel inside the upsampled tensor
+        const int off = ((nn * p.a1.Hs + sy) * p.a1.Ws + sx) * p.a1.pstride + cu;
+        rawU[0] = ld4(p.a1.z, off);
+        rawU[1] = ld4(p.a1.z, off + 4);
+      } else if (DEEP) {
 #pragma unroll
         for (int i = 0; i < C::NLD; ++i) {
           const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
           const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
-          issue_piece<KIND>(raw[DEEP ? i : 0], p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
+          issue_piece<SK>(raw[DEEP ? i : 0], p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
         }
       }
       HPFG_TR(5)
@@ -388,14 +428,14 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
               const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
               const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
               f32x4 v0, v1;       // also on the last item (more == false): the parked piece lands in the unused buffer, no branch
-              finish_piece<KIND>(v0, v1, raw[i & 1], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
+              finish_piece<SK>(v0, v1, raw[i & 1], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
               store_piece<C>(nxt, pc[i], v0, v1);
             }
             if (s < C::NLD) {
               const int i = s < C::NLD ? s : 0;
               const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
               const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
-              issue_piece<KIND>(raw[i & 1], p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
+              issue_piece<SK>(raw[i & 1], p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
             }
           }
           int ksn = ch * C::KSTEPS + s + BD;
@@ -407,13 +447,47 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
         if (FENCE) __builtin_amdgcn_sched_barrier(0x216);   // VALU, SALU, VMEM and DS writes may cross; DS reads and MFMAs may not
       }
       HPFG_TR(6)
-      if (DEEP) {      // also on the last item: the pieces land in the unused buffer
+      if (CATK && up_next) {
+        using UG = UpGeo<C>;
+        // park the low-res patch (fp32, [pixel][KC channels]), then every output piece blends its four taps from LDS
+        if (tid < UG::NPIECE) {
+          float* d = ldsU + (tid / C::NG) * C::KC + g8;
+          *reinterpret_cast<f32x4*>(d) = rawU[0];
+          *reinterpret_cast<f32x4*>(d + 4) = rawU[1];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < C::NLD; ++i) {
+          const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
+          const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
+          int y0, y1, x0, x1;
+          float wy1, wx1;
+          up_coord(clampi(gy, 0, H - 1), p.a1.Hs, y0, y1, wy1);
+          up_coord(clampi(gx, 0, W - 1), p.a1.Ws, x0, x1, wx1);
+          const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+          const float* r0 = ldsU + ((y0 - sy_base) * UG::SW) * C::KC + g8;
+          const float* r1 = ldsU + ((y1 - sy_base) * UG::SW) * C::KC + g8;
+          const int o0 = (x0 - sx_base) * C::KC, o1 = (x1 - sx_base) * C::KC;
+          const f32x4 a00 = *reinterpret_cast<const f32x4*>(r0 + o0), b00 = *reinterpret_cast<const f32x4*>(r0 + o0 + 4);
+          const f32x4 a01 = *reinterpret_cast<const f32x4*>(r0 + o1), b01 = *reinterpret_cast<const f32x4*>(r0 + o1 + 4);
+          const f32x4 a10 = *reinterpret_cast<const f32x4*>(r1 + o0), b10 = *reinterpret_cast<const f32x4*>(r1 + o0 + 4);
+          const f32x4 a11 = *reinterpret_cast<const f32x4*>(r1 + o1), b11 = *reinterpret_cast<const f32x4*>(r1 + o1 + 4);
+          f32x4 v0 = wy0 * (wx0 * a00 + wx1 * a01) + wy1 * (wx0 * a10 + wx1 * a11);     // same expression order as finish_piece<CAT>
+          f32x4 v1 = wy0 * (wx0 * b00 + wx1 * b01) + wy1 * (wx0 * b10 + wx1 * b11);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v0[j] = ok ? v0[j] : 0.f;
+            v1[j] = ok ? v1[j] : 0.f;
+          }
+          store_piece<C>(nxt, pc[i], v0, v1);
+        }
+      } else if (DEEP) {      // also on the last item: the pieces land in the unused buffer
 #pragma unroll
         for (int i = 0; i < C::NLD; ++i) {
           const int gy = nty + pc[i].ly, gx = ntx + pc[i].lx;
           const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
           f32x4 v0, v1;
-          finish_piece<KIND>(v0, v1, raw[DEEP ? i : 0], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
+          finish_piece<SK>(v0, v1, raw[DEEP ? i : 0], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
           store_piece<C>(nxt, pc[i], v0, v1);
         }
       }
