@@ -211,6 +211,15 @@ class UNet(nn.Module):
                     p.grad = g
 
     def zero_flat_grad(self):
+        """One memset -- or none in ``direct_grads`` mode: every backward then OVERWRITES the encoder/decoder gradients in place
+        (slots backward never writes, e.g. biases in front of a train-mode BatchNorm, stay at their initial zero), which is what
+        a zero_grad() + one backward() per step amounts to.  The fused step classes switch it on; loops that accumulate several
+        backward passes into .grad must leave it off."""
+        if getattr(self, "direct_grads", False):
+            n = self._backbone_numel
+            if n < self._flat_grad.numel():
+                self._flat_grad[n:].zero_()          # projection-neck gradients still come from torch autograd
+            return
         self._flat_grad.zero_()
 
     # ---- engines ----------------------------------------------------------------------------------------------
@@ -235,17 +244,20 @@ class UNet(nn.Module):
             raise RuntimeError(f"input on {x.device} but parameters on {self._flat.device}")
         key = (tuple(x.shape), x.device.index)
         pool = self._engines.setdefault(key, [])
-        eng = next((e for e in pool if not e.bwd_ready), None)
+        direct = bool(getattr(self, "direct_grads", False))
+        eng = next((e for e in pool if not e.bwd_ready and getattr(e, "direct", False) == direct), None)
         if eng is None and len(pool) >= 4:
-            eng = pool[0]   # graphs that were never back-propagated are dropped
+            eng = next((e for e in pool if getattr(e, "direct", False) == direct), None)   # graphs never back-propagated are dropped
         if eng is None:
             named = dict(self.named_parameters())
             params = {n: p.data for n, p in named.items()}
             bufs = {n: b.data for n, b in self.named_buffers()}
-            gtmp = torch.zeros_like(self._flat)
+            # direct mode: the engine's gradient views ARE the flat gradient buffer (no staging copy, no accumulate pass)
+            gtmp = self._flat_grad if direct else torch.zeros_like(self._flat)
             grads = {n: gtmp[o:o + k].view(named[n].shape) for n, (o, k) in self._offsets.items()}
             eng = E.UNetEngine(params, bufs, grads, self.in_channels, self.num_classes, x.shape[0], x.shape[2], x.shape[3], x.device)
             eng.gtmp = gtmp
+            eng.direct = direct
             pool.append(eng)
         eng.base_seed = self.dropout_seed
         eng.math = L.MATH_BF16X3 if self.math == "bf16x3" else L.MATH_F32
@@ -256,6 +268,9 @@ class UNet(nn.Module):
         return eng
 
     def _accumulate_grads(self, eng: E.UNetEngine):
+        if getattr(eng, "direct", False):      # backward wrote straight into the flat gradient buffer
+            self.attach_grad_views()
+            return
         n = self._backbone_numel
         first = next(iter(self.parameters()))
         if first.grad is None:          # zero_grad(set_to_none=True) semantics: None means zero

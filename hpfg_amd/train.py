@@ -102,6 +102,16 @@ class _StepBase:
 
     def _attach(self, model):
         model.dp = self.dp
+        if any(p.requires_grad for p in model.parameters()):
+            model.direct_grads = True          # one zero_grad + one backward per step: write gradients in place (no memset, no add)
+
+    def _loss_backward(self, res):
+        """backward() of the fused loss vector [total, parts...]: only element 0 carries gradient; a constant one-hot gradient
+        spares autograd a ones() + zeros() + select-scatter per step."""
+        if getattr(self, "_g1", None) is None or self._g1.device != res.device:
+            self._g1 = torch.zeros(res.numel(), dtype=res.dtype, device=res.device)
+            self._g1[0] = 1.0
+        res.backward(self._g1)
 
     def _reduce_grads(self, *models):
         if self.dp is not None and (self.dp.world_size > 1 or self.dp.force_sync):
@@ -138,7 +148,7 @@ class SupervisedStep(_StepBase):
         out = self.model(img)
         res = seg_loss(out, label, coef=self.sc.view(S_COEF_A, 8), dp=self.dp)
         self.optimizer.zero_grad()
-        res[0].backward()
+        self._loss_backward(res)
         self._reduce_grads(self.model)
         self.optimizer.step(push_lr=False)
         return {"loss": res[0].detach(), "logits": out.detach(), "parts": res.detach()}
@@ -183,7 +193,7 @@ class MeanTeacherStep(_StepBase):
         self._join_teacher(t_out)
         res = seg_loss(out, target_label, nl, coef=self.sc.view(S_COEF_A, 8), teacher_logits=t_out, dp=self.dp)
         self.optimizer.zero_grad()
-        res[0].backward()
+        self._loss_backward(res)
         return {"loss": res[0].detach(), "parts": res.detach(), "logits": out.detach(), "t_logits": t_out}
 
     def exchange(self):
