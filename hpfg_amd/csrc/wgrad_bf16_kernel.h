@@ -38,10 +38,14 @@ struct Geo {                                   // A tile: 3x3 with a 1-pixel hal
   static constexpr int A_PLANE = A_SLOTS * 32; // bytes per hi / lo plane of one input-channel tile
 };
 
+// concat A source: the upsampled half's bilinear taps of an (8+2)x(16+2) tile come from a 7x11 low-res patch (see conv_bf16_kernel.h)
+constexpr int UP_SH = TH / 2 + 3, UP_SW = TW / 2 + 3;
+
 template <int NI, int NJ, int TAPS>
 struct Lds {
   static constexpr int A_BYTES = NI * 2 * Geo<TAPS>::A_PLANE;
   static constexpr int G_BYTES = NJ * 2 * G_PLANE;
+  static constexpr int UP_BYTES = UP_SH * UP_SW * 16 * NI * 4;      // fp32 patch [pixel][16 NI channels] (concat sources only)
   static constexpr int BYTES = A_BYTES + G_BYTES;
 };
 
@@ -69,6 +73,11 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* row0, const unsi
 #define HPFG_WTR_REAL(ID)
 #endif
 
+__device__ __forceinline__ int up_base_w(int o0, int L) {      // first low-res row / column a tile with halo touches
+  const float r = L > 1 ? (float)(L - 1) / (float)(2 * L - 1) : 0.f;
+  return (int)(r * (float)(o0 < 0 ? 0 : o0));
+}
+
 // One staging piece of a thread: tile-invariant local pixel and LDS byte offset (ly < 0 marks a padding piece beyond the tile).
 struct WPiece {
   short ly, lx;
@@ -80,9 +89,21 @@ template <int NI, int NJ, int AK, int GK, int TAPS = 9>
 __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, int tiles_x, int tiles_y) {
   using L = Lds<NI, NJ, TAPS>;
   constexpr int HALO = Geo<TAPS>::HALO, WP = Geo<TAPS>::WP, A_SLOTS = Geo<TAPS>::A_SLOTS, A_PLANE = Geo<TAPS>::A_PLANE;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[L::BYTES];
+  // Concat input (torch.cat([skip, up])): a workgroup's 16 NI input channels lie entirely in the skip half (a0.C % (16 NI) == 0)
+  // or entirely in the upsampled half.  Skip workgroups load BN + LeakyReLU pieces like a plain activated source; upsampled
+  // workgroups fetch the low-res patch of the tile (<= 2 pieces of 2 float4 per thread, prefetched across the MFMA phase like
+  // every other batch) into LDS and blend the four taps of each A piece from there -- the 8-float4-per-piece loader it replaces
+  // had to go one piece at a time and paid three memory latencies per work item.
+  constexpr bool CATA = AK == HPFG_KIND_CAT;
+  constexpr int SA = CATA ? HPFG_KIND_BNACT : AK;          // loader kind of the per-pixel A pieces
+  __shared__ __attribute__((aligned(16))) unsigned char lds[L::BYTES + (CATA ? L::UP_BYTES : 0)];
   unsigned char* ldsA = lds;
   unsigned char* ldsG = lds + L::A_BYTES;
+  float* ldsU = reinterpret_cast<float*>(lds + L::BYTES);
+  (void)ldsU;
+  // dZ producer tables (scale, shift, k1, k2, k3 of the 16 NJ output channels) live in LDS and are re-read per work item: as
+  // registers they were 40 VGPRs held across the MFMA phase for nothing
+  __shared__ __attribute__((aligned(16))) float ldsTG[5][16 * NJ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ci0 = blockIdx.y * 16 * NI, co0 = blockIdx.z * 16 * NJ;
   const int H = p.H, W = p.W;
@@ -112,13 +133,22 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
   Tab ta, tg;
   const int ca = ci0 + ga, cg = co0 + gg;
   const bool cva = ca < cin_total, cvg = cg < p.g.C;
-  load_tables<AK>(ta, p.a0, cva ? ca : 0, true);
-  load_tables<GK>(tg, p.g, cvg ? cg : 0, true);
+  const bool a_up = CATA && ci0 >= p.a0.C;                // workgroup-uniform
+  if (!a_up) load_tables<SA>(ta, p.a0, cva ? ca : 0, true);
+  if (GK == HPFG_KIND_DZ) {
+    for (int i = tid; i < 5 * 16 * NJ; i += NTHR) {
+      const int r = i / (16 * NJ), c = co0 + i % (16 * NJ);
+      const int row = r == 0 ? HPFG_BN_SCALE : (r == 1 ? HPFG_BN_SHIFT : (r == 2 ? HPFG_BN_K1 : (r == 3 ? HPFG_BN_K2 : HPFG_BN_K3)));
+      ldsTG[r][i % (16 * NJ)] = c < p.g.C ? p.g.bn[p.g.bn_coff + row * p.g.bn_stride + c] : 0.f;
+    }
+  }
 
   // Staging is batched: every global load of a batch is in flight before the first one is consumed (a thread owns NA pieces of
   // the A tile and NG pieces of the dZ tile; one exposed memory latency per batch instead of one per piece).  Batch 0 = the A
   // pieces + the first GB dZ pieces, and batch 0 of the NEXT work item is requested before the MFMA phase of the current one.
-  constexpr int NRA = RawCount<AK>::N, NRG = RawCount<GK>::N;
+  constexpr int NRA = RawCount<SA>::N, NRG = RawCount<GK>::N;
+  constexpr int CW = 16 * NI;                               // channels of the patch
+  constexpr int NU = CATA ? (UP_SH * UP_SW * GA + NTHR - 1) / NTHR : 1;   // patch pieces per thread
   constexpr int NA = (A_SLOTS * GA + NTHR - 1) / NTHR;
   constexpr int NG = (TH * TW * GG + NTHR - 1) / NTHR;
   constexpr int GB = NG < 2 ? NG : 2;                       // dZ pieces per batch
@@ -143,8 +173,22 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
     pg[i].lx = (short)(pix % TW);
     pg[i].lds = (gg >> 4) * 2 * G_PLANE + pix * 32 + (gg & 8) * 2;
   }
-  RawPiece<AK> rawA[PREA ? NA : 1];
+  RawPiece<SA> rawA[PREA ? NA : 1];
   RawPiece<GK> rawG[GB];
+  f32x4 rawU[NU][2];
+#define HPFG_WG_U_ISSUE()                                                                              \
+  {                                                                                                   \
+    const int sy_b = up_base_w(ty0 - 1, p.a1.Hs), sx_b = up_base_w(tx0 - 1, p.a1.Ws);                 \
+    _Pragma("unroll") for (int i = 0; i < NU; ++i) {                                                  \
+      const int pix = (tid + i * NTHR) / GA;                                                          \
+      int sy = sy_b + pix / UP_SW, sx = sx_b + pix % UP_SW;                                           \
+      sy = sy > p.a1.Hs - 1 ? p.a1.Hs - 1 : sy;                                                       \
+      sx = sx > p.a1.Ws - 1 ? p.a1.Ws - 1 : sx;                                                       \
+      const int off = ((n * p.a1.Hs + sy) * p.a1.Ws + sx) * p.a1.pstride + (cva ? ca - p.a0.C : 0);   \
+      rawU[i][0] = ld4(p.a1.z, off);                                                                  \
+      rawU[i][1] = ld4(p.a1.z, off + 4);                                                              \
+    }                                                                                                 \
+  }
 
 #define HPFG_WG_A_COORD(I)                                                                            \
   const int gy = ty0 + pa[I].ly, gx = tx0 + pa[I].lx;                                                 \
@@ -165,11 +209,13 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
   if (wk < nwork) {
     const int n = wk / ntiles, tile = wk % ntiles;
     const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
-    if (PREA) {
+    if (a_up) {
+      HPFG_WG_U_ISSUE()
+    } else if (PREA) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         HPFG_WG_A_COORD(i)
-        issue_piece<AK>(rawA[PREA ? i : 0], p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);
+        issue_piece<SA>(rawA[PREA ? i : 0], p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);
       }
     }
 #pragma unroll
@@ -184,20 +230,76 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
     const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
     __syncthreads();            // the previous item's MFMA phase has finished reading the tiles
     HPFG_WTR(3)
+    if (a_up) {
+      // park the low-res patch, then blend every A piece's four taps from LDS (same expression order as finish_piece<CAT>)
+      const int sy_b = up_base_w(ty0 - 1, p.a1.Hs), sx_b = up_base_w(tx0 - 1, p.a1.Ws);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      HPFG_WG_A_COORD(i)
-      f32x4 v0, v1;
-      if (!PREA) issue_piece<AK>(rawA[0], p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);      // one piece at a time
-      finish_piece<AK>(v0, v1, rawA[PREA ? i : 0], ta, p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);
-      if (pa[i].real) {
-        bf16x8 hi, lo;
-        split8(v0, v1, hi, lo);
-        *reinterpret_cast<bf16x8*>(ldsA + pa[i].lds) = hi;
-        *reinterpret_cast<bf16x8*>(ldsA + pa[i].lds + A_PLANE) = lo;
+      for (int i = 0; i < NU; ++i) {
+        const int idx = tid + i * NTHR;
+        if (idx < UP_SH * UP_SW * GA) {
+          float* d = ldsU + (idx / GA) * CW + ga;
+          *reinterpret_cast<f32x4*>(d) = rawU[i][0];
+          *reinterpret_cast<f32x4*>(d + 4) = rawU[i][1];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        HPFG_WG_A_COORD(i)
+        int y0, y1, x0, x1;
+        float wy1, wx1;
+        up_coord(gyc, p.a1.Hs, y0, y1, wy1);
+        up_coord(gxc, p.a1.Ws, x0, x1, wx1);
+        const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+        const float* r0 = ldsU + ((y0 - sy_b) * UP_SW) * CW + ga;
+        const float* r1 = ldsU + ((y1 - sy_b) * UP_SW) * CW + ga;
+        const int o0 = (x0 - sx_b) * CW, o1 = (x1 - sx_b) * CW;
+        const f32x4 a00 = *reinterpret_cast<const f32x4*>(r0 + o0), b00 = *reinterpret_cast<const f32x4*>(r0 + o0 + 4);
+        const f32x4 a01 = *reinterpret_cast<const f32x4*>(r0 + o1), b01 = *reinterpret_cast<const f32x4*>(r0 + o1 + 4);
+        const f32x4 a10 = *reinterpret_cast<const f32x4*>(r1 + o0), b10 = *reinterpret_cast<const f32x4*>(r1 + o0 + 4);
+        const f32x4 a11 = *reinterpret_cast<const f32x4*>(r1 + o1), b11 = *reinterpret_cast<const f32x4*>(r1 + o1 + 4);
+        f32x4 v0 = wy0 * (wx0 * a00 + wx1 * a01) + wy1 * (wx0 * a10 + wx1 * a11);
+        f32x4 v1 = wy0 * (wx0 * b00 + wx1 * b01) + wy1 * (wx0 * b10 + wx1 * b11);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v0[j] = ok ? v0[j] : 0.f;
+          v1[j] = ok ? v1[j] : 0.f;
+        }
+        if (pa[i].real) {
+          bf16x8 hi, lo;
+          split8(v0, v1, hi, lo);
+          *reinterpret_cast<bf16x8*>(ldsA + pa[i].lds) = hi;
+          *reinterpret_cast<bf16x8*>(ldsA + pa[i].lds + A_PLANE) = lo;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        HPFG_WG_A_COORD(i)
+        f32x4 v0, v1;
+        if (!PREA) issue_piece<SA>(rawA[0], p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);      // one piece at a time
+        finish_piece<SA>(v0, v1, rawA[PREA ? i : 0], ta, p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);
+        if (pa[i].real) {
+          bf16x8 hi, lo;
+          split8(v0, v1, hi, lo);
+          *reinterpret_cast<bf16x8*>(ldsA + pa[i].lds) = hi;
+          *reinterpret_cast<bf16x8*>(ldsA + pa[i].lds + A_PLANE) = lo;
+        }
       }
     }
     HPFG_WTR(4)
+    if (GK == HPFG_KIND_DZ) {
+      tg.sc[0] = *reinterpret_cast<const f32x4*>(&ldsTG[0][gg]);
+      tg.sc[1] = *reinterpret_cast<const f32x4*>(&ldsTG[0][gg + 4]);
+      tg.sh[0] = *reinterpret_cast<const f32x4*>(&ldsTG[1][gg]);
+      tg.sh[1] = *reinterpret_cast<const f32x4*>(&ldsTG[1][gg + 4]);
+      tg.k1[0] = *reinterpret_cast<const f32x4*>(&ldsTG[2][gg]);
+      tg.k1[1] = *reinterpret_cast<const f32x4*>(&ldsTG[2][gg + 4]);
+      tg.k2[0] = *reinterpret_cast<const f32x4*>(&ldsTG[3][gg]);
+      tg.k2[1] = *reinterpret_cast<const f32x4*>(&ldsTG[3][gg + 4]);
+      tg.k3[0] = *reinterpret_cast<const f32x4*>(&ldsTG[4][gg]);
+      tg.k3[1] = *reinterpret_cast<const f32x4*>(&ldsTG[4][gg + 4]);
+    }
 #pragma unroll
     for (int b = 0; b < NGB; ++b) {
       if (b > 0) {
@@ -229,11 +331,13 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
       const int wk2 = wk + (int)gridDim.x < nwork ? wk + (int)gridDim.x : wk;
       const int n = wk2 / ntiles, tile = wk2 % ntiles;
       const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
-      if (PREA) {
+      if (a_up) {
+        HPFG_WG_U_ISSUE()
+      } else if (PREA) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
           HPFG_WG_A_COORD(i)
-          issue_piece<AK>(rawA[PREA ? i : 0], p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);
+          issue_piece<SA>(rawA[PREA ? i : 0], p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);
         }
       }
 #pragma unroll
@@ -268,6 +372,7 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
   }
 #undef HPFG_WG_A_COORD
 #undef HPFG_WG_G_COORD
+#undef HPFG_WG_U_ISSUE
   // slab[s][tap][ci][co]; C/D layout: row (ci) = (lane>>4)*4 + r, col (co) = lane & 15
 #ifdef HPFG_TRACE
   if (p.math & 0x2000) {
