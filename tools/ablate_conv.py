@@ -49,7 +49,7 @@ names = os.environ.get("LAYERS", "encoder.in_conv.conv_conv.4,decoder.up4.conv.c
 if os.environ.get("QUICK"):
     for name in names:
         s = eng.specs[name]
-        print(f"{name} ({s.cin}->{s.cout} @{s.h}): {run(name, 0):.1f} us")
+        print(f"{name} ({s.cin}->{s.cout} @{s.h}): {run(name, int(os.environ.get('FLAGS', '0'), 0)):.1f} us")
     raise SystemExit
 for name in names:
     s = eng.specs[name]
