@@ -54,6 +54,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if os.environ.get("HPFG_BENCH_ONE_DEVICE", "0") == "1":      # rehearsal: several ranks on one GPU (with HPFG_DP_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -64,7 +66,7 @@ def main():
     from hpfg_amd.train import GraphedStep, MeanTeacherStep
     from hpfg_amd.utils import loadyaml
 
-    dp = parallel.init_from_env(dev) if (world > 1 or a.force_sync) else None
+    dp = parallel.init_from_env(dev, backend=os.environ.get("HPFG_DP_BACKEND") or None) if (world > 1 or a.force_sync) else None
     if a.force_sync and dp is not None:
         os.environ.setdefault("MASTER_PORT", "29511")
         dp.force_sync = True
@@ -133,7 +135,7 @@ def main():
     if rank == 0:
         roof = dominant_kernel_roofline(model, xl, xu, dev)
     cpu = None
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:      # reported baseline: rank 0 at N=1 only
         cpu = cpu_baseline(a.lab, a.unlab, a.size)
     if rank == 0:
         step_bytes = algorithmic_bytes_mt(n_img)

@@ -38,7 +38,7 @@ class DataParallelContext:
         return t
 
     def barrier(self):
-        if self.device is not None and self.device.type == "cuda":
+        if self.device is not None and self.device.type == "cuda" and dist.get_backend(self.group) == "nccl":
             dist.barrier(group=self.group, device_ids=[self.device.index])
         else:
             dist.barrier(group=self.group)
