@@ -47,31 +47,43 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 }
 
 // all layers of a backward pass in one launch: blockIdx.y = layer, workgroups stride over that layer's 16-element groups
+// One launch for every layer (blockIdx.y): a workgroup sums 64 consecutive slab elements (16 threads x float4: 256 contiguous
+// bytes per slab row) over the slabs in 16 interleaved lanes, in a fixed order (reproducible), and scatters them to OIHW.
 __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const HpfgSlabDesc* __restrict__ table) {
-  __shared__ float red[16][17];
+  __shared__ float red[16][65];
   const HpfgSlabDesc d = table[blockIdx.y];
   const long per = (long)d.taps * d.CinPad * d.CoutPad;
   const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  for (long g0 = (long)blockIdx.x * 16; g0 < per; g0 += (long)gridDim.x * 16) {
-    const long i = g0 + il;
-    float t0 = 0.f, t1 = 0.f;
-    if (i < per) {
+  const bool vec = (per & 3) == 0;
+  for (long g0 = (long)blockIdx.x * 64; g0 < per; g0 += (long)gridDim.x * 64) {
+    const long i = g0 + il * 4;
+    f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+    if (vec && i + 3 < per) {
       int s = sl;
       for (; s + 16 < d.S; s += 32) {
-        t0 += d.slab[s * per + i];
-        t1 += d.slab[(s + 16) * per + i];
+        t0 += *reinterpret_cast<const f32x4*>(d.slab + s * per + i);
+        t1 += *reinterpret_cast<const f32x4*>(d.slab + (s + 16) * per + i);
       }
-      if (s < d.S) t0 += d.slab[s * per + i];
+      if (s < d.S) t0 += *reinterpret_cast<const f32x4*>(d.slab + s * per + i);
+    } else {
+      for (int s = sl; s < d.S; s += 16)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (i + j < per) t0[j] += d.slab[s * per + i + j];
     }
     __syncthreads();
-    red[sl][il] = t0 + t1;
-    __syncthreads();
-    if (sl == 0 && i < per) {
-      float t = 0.f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) t += red[k][il];
-      const int co = (int)(i % d.CoutPad), ci = (int)((i / d.CoutPad) % d.CinPad), tap = (int)(i / ((long)d.CoutPad * d.CinPad));
-      if (co < d.Cout && ci < d.Cin) d.dw_oihw[((long)co * d.Cin + ci) * d.taps + tap] = t;
+    for (int j = 0; j < 4; ++j) red[sl][il * 4 + j] = t0[j] + t1[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const long e = g0 + threadIdx.x;
+      if (e < per) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        const int co = (int)(e % d.CoutPad), ci = (int)((e / d.CoutPad) % d.CinPad), tap = (int)(e / ((long)d.CoutPad * d.CinPad));
+        if (co < d.Cout && ci < d.Cin) d.dw_oihw[((long)co * d.Cin + ci) * d.taps + tap] = t;
+      }
     }
   }
 }
@@ -158,8 +170,8 @@ extern "C" int hpfg_slab_reduce_multi(const HpfgSlabDesc* table_dev, const HpfgS
     long per = (long)table_host[i].taps * table_host[i].CinPad * table_host[i].CoutPad;
     if (per > mx) mx = per;
   }
-  long gx = (mx + 15) / 16;
-  if (gx > 4096) gx = 4096;
+  long gx = (mx + 63) / 64;
+  if (gx > 2048) gx = 2048;
   hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((unsigned)gx, nlayers), dim3(256), 0, (hipStream_t)stream, table_dev);
   return hpfg_launch_status("slab_reduce_multi_kernel");
 }
