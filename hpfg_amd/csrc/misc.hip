@@ -47,37 +47,28 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const HpfgPackDesc* _
     const int Kch = dir == 0 ? d.Cin : d.Cout;                  // contraction channels
     const int ntn = (dir == 0 ? d.CoutPad : d.CinPad) / 16;     // output-channel tiles
     const int nchunks = (Kch + d.kc - 1) / d.kc;
-    const long tot = (long)nchunks * ksteps * ntn * 64;           // one thread per lane fragment: 8 k-values -> one 16-B store per plane
+    const long tot = (long)nchunks * ksteps * ntn * 512;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
-      const int lane = (int)(i & 63);
-      const long r = i >> 6;
+      const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+      const long r = i >> 9;
       const int nt = (int)(r % ntn), ks = (int)(r / ntn);
       const int chunk = ks / ksteps, s = ks % ksteps;
+      const int kl = 8 * (lane >> 4) + j;
+      int tap, kch;
+      if (d.taps == 1) { tap = 0; kch = chunk * 32 + kl; }
+      else if (d.kc == 32) { tap = s; kch = chunk * 32 + kl; }
+      else { tap = 2 * s + (kl >> 4); kch = chunk * 16 + (kl & 15); }
       const int nch = nt * 16 + (lane & 15);
-      float w[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int kl = 8 * (lane >> 4) + j;
-        int tap, kch;
-        if (d.taps == 1) { tap = 0; kch = chunk * 32 + kl; }
-        else if (d.kc == 32) { tap = s; kch = chunk * 32 + kl; }
-        else { tap = 2 * s + (kl >> 4); kch = chunk * 16 + (kl & 15); }
-        w[j] = 0.f;
-        if (tap < d.taps && kch < Kch) {
-          if (dir == 0) { if (nch < d.Cout) w[j] = d.w_oihw[((long)nch * d.Cin + kch) * d.taps + tap]; }
-          else { if (nch < d.Cin) w[j] = d.w_oihw[((long)kch * d.Cin + nch) * d.taps + (d.taps - 1 - tap)]; }
-        }
+      float w = 0.f;
+      if (tap < d.taps && kch < Kch) {
+        if (dir == 0) { if (nch < d.Cout) w = d.w_oihw[((long)nch * d.Cin + kch) * d.taps + tap]; }
+        else { if (nch < d.Cin) w = d.w_oihw[((long)kch * d.Cin + nch) * d.taps + (d.taps - 1 - tap)]; }
       }
-      typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
-      b16x8 hi, lo;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        hi[j] = (__bf16)w[j];
-        lo[j] = (__bf16)(w[j] - (float)hi[j]);
-      }
+      const __bf16 hi = (__bf16)w;
+      const __bf16 lo = (__bf16)(w - (float)hi);
       const long base = ((long)ks * ntn + nt) * 2;
-      *reinterpret_cast<b16x8*>(out + (base + 0) * 512 + lane * 8) = hi;
-      *reinterpret_cast<b16x8*>(out + (base + 1) * 512 + lane * 8) = lo;
+      out[(base + 0) * 512 + lane * 8 + j] = hi;
+      out[(base + 1) * 512 + lane * 8 + j] = lo;
     }
   }
 }
