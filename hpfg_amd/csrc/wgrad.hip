@@ -90,8 +90,32 @@ __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const HpfgSlabDe
 
 // db[c] = sum_p g[p*pstride + c]: two-stage deterministic reduction
 __global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restrict__ g, int pstride, long npix, int C, float* __restrict__ scratch) {
-  __shared__ float red[256];
+  __shared__ float red[256 * 4];
   const int tid = threadIdx.x;
+  if ((C & 3) == 0 && (pstride & 3) == 0) {      // float4 per thread: quad q of pixel lane pl, 4 independent pixel loads in flight
+    const int Q = C >> 2, q = tid % Q, pl = tid / Q, PL = 256 / Q;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (pl < PL) {
+      const long stride = (long)gridDim.x * PL;
+      for (long pix = (long)blockIdx.x * PL + pl; pix < npix; pix += 4 * stride) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long px = pix + u * stride;
+          if (px < npix) a += *reinterpret_cast<const f32x4*>(g + px * pstride + q * 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[tid * 4 + j] = a[j];
+    __syncthreads();
+    if (tid < C) {
+      float t = 0.f;
+      const int qq = tid >> 2, j = tid & 3;
+      for (int l = 0; l < PL; ++l) t += red[(l * Q + qq) * 4 + j];
+      scratch[(long)blockIdx.x * C + tid] = t;
+    }
+    return;
+  }
   const int c = tid % C, pl = tid / C, PL = 256 / C;
   float a = 0.f;
   if (pl < PL)
@@ -104,6 +128,7 @@ __global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restric
     scratch[(long)blockIdx.x * C + tid] = t;
   }
 }
+
 __global__ __launch_bounds__(64) void channel_sum_stage2(const float* __restrict__ scratch, int nblk, int C, float* __restrict__ out) {
   const int c = blockIdx.x;
   double a = 0.0;
