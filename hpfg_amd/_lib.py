@@ -43,6 +43,12 @@ class WgradArgs(C.Structure):
                 ("W", C.c_int32), ("taps", C.c_int32), ("S", C.c_int32), ("math", C.c_int32), ("defer_reduce", C.c_int32)]
 
 
+class AugSample(C.Structure):
+    _fields_ = [("img_off", C.c_int64), ("lab_off", C.c_int64), ("h", C.c_int32), ("w", C.c_int32), ("mode", C.c_int32), ("k", C.c_int32),
+                ("axis", C.c_int32), ("tab_off", C.c_int32), ("m00", C.c_double), ("m01", C.c_double), ("m10", C.c_double),
+                ("m11", C.c_double), ("off_y", C.c_double), ("off_x", C.c_double)]
+
+
 class SlabDesc(C.Structure):
     _fields_ = [("slab", C.c_void_p), ("dw_oihw", C.c_void_p), ("S", C.c_int32), ("taps", C.c_int32), ("Cin", C.c_int32),
                 ("CinPad", C.c_int32), ("Cout", C.c_int32), ("CoutPad", C.c_int32)]
@@ -92,6 +98,7 @@ PROTOTYPES = {
     "hpfg_conv_first_rows": (_i, [_i, _i, _i]),
     "hpfg_confusion_counts": (_i, [_p, _p, _l, _i, _p, _p]),
     "hpfg_box_masks": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "hpfg_augment_batch": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "hpfg_pool_scatter_add": (_i, [C.POINTER(Act), _p, _i, _p, _i, _i, _i, _i, _p]),
     "hpfg_upsample2x_bwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "hpfg_loss_blocks": (_i, [_i, _i, _i]),

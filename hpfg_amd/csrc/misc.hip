@@ -221,6 +221,57 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
   }
 }
 
+// Training-time augmentation of ACDC slices (datasets/utils.py:73-117 RandomGenerator): optional rot90+flip or integer-angle
+// rotation (scipy.ndimage.rotate, order 0, reshape=False), then nearest resize to the network size (scipy.ndimage.zoom, order 0),
+// for image and mask alike.  All three are index remaps, so one gather per output pixel does the whole chain: the zoom's
+// per-axis source indices come from the host (scipy's own 1-D tables), the rotation follows scipy's affine arithmetic in
+// double precision (matrix and offset computed on the host exactly as ndimage.rotate does), rot90 / flip are exact permutations.
+__global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ img_pool, const uint8_t* __restrict__ lab_pool,
+                                                      const HpfgAugSample* __restrict__ samples, const int* __restrict__ tabs, int B, int H, int W,
+                                                      float* __restrict__ out_img, uint8_t* __restrict__ out_lab) {
+  const long total = (long)B * H * W;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int X = (int)(i % W), Y = (int)((i / W) % H), b = (int)(i / ((long)W * H));
+    const HpfgAugSample s = samples[b];
+    const int y1 = tabs[s.tab_off + Y], x1 = tabs[s.tab_off + H + X];      // pixel of the (possibly rotated) intermediate image
+    int ys = y1, xs = x1;
+    bool inside = y1 >= 0 && x1 >= 0;            // -1: scipy's zoom wrote its constant there
+    if (!inside) {
+    } else if (s.mode == 1) {
+      const bool odd = s.k & 1;
+      const int h1 = odd ? s.w : s.h, w1 = odd ? s.h : s.w;                  // shape after rot90
+      int bi = y1, bj = x1;                                                  // undo the flip
+      if (s.axis == 0) bi = h1 - 1 - y1;
+      else bj = w1 - 1 - x1;
+      switch (s.k & 3) {                                                     // np.rot90(a, k)[bi, bj]
+        case 0: ys = bi; xs = bj; break;
+        case 1: ys = bj; xs = s.w - 1 - bi; break;
+        case 2: ys = s.h - 1 - bi; xs = s.w - 1 - bj; break;
+        default: ys = s.h - 1 - bj; xs = bi; break;
+      }
+    } else if (s.mode == 2) {
+      // icoor = ((0 + y*m00) + x*m01) + shift, no contraction: the operation order of scipy's NI_GeometricTransform
+      double cy = __dmul_rn((double)y1, s.m00);
+      cy = __dadd_rn(cy, __dmul_rn((double)x1, s.m01));
+      cy = __dadd_rn(cy, s.off_y);
+      double cx = __dmul_rn((double)y1, s.m10);
+      cx = __dadd_rn(cx, __dmul_rn((double)x1, s.m11));
+      cx = __dadd_rn(cx, s.off_x);
+      inside = !(cy < 0.0 || cy > (double)(s.h - 1) || cx < 0.0 || cx > (double)(s.w - 1));      // mode='constant', cval 0
+      ys = (int)floor(cy + 0.5);
+      xs = (int)floor(cx + 0.5);
+    }
+    float v = 0.f;
+    uint8_t l = 0;
+    if (inside) {
+      v = img_pool[s.img_off + (long)ys * s.w + xs];
+      l = lab_pool[s.lab_off + (long)ys * s.w + xs];
+    }
+    out_img[i] = v;
+    out_lab[i] = l;
+  }
+}
+
 // CutMix box masks (utils/utils.py:165-173): mask = invert ? 0 : 1, flipped once per box that covers the pixel
 __global__ __launch_bounds__(256) void box_masks_kernel(const int* __restrict__ rects, int n, int nb, int H, int W, int invert,
                                                         float* __restrict__ out) {
@@ -346,6 +397,14 @@ extern "C" int hpfg_argmax_labels(const float* logits, int N, int H, int W, int 
   long npix = (long)N * H * W;
   hipLaunchKernelGGL(argmax_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, logits, npix, C, mix_labels, mix_mask, out);
   return hpfg_launch_status("argmax_kernel");
+}
+
+extern "C" int hpfg_augment_batch(const float* img_pool, const uint8_t* lab_pool, const HpfgAugSample* samples_dev, const int* tabs_dev, int B, int H,
+                                  int W, float* out_img, uint8_t* out_lab, void* stream) {
+  HPFG_ARG_CHECK(img_pool && lab_pool && samples_dev && tabs_dev && out_img && out_lab && B > 0 && H > 0 && W > 0, "augment_batch: bad args");
+  hipLaunchKernelGGL(augment_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, img_pool, lab_pool, samples_dev, tabs_dev, B,
+                     H, W, out_img, out_lab);
+  return hpfg_launch_status("augment_kernel");
 }
 
 extern "C" int hpfg_box_masks(const int* rects, int n, int n_boxes, int H, int W, int invert, float* out, void* stream) {

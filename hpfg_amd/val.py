@@ -30,10 +30,10 @@ def _zoom_index(src_hw: Tuple[int, int], dst_hw: Tuple[int, int]) -> np.ndarray:
     (val.py:274,280: zoom(slice, (dst/src, dst/src), order=0))."""
     from scipy.ndimage import zoom
     h, w = src_hw
-    idx = np.arange(h * w, dtype=np.float64).reshape(h, w)
+    idx = np.arange(1, h * w + 1, dtype=np.float64).reshape(h, w)
     out = zoom(idx, (dst_hw[0] / h, dst_hw[1] / w), order=0)
     assert out.shape == tuple(dst_hw), (out.shape, dst_hw)
-    return np.rint(out).astype(np.int64).reshape(-1)
+    return np.rint(out).astype(np.int64).reshape(-1) - 1      # -1: scipy wrote its constant 0 (coordinate a rounding error past the edge)
 
 
 def _resize_nearest(t: torch.Tensor, dst_hw: Sequence[int]) -> torch.Tensor:
@@ -42,7 +42,9 @@ def _resize_nearest(t: torch.Tensor, dst_hw: Sequence[int]) -> torch.Tensor:
     if (h, w) == tuple(dst_hw):
         return t
     idx = torch.from_numpy(_zoom_index((h, w), (int(dst_hw[0]), int(dst_hw[1])))).to(t.device)
-    return t.reshape(s, h * w).index_select(1, idx).reshape(s, int(dst_hw[0]), int(dst_hw[1]))
+    out = t.reshape(s, h * w).index_select(1, idx.clamp(min=0))
+    out = torch.where(idx.unsqueeze(0) >= 0, out, torch.zeros((), dtype=t.dtype, device=t.device))
+    return out.reshape(s, int(dst_hw[0]), int(dst_hw[1]))
 
 
 def predict_volume(image: torch.Tensor, net, patch_size: Sequence[int] = (256, 256)) -> torch.Tensor:

@@ -182,6 +182,20 @@ int hpfg_argmax_labels(const float* logits, int N, int H, int W, int C, const ui
 /* evaluation (val.py:376-387, medpy binary dc): counts[gt*C + pred] += 1 over n voxels (labels >= C are ignored); the caller
  * zeroes `counts` (C*C uint64) and derives per-class Dice = 2*n(A&B) / (n(A) + n(B)) from rows / columns */
 int hpfg_confusion_counts(const uint8_t* pred, const uint8_t* gt, long n, int C, unsigned long long* counts, void* stream);
+/* Training-time slice augmentation on the device (datasets/utils.py:73-117 RandomGenerator.__call__: random_rot_flip | random_rotate,
+ * then scipy zoom(order=0) to the network size, image and mask alike).  The host draws the random parameters in the reference's
+ * order and supplies, per sample, the source slice, the rot90/flip or rotation parameters (rotation matrix and offset exactly
+ * as scipy.ndimage.rotate computes them) and scipy's 1-D zoom index tables; the kernel gathers image [B][1][H][W] and mask [B][H][W]. */
+typedef struct HpfgAugSample {
+  int64_t img_off, lab_off;   /* element offsets of the source slice in the pools */
+  int32_t h, w;               /* source slice size */
+  int32_t mode;               /* 0 none, 1 rot90 + flip, 2 rotate */
+  int32_t k, axis;            /* mode 1: np.rot90(a, k) then np.flip(axis) */
+  int32_t tab_off;            /* offset into tabs: H row indices then W column indices of the intermediate image */
+  double m00, m01, m10, m11, off_y, off_x;   /* mode 2: input coordinate = M * output index + offset */
+} HpfgAugSample;
+int hpfg_augment_batch(const float* img_pool, const uint8_t* lab_pool, const HpfgAugSample* samples_dev, const int* tabs_dev, int B, int H, int W,
+                       float* out_img, uint8_t* out_lab, void* stream);
 /* CutMix box masks (utils/utils.py:115-173 BoxMaskGenerator.generate_params): rects int32 [n][n_boxes][y0,y1,x0,x1] (bounds already
  * normalised like Python slices), out float [n][1][H][W] = (invert ? 0 : 1) flipped once per covering box */
 int hpfg_box_masks(const int* rects, int n, int n_boxes, int H, int W, int invert, float* out, void* stream);
