@@ -102,7 +102,12 @@ __global__ __launch_bounds__(256) void loss_partials_kernel(HpfgLossArgs a, long
     if (grp == 1 && a.t_logits) {
       float q[C], tl[C];
       load_px<C>(a.t_logits, pix, tl);
-      softmax_c<C>(tl, q);
+      if (a.teacher_is_prob) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) q[c] = tl[c];
+      } else {
+        softmax_c<C>(tl, q);
+      }
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         float d = p[c] - q[c];
@@ -220,7 +225,12 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(HpfgLossArgs a, long npix
     if (grp == 1 && a.t_logits) {
       float q[C], tl[C];
       load_px<C>(a.t_logits, pix, tl);
-      softmax_c<C>(tl, q);
+      if (a.teacher_is_prob) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) q[c] = tl[c];
+      } else {
+        softmax_c<C>(tl, q);
+      }
 #pragma unroll
       for (int c = 0; c < C; ++c) dp[c] += wm * (p[c] - q[c]);
     }

@@ -272,6 +272,35 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
   }
 }
 
+// ICT (2022_02_ISBI_ICT-MedSeg_ACDC.py:111-129): per-sample mixes of inputs and of teacher probabilities
+__global__ __launch_bounds__(256) void mix_samples_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ f,
+                                                          float* __restrict__ out, long total, long per) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const float w = f[i / per];
+    out[i] = a[i] * (1.0f - w) + b[i] * w;
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_mix_kernel(const float* __restrict__ t0, const float* __restrict__ t1, const float* __restrict__ f,
+                                                          float* __restrict__ out, long npix, long pix_per_sample, int C) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+    const float w = f[i / pix_per_sample];
+    const float* x0 = t0 + i * C;
+    const float* x1 = t1 + i * C;
+    float m0 = x0[0], m1 = x1[0];
+    for (int c = 1; c < C; ++c) {
+      m0 = fmaxf(m0, x0[c]);
+      m1 = fmaxf(m1, x1[c]);
+    }
+    float s0 = 0.f, s1 = 0.f;
+    for (int c = 0; c < C; ++c) {
+      s0 += expf(x0[c] - m0);
+      s1 += expf(x1[c] - m1);
+    }
+    for (int c = 0; c < C; ++c) out[i * C + c] = expf(x0[c] - m0) / s0 * (1.0f - w) + expf(x1[c] - m1) / s1 * w;
+  }
+}
+
 // CutMix box masks (utils/utils.py:165-173): mask = invert ? 0 : 1, flipped once per box that covers the pixel
 __global__ __launch_bounds__(256) void box_masks_kernel(const int* __restrict__ rects, int n, int nb, int H, int W, int invert,
                                                         float* __restrict__ out) {
@@ -405,6 +434,20 @@ extern "C" int hpfg_augment_batch(const float* img_pool, const uint8_t* lab_pool
   hipLaunchKernelGGL(augment_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, img_pool, lab_pool, samples_dev, tabs_dev, B,
                      H, W, out_img, out_lab);
   return hpfg_launch_status("augment_kernel");
+}
+
+extern "C" int hpfg_mix_samples(const float* a, const float* b, const float* f, float* out, int n, long per_sample, void* stream) {
+  HPFG_ARG_CHECK(a && b && f && out && n > 0 && per_sample > 0, "mix_samples: bad args");
+  hipLaunchKernelGGL(mix_samples_kernel, dim3(grid_for((long)n * per_sample)), dim3(256), 0, (hipStream_t)stream, a, b, f, out, (long)n * per_sample,
+                     per_sample);
+  return hpfg_launch_status("mix_samples_kernel");
+}
+
+extern "C" int hpfg_softmax_mix(const float* t0, const float* t1, const float* f, float* out_prob, int n, int H, int W, int C, void* stream) {
+  HPFG_ARG_CHECK(t0 && t1 && f && out_prob && n > 0 && H > 0 && W > 0 && C >= 1 && C <= 64, "softmax_mix: bad args");
+  hipLaunchKernelGGL(softmax_mix_kernel, dim3(grid_for((long)n * H * W)), dim3(256), 0, (hipStream_t)stream, t0, t1, f, out_prob, (long)n * H * W,
+                     (long)H * W, C);
+  return hpfg_launch_status("softmax_mix_kernel");
 }
 
 extern "C" int hpfg_box_masks(const int* rects, int n, int n_boxes, int H, int W, int invert, float* out, void* stream) {

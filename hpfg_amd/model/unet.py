@@ -261,7 +261,12 @@ class UNet(nn.Module):
             pool.append(eng)
         eng.base_seed = self.dropout_seed
         eng.math = L.MATH_BF16X3 if self.math == "bf16x3" else L.MATH_F32
-        eng.ext_masks = self.external_dropout_masks or {}
+        ext = self.external_dropout_masks
+        if isinstance(ext, (list, tuple)):      # tests: one mask set per forward, consumed in order (several forwards per step)
+            k = getattr(self, "_ext_mask_idx", 0)
+            self._ext_mask_idx = k + 1
+            ext = ext[k % len(ext)] if len(ext) else None
+        eng.ext_masks = ext or {}
         if self.dp is not None and getattr(self.dp, "sync_bn", True):
             eng.world, eng.allreduce = self.dp.world_size, self.dp.allreduce_sum
             eng.force_sync = bool(getattr(self.dp, "force_sync", False))

@@ -220,6 +220,87 @@ class MeanTeacherStep(_StepBase):
         return r
 
 
+def mix_samples(a: torch.Tensor, b: torch.Tensor, f: torch.Tensor) -> torch.Tensor:
+    """a*(1-f[s]) + b*f[s] per sample s (ICT input mix, 2022_02_ISBI_ICT-MedSeg_ACDC.py:116-117)."""
+    a, b, f = a.contiguous(), b.contiguous(), f.reshape(-1).float().contiguous()
+    out = torch.empty_like(a)
+    L.check(L.load().hpfg_mix_samples(L.ptr(a), L.ptr(b), L.ptr(f), L.ptr(out), a.shape[0], a[0].numel(),
+                                      torch.cuda.current_stream(a.device).cuda_stream), "mix_samples")
+    return out
+
+
+def softmax_mix(t0: torch.Tensor, t1: torch.Tensor, f: torch.Tensor) -> torch.Tensor:
+    """softmax(t0)*(1-f[s]) + softmax(t1)*f[s] of two logit tensors [n,C,H,W] -> probabilities [n,C,H,W] (ICT :126-129)."""
+    x0, x1 = _nhwc(t0.detach()), _nhwc(t1.detach())
+    n, H, W, Cc = x0.shape
+    out = torch.empty(n, H, W, Cc, dtype=torch.float32, device=x0.device)
+    L.check(L.load().hpfg_softmax_mix(L.ptr(x0), L.ptr(x1), L.ptr(f.reshape(-1).float().contiguous()), L.ptr(out), n, H, W, Cc,
+                                      torch.cuda.current_stream(x0.device).cuda_stream), "softmax_mix")
+    return out.permute(0, 3, 1, 2)
+
+
+class ICTStep(_StepBase):
+    """Interpolation consistency training (2022_02_ISBI_ICT-MedSeg_ACDC.py:110-143): the student sees
+    [labelled ; mix(u0, u1)], the train-mode teacher sees u0 and u1 separately, and the consistency target is the same mix of the
+    two teacher softmaxes.  Recomposition of the hot-path kernels plus two per-sample mix kernels."""
+
+    def __init__(self, model, ema_model, args, dp=None):
+        super().__init__(next(model.parameters()).device, dp)
+        self.model, self.ema_model, self.args = model, ema_model, args
+        self._attach(model)
+        self._attach(ema_model)
+        self.optimizer = build_optimizer(args=args, model=model)
+        self.lr_scheduler = build_lr_scheduler(args=args, optimizer=self.optimizer)
+        self.optimizer._lr_dev = self.sc.view(S_LR1)
+        self._set_grad_scale(self.optimizer)
+
+    def draw_mix_factors(self, unlabel_bs: int, rng=None) -> torch.Tensor:
+        import numpy as np
+        rng = np.random if rng is None else rng
+        a = float(getattr(self.args, "ict_alpha", 0.2))
+        return torch.tensor(rng.beta(a, a, size=(unlabel_bs // 2, 1, 1, 1)), dtype=torch.float)      # host draw, as the reference (:111)
+
+    def host_scalars(self, cur_itrs, cons_w=None):
+        a = self.args
+        w = a.consistency * sigmoid_rampup(cur_itrs // 150, a.consistency_rampup) if cons_w is None else cons_w
+        h = self.sc.host
+        h[S_LR1] = self._lr(self.optimizer)
+        h[S_ALPHA] = ema_alpha(cur_itrs, a.ema_decay)
+        h[S_COEF_A:S_COEF_A + 5] = torch.tensor([0.5, 0.5, 0.0, 0.0, w])
+        return w
+
+    def device_step(self, label_img, target_label, unlabel_img, mix_factors):
+        nl, nu = label_img.shape[0], unlabel_img.shape[0]
+        u0, u1 = unlabel_img[:nu // 2], unlabel_img[nu // 2:]
+        f = mix_factors.to(label_img.device)
+        x = torch.cat([label_img, mix_samples(u0, u1, f)], 0)
+        with torch.no_grad():
+            t0 = self.ema_model(u0.contiguous())
+            t1 = self.ema_model(u1.contiguous())
+        out = self.model(x)
+        tp = softmax_mix(t0, t1, f)
+        pad = tp.new_zeros(nl, *tp.shape[1:])              # the loss indexes the target like the student batch; the labelled part is unused
+        res = seg_loss(out, target_label, nl, coef=self.sc.view(S_COEF_A, 8), teacher_prob=torch.cat([pad, tp], 0), dp=self.dp)
+        self.optimizer.zero_grad()
+        self._loss_backward(res)
+        self._reduce_grads(self.model)
+        self.optimizer.step(push_lr=False)
+        update_ema_variables(self.model, self.ema_model, self.args.ema_decay, 0, alpha_dev=self.sc.view(S_ALPHA))
+        return {"loss": res[0].detach(), "parts": res.detach(), "logits": out.detach(), "t_prob": tp}
+
+    def after(self):
+        self.lr_scheduler.step()
+
+    def step(self, label_img, target_label, unlabel_img, cur_itrs, mix_factors=None, cons_w=None):
+        if mix_factors is None:
+            mix_factors = self.draw_mix_factors(unlabel_img.shape[0])
+        self.host_scalars(cur_itrs, cons_w)
+        self.sc.push()
+        r = self.device_step(label_img, target_label, unlabel_img, mix_factors)
+        self.after()
+        return r
+
+
 class CPSStep(_StepBase):
     def __init__(self, model1, model2, args, dp=None):
         super().__init__(next(model1.parameters()).device, dp)

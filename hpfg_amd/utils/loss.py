@@ -35,7 +35,7 @@ def _labels_u8(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 class _SegLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, coef, labels0, labels1, t_logits, n_lab, is_prob, dp):
+    def forward(ctx, logits, coef, labels0, labels1, t_logits, n_lab, is_prob, dp, t_is_prob=False):
         lib = L.load()
         if not logits.is_cuda:
             raise RuntimeError("hpfg_amd losses run on the HIP library only (no CPU fallback)")
@@ -55,6 +55,7 @@ class _SegLossFn(torch.autograd.Function):
             dp = None                     # per-rank loss (DDP semantics): no exchange of the partial sums
         a.world = dp.world_size if dp is not None else 1
         a.input_is_prob = 1 if is_prob else 0
+        a.teacher_is_prob = 1 if t_is_prob else 0
         st = torch.cuda.current_stream(dev).cuda_stream
         L.check(lib.hpfg_seg_loss_partials(C.byref(a), st), "seg_loss_partials")
         if dp is not None and (dp.world_size > 1 or dp.force_sync):
@@ -74,20 +75,24 @@ class _SegLossFn(torch.autograd.Function):
         a.dlogits = L.ptr(dl)
         gs = gout[0:1].contiguous()     # d(total)/d(out[0]); the other entries are detached diagnostics
         L.check(lib.hpfg_seg_loss_bwd(C.byref(a), L.ptr(gs), torch.cuda.current_stream(x.device).cuda_stream), "seg_loss_bwd")
-        return dl.permute(0, 3, 1, 2), None, None, None, None, None, None, None
+        return dl.permute(0, 3, 1, 2), None, None, None, None, None, None, None, None
 
 
 def seg_loss(logits: torch.Tensor, labels: Optional[torch.Tensor], n_lab: Optional[int] = None, *,
              coef: torch.Tensor, pseudo: Optional[torch.Tensor] = None, teacher_logits: Optional[torch.Tensor] = None,
-             is_prob: bool = False, dp=None) -> torch.Tensor:
+             is_prob: bool = False, dp=None, teacher_prob: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused loss over logits [N,C,H,W].
 
     coef (device fp32 [8]) = [ce0, dice0, ce1, dice1, mse_w, 0, 0, 0]; images [0,n_lab) use ``labels`` (group 0),
     images [n_lab,N) use ``pseudo`` (group 1) and, if ``teacher_logits`` is given, the MSE between the two softmaxes.
+    ``teacher_prob`` ([N,C,H,W] probabilities, e.g. ICT's mixed teacher prediction) replaces ``teacher_logits`` as the MSE target.
     Returns a device tensor [8] = [total, ce0, dice0, ce1, dice1, mse, 0, 0]; only [0] carries gradient.
     """
     N = logits.shape[0]
     n_lab = N if n_lab is None else int(n_lab)
+    if teacher_prob is not None:
+        assert teacher_logits is None
+        return _SegLossFn.apply(logits, coef, _labels_u8(labels), _labels_u8(pseudo), teacher_prob, n_lab, is_prob, dp, True)
     return _SegLossFn.apply(logits, coef, _labels_u8(labels), _labels_u8(pseudo), teacher_logits, n_lab, is_prob, dp)
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 105
+#define HPFG_VERSION 106
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -170,6 +170,7 @@ typedef struct HpfgLossArgs {
   int32_t N, n_lab, H, W, C;
   int32_t world;            /* data-parallel world size (MSE / CE counts are global after the all-reduce) */
   int32_t input_is_prob;    /* 1: `logits` already holds probabilities (DiceLoss(softmax=False), diceloss.py:178); CE/MSE weights must be 0 */
+  int32_t teacher_is_prob;  /* 1: `t_logits` already holds probabilities (ICT's mixed teacher prediction, 2022_02...ICT...py:126-137) */
 } HpfgLossArgs;
 #define HPFG_LOSS_NSUM 32
 int hpfg_loss_blocks(int N, int H, int W);
@@ -199,6 +200,10 @@ int hpfg_augment_batch(const float* img_pool, const uint8_t* lab_pool, const Hpf
 /* CutMix box masks (utils/utils.py:115-173 BoxMaskGenerator.generate_params): rects int32 [n][n_boxes][y0,y1,x0,x1] (bounds already
  * normalised like Python slices), out float [n][1][H][W] = (invert ? 0 : 1) flipped once per covering box */
 int hpfg_box_masks(const int* rects, int n, int n_boxes, int H, int W, int invert, float* out, void* stream);
+/* per-sample linear mix out[s] = a[s]*(1-f[s]) + b[s]*f[s] (ICT input mix, 2022_02_ISBI_ICT-MedSeg_ACDC.py:111-117) */
+int hpfg_mix_samples(const float* a, const float* b, const float* f, float* out, int n, long per_sample, void* stream);
+/* softmax(t0)*(1-f[s]) + softmax(t1)*f[s] over NHWC logits [n,H,W,C] (ICT mixed teacher prediction, :126-129) */
+int hpfg_softmax_mix(const float* t0, const float* t1, const float* f, float* out_prob, int n, int H, int W, int C, void* stream);
 /* CutMix image blend x1*(1-M)+xu*M (main.py:149) */
 int hpfg_cutmix_blend(const float* a, const float* b, const float* mask, float* out, long n, void* stream);
 

@@ -91,6 +91,30 @@ def mean_teacher_step(st, ema, bufs, xl, yl, xu, lr, cons_w, alpha, momentum=0.9
     return {"loss": float(loss.detach()), "sup": float(sup.detach()), "cons": float(cons.detach()), "logits": out.detach(), "t_logits": t_out, "grads": g}
 
 
+def ict_step(st, ema, bufs, xl, yl, xu, mix, lr, cons_w, alpha, momentum=0.9, weight_decay=1e-4, masks_student=None, masks_t0=None,
+             masks_t1=None):
+    """Interpolation consistency training, 2022_02_ISBI_ICT-MedSeg_ACDC.py:110-143: mix [nu/2,1,1,1] factors; the teacher (train
+    mode) sees the two unlabelled halves separately, the student the labelled batch and their mix."""
+    names = _train_state(st)
+    nl, nu = xl.shape[0], xu.shape[0]
+    u0, u1 = xu[:nu // 2], xu[nu // 2:]
+    mixed = u0 * (1.0 - mix) + u1 * mix
+    out = unet_ref.unet_forward(st, torch.cat([xl, mixed], 0), True, masks_student)
+    soft = torch.softmax(out, 1)
+    with torch.no_grad():
+        e0 = torch.softmax(unet_ref.unet_forward(ema, u0, True, masks_t0), 1)
+        e1 = torch.softmax(unet_ref.unet_forward(ema, u1, True, masks_t1), 1)
+        target = e0 * (1.0 - mix) + e1 * mix
+    sup = losses_ref.med_sup_loss(out[:nl], yl)
+    cons = torch.mean((soft[nl:] - target) ** 2)
+    loss = sup + cons_w * cons
+    g = _grads(loss, st, names)
+    _detach_state(st)
+    sgd_update(st, g, bufs, lr, momentum, weight_decay)
+    ema_update(ema, st, alpha)
+    return {"loss": float(loss.detach()), "sup": float(sup.detach()), "cons": float(cons.detach()), "logits": out.detach(), "target": target}
+
+
 def _grads_joint(loss, states_names):
     """One backward through several networks, like the reference's single loss.backward()."""
     flat = [st[n] for st, names in states_names for n in names]

@@ -9,7 +9,7 @@ import torch
 
 from hpfg_amd import engine as E
 from hpfg_amd.model import UNet, UNet_Plus
-from hpfg_amd.train import CPSStep, HPFGStep, MeanTeacherStep, SupervisedStep
+from hpfg_amd.train import CPSStep, HPFGStep, ICTStep, MeanTeacherStep, SupervisedStep
 from hpfg_amd.utils import AttrDict
 from oracle import losses_ref
 from tests.helpers import maxerr
@@ -89,6 +89,33 @@ def test_mean_teacher_trace(golden_dir, math):
     assert np.abs(np.array(rows) - d["losses"]).max() < TOL, (rows, d["losses"])
     assert maxerr(r["logits"].cpu(), torch.from_numpy(d["student_logits_last"])) < logit_tol(math)
     assert maxerr(r["t_logits"].cpu(), torch.from_numpy(d["teacher_logits_last"])) < logit_tol(math)
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_ict_trace(golden_dir, math):
+    """ICT step against 3 iterations of the reference's own pieces (oracle/make_golden_ict.py)."""
+    d = np.load(f"{golden_dir}/trace_ict.npz")
+    torch.manual_seed(1337)
+    m = UNet(1, 4).to(DEV)
+    m.math = math
+    ema = deepcopy(m)
+    for p in ema.parameters():
+        p.requires_grad = False
+    m.train()
+    ema.train()
+    st = ICTStep(m, ema, _opt_args())
+    xl, yl, xu = (torch.from_numpy(d[k]).to(DEV) for k in ("xl", "yl", "xu"))
+    rows = []
+    for k in range(3):
+        m.external_dropout_masks = _masks(d, f"it{k}_s", 4, 32)
+        ema.external_dropout_masks = [_masks(d, f"it{k}_a", 2, 32), _masks(d, f"it{k}_b", 2, 32)]      # teacher forwards on u0, then u1
+        ema._ext_mask_idx = 0
+        r = st.step(xl, yl, xu, k + 1, mix_factors=torch.from_numpy(d["mixes"][k]), cons_w=float(d["cons_w"]))
+        p = r["parts"].cpu()
+        rows.append([float(r["loss"]), 0.5 * float(p[1]) + 0.5 * float(p[2]), float(p[5])])
+    assert np.abs(np.array(rows) - d["losses"]).max() < TOL, (rows, d["losses"])
+    assert maxerr(r["logits"].cpu(), torch.from_numpy(d["student_logits_last"])) < logit_tol(math)
+    assert maxerr(r["t_prob"].cpu(), torch.from_numpy(d["target_last"])) < TOL
 
 
 @pytest.mark.parametrize("math", ["f32", "bf16x3"])

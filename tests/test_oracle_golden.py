@@ -124,6 +124,21 @@ def test_supervised_and_mean_teacher_traces(golden_dir):
     assert float((r["logits"] - torch.from_numpy(d["student_logits_last"])).abs().max()) < 1e-4
 
 
+def test_ict_trace(golden_dir):
+    d = np.load(f"{golden_dir}/trace_ict.npz")
+    st = unet_ref.init_state(1337, 1, 4)
+    ema, bufs = unet_ref.clone_state(st), {}
+    xl, yl, xu = torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xu"])
+    rows = []
+    for k in range(3):
+        r = steps_ref.ict_step(st, ema, bufs, xl, yl, xu, torch.from_numpy(d["mixes"][k]), laws_ref.medical_lr(k + 1, 0.01, 30000), float(d["cons_w"]),
+                               laws_ref.ema_alpha(k + 1, 0.99), 0.9, 1e-4, _unpack_masks(d, f"it{k}_s", 4, 32), _unpack_masks(d, f"it{k}_a", 2, 32),
+                               _unpack_masks(d, f"it{k}_b", 2, 32))
+        rows.append([r["loss"], r["sup"], r["cons"]])
+    assert np.abs(np.array(rows) - d["losses"]).max() < 2e-5
+    assert float((r["logits"] - torch.from_numpy(d["student_logits_last"])).abs().max()) < 1e-4
+
+
 def test_cps_and_hpfg_traces(golden_dir):
     d = np.load(f"{golden_dir}/trace_cps.npz")
     torch.manual_seed(1337)
