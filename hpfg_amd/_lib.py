@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ = range(7)
 LOSS_NSUM = 32
-VERSION = 106
+VERSION = 107
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -64,7 +64,12 @@ class LossArgs(C.Structure):
     _fields_ = [("logits", C.c_void_p), ("t_logits", C.c_void_p), ("labels0", C.c_void_p), ("labels1", C.c_void_p),
                 ("coef", C.c_void_p), ("partials", C.c_void_p), ("sums", C.c_void_p), ("out", C.c_void_p),
                 ("dlogits", C.c_void_p), ("N", C.c_int32), ("n_lab", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("C", C.c_int32), ("world", C.c_int32), ("input_is_prob", C.c_int32), ("teacher_is_prob", C.c_int32)]
+                ("C", C.c_int32), ("world", C.c_int32), ("input_is_prob", C.c_int32), ("teacher_is_prob", C.c_int32),
+                ("t_unlab_only", C.c_int32), ("reserved0", C.c_int32), ("cons_mask", C.c_void_p)]
+
+
+class PredBlocks(C.Structure):
+    _fields_ = [("p", C.c_void_p * 8), ("n_blocks", C.c_int32), ("per_block", C.c_int32)]
 
 
 _i, _l, _f, _d, _p, _u32 = C.c_int, C.c_long, C.c_float, C.c_double, C.c_void_p, C.c_uint32
@@ -99,6 +104,8 @@ PROTOTYPES = {
     "hpfg_confusion_counts": (_i, [_p, _p, _l, _i, _p, _p]),
     "hpfg_box_masks": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "hpfg_augment_batch": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "hpfg_noise_add": (_i, [_p, _p, _p, _l, _l, _f, _f, _f, _p]),
+    "hpfg_uncertainty_mask": (_i, [C.POINTER(PredBlocks), _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "hpfg_mix_samples": (_i, [_p, _p, _p, _p, _i, _l, _p]),
     "hpfg_softmax_mix": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "hpfg_pool_scatter_add": (_i, [C.POINTER(Act), _p, _i, _p, _i, _i, _i, _i, _p]),

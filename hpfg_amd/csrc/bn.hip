@@ -27,40 +27,77 @@ __device__ inline double block_sum(double v, double* sh) {
   return t;
 }
 
+// Both per-channel sums of a finalize kernel in ONE reduction round (these kernels are pure latency: a handful of dependent
+// steps on the critical path of every BatchNorm layer, so the loads are issued together and there is a single barrier).
+__device__ inline void block_sum2(double& a, double& b, double* sh8) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b += __shfl_xor(b, o);
+  }
+  if ((tid & 63) == 0) {
+    sh8[(tid >> 6) * 2] = a;
+    sh8[(tid >> 6) * 2 + 1] = b;
+  }
+  __syncthreads();
+  a = (sh8[0] + sh8[2]) + (sh8[4] + sh8[6]);
+  b = (sh8[1] + sh8[3]) + (sh8[5] + sh8[7]);
+}
+
+// Partial rows [nblk][2][C] -> the two fp64 sums of channel c; up to 4 rows per thread are requested before any is consumed.
+__device__ inline void sum_partials(const float* __restrict__ partials, int nblk, int C, int c, double& a, double& b, double* sh8) {
+  a = 0.0;
+  b = 0.0;
+  for (int i0 = threadIdx.x; i0 < nblk; i0 += 1024) {
+    float x[4], y[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * 256;
+      const bool ok = i < nblk;
+      const long o = (long)(ok ? i : i0) * 2 * C + c;
+      x[k] = ok ? partials[o] : 0.f;
+      y[k] = ok ? partials[o + C] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a += (double)x[k];
+      b += (double)y[k];
+    }
+  }
+  block_sum2(a, b, sh8);
+}
+
 // grid = C blocks; partials [nblk][2][C]
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __restrict__ partials, int nblk, const double* __restrict__ sums,
                                                               double count, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* running_mean, float* running_var, float momentum, float eps,
                                                               float* __restrict__ bn, int C) {
-  __shared__ double sh[4];
+  __shared__ double sh[8];
   const int c = blockIdx.x;
+  const float ga = gamma[c], be = beta[c];                       // requested up front: off the dependent chain below
+  const float rm = running_mean ? running_mean[c] : 0.f, rv = running_mean ? running_var[c] : 0.f;
   double s1, s2;
   if (sums) {
     s1 = sums[c];
     s2 = sums[C + c];
   } else {
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
-      a += (double)partials[((long)i * 2 + 0) * C + c];
-      b += (double)partials[((long)i * 2 + 1) * C + c];
-    }
-    s1 = block_sum(a, sh);
-    s2 = block_sum(b, sh);
+    sum_partials(partials, nblk, C, c, s1, s2, sh);
   }
   if (threadIdx.x == 0) {
     double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
     double rstd = 1.0 / sqrt(var + (double)eps);
-    float scale = (float)((double)gamma[c] * rstd);
+    float scale = (float)((double)ga * rstd);
     bn[HPFG_BN_MEAN * C + c] = (float)mean;
     bn[HPFG_BN_RSTD * C + c] = (float)rstd;
     bn[HPFG_BN_SCALE * C + c] = scale;
-    bn[HPFG_BN_SHIFT * C + c] = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
+    bn[HPFG_BN_SHIFT * C + c] = (float)((double)be - mean * (double)ga * rstd);
     if (running_mean) {
       double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
-      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+      running_mean[c] = (float)((1.0 - momentum) * (double)rm + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * (double)rv + momentum * unb);
     }
   }
 }
@@ -135,24 +172,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(HpfgAct s, long npix
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, const double* __restrict__ sums,
                                                               double count, const float* __restrict__ gamma, float* __restrict__ bn,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
-  __shared__ double sh[4];
+  __shared__ double sh[8];
   const int c = blockIdx.x;
+  const double mean = bn[HPFG_BN_MEAN * C + c], rstd = bn[HPFG_BN_RSTD * C + c], ga = gamma[c];
   double sg, sgx;
   if (sums) {
     sg = sums[c];
     sgx = sums[C + c];
   } else {
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
-      a += (double)partials[((long)i * 2 + 0) * C + c];
-      b += (double)partials[((long)i * 2 + 1) * C + c];
-    }
-    sg = block_sum(a, sh);
-    sgx = block_sum(b, sh);
+    sum_partials(partials, nblk, C, c, sg, sgx, sh);
   }
   if (threadIdx.x == 0) {
     double m1 = sg / count, m2 = sgx / count;
-    double mean = bn[HPFG_BN_MEAN * C + c], rstd = bn[HPFG_BN_RSTD * C + c], ga = gamma[c];
     bn[HPFG_BN_K1 * C + c] = (float)(ga * rstd);
     bn[HPFG_BN_K2 * C + c] = (float)(-ga * rstd * rstd * m2);
     bn[HPFG_BN_K3 * C + c] = (float)(ga * rstd * (mean * rstd * m2 - m1));

@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int NS = HPFG_LOSS_NSUM;
-// sums layout: 0 nll0, 1 cnt0, 2 nll1, 3 cnt1, 4 mse, 8+c I0, 12+c Z0, 16+c Y0, 20+c I1, 24+c Z1, 28+c Y1   (C <= 4)
+// sums layout: 0 nll0, 1 cnt0, 2 nll1, 3 cnt1, 4 mse (masked: sum mask*d^2), 5 sum mask, 8+c I0, 12+c Z0, 16+c Y0, 20+c I1, 24+c Z1, 28+c Y1   (C <= 4)
 constexpr int PIX_PER_BLOCK = 1024;
 constexpr float SMOOTH = 1e-5f;
 
@@ -52,7 +52,7 @@ template <int C>
 __global__ __launch_bounds__(256) void loss_partials_kernel(HpfgLossArgs a, long npix_img) {
   __shared__ float red[4][NS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float nll[2] = {0.f, 0.f}, cnt[2] = {0.f, 0.f}, mse = 0.f;
+  float nll[2] = {0.f, 0.f}, cnt[2] = {0.f, 0.f}, mse = 0.f, msk = 0.f;
   float I[2][4], Z[2][4], Y[2][4];
 #pragma unroll
   for (int g = 0; g < 2; ++g)
@@ -101,24 +101,29 @@ __global__ __launch_bounds__(256) void loss_partials_kernel(HpfgLossArgs a, long
     }
     if (grp == 1 && a.t_logits) {
       float q[C], tl[C];
-      load_px<C>(a.t_logits, pix, tl);
+      const long upix = pix - (long)a.n_lab * npix_img;
+      load_px<C>(a.t_logits, a.t_unlab_only ? upix : pix, tl);
       if (a.teacher_is_prob) {
 #pragma unroll
         for (int c = 0; c < C; ++c) q[c] = tl[c];
       } else {
         softmax_c<C>(tl, q);
       }
+      const float w = a.cons_mask ? a.cons_mask[upix] : 1.f;
+      float dd = 0.f;
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         float d = p[c] - q[c];
-        mse += d * d;
+        dd += d * d;
       }
+      mse += w * dd;
+      msk += w;
     }
   }
   float s[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) s[i] = 0.f;
-  s[0] = nll[0]; s[1] = cnt[0]; s[2] = nll[1]; s[3] = cnt[1]; s[4] = mse;
+  s[0] = nll[0]; s[1] = cnt[0]; s[2] = nll[1]; s[3] = cnt[1]; s[4] = mse; s[5] = msk;
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     s[8 + c] = I[0][c]; s[12 + c] = Z[0][c]; s[16 + c] = Y[0][c];
@@ -162,7 +167,7 @@ __global__ void loss_finalize_kernel(HpfgLossArgs a) {
   float d0 = a.labels0 && a.n_lab > 0 ? dice_of(s, 8, C) : 0.f;
   float d1 = a.labels1 && a.n_lab < a.N ? dice_of(s, 20, C) : 0.f;
   float cnt = (float)((double)(a.N - a.n_lab) * a.H * a.W * C * a.world);
-  float mse = (a.t_logits && cnt > 0.f) ? s[4] / cnt : 0.f;
+  float mse = (a.t_logits && cnt > 0.f) ? (a.cons_mask ? s[4] / (2.f * s[5] + 1e-16f) : s[4] / cnt) : 0.f;
   const float* k = a.coef;
   a.out[0] = k[0] * ce0 + k[1] * d0 + k[2] * ce1 + k[3] * d1 + k[4] * mse;
   a.out[1] = ce0;
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(HpfgLossArgs a, long npix
       dB[g][c] = 2.f * wd * num / (den * den);
     }
   }
-  const float wm = cnt_mse > 0.f ? k[4] * 2.f / cnt_mse : 0.f;
+  const float wm = cnt_mse > 0.f ? k[4] * 2.f / (a.cons_mask ? 2.f * s[5] + 1e-16f : cnt_mse) : 0.f;
   for (long pix = blockIdx.x * 256L + threadIdx.x; pix < total; pix += (long)gridDim.x * 256) {
     const int n = (int)(pix / npix_img);
     float l[C], p[C], dp[C];
@@ -224,15 +229,17 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(HpfgLossArgs a, long npix
     }
     if (grp == 1 && a.t_logits) {
       float q[C], tl[C];
-      load_px<C>(a.t_logits, pix, tl);
+      const long upix = pix - (long)a.n_lab * npix_img;
+      load_px<C>(a.t_logits, a.t_unlab_only ? upix : pix, tl);
       if (a.teacher_is_prob) {
 #pragma unroll
         for (int c = 0; c < C; ++c) q[c] = tl[c];
       } else {
         softmax_c<C>(tl, q);
       }
+      const float w = a.cons_mask ? wm * a.cons_mask[upix] : wm;
 #pragma unroll
-      for (int c = 0; c < C; ++c) dp[c] += wm * (p[c] - q[c]);
+      for (int c = 0; c < C; ++c) dp[c] += w * (p[c] - q[c]);
     }
     float dot = 0.f;
 #pragma unroll

@@ -301,6 +301,59 @@ __global__ __launch_bounds__(256) void softmax_mix_kernel(const float* __restric
   }
 }
 
+// UAMT (2019_07_MICCAI_Uncertainty_Aware_ACDC.py:130-147): input noise for the teacher passes, and the uncertainty mask
+// out[i] = x[i % n_src] + clamp(noise[i] * scale, lo, hi)   (unlabeled.repeat(2,1,1,1) + clamp(randn*0.1, -0.2, 0.2), :130,142)
+__global__ __launch_bounds__(256) void noise_add_kernel(const float* __restrict__ x, const float* __restrict__ noise, float* __restrict__ out,
+                                                        long n_src, long n_out, float scale, float lo, float hi) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n_out; i += (long)gridDim.x * 256) {
+    const float v = fminf(fmaxf(noise[i] * scale, lo), hi);
+    out[i] = x[i % n_src] + v;
+  }
+}
+
+// T stochastic teacher predictions of the same S images (image g = t*S + s lives in block g / per_block): mean over t of the
+// softmax, entropy  u = -sum_c p log(p + 1e-6)  (:147-151), mask = u < *threshold (:162-163)
+__global__ __launch_bounds__(256) void uncertainty_mask_kernel(HpfgPredBlocks pb, int T, int S, long npix_img, int C,
+                                                               const float* __restrict__ threshold, float* __restrict__ mask,
+                                                               float* __restrict__ uncertainty) {
+  const float thr = *threshold;
+  const long total = (long)S * npix_img;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int s = (int)(i / npix_img);
+    const long px = i - (long)s * npix_img;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const int g = t * S + s;
+      const float* l = pb.p[g / pb.per_block] + ((long)(g % pb.per_block) * npix_img + px) * C;
+      float v[8], m = l[0];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = c < C ? l[c] : 0.f;
+#pragma unroll
+      for (int c = 1; c < 8; ++c) m = c < C ? fmaxf(m, v[c]) : m;
+      float se = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        v[c] = c < C ? expf(v[c] - m) : 0.f;
+        se += v[c];
+      }
+      const float inv = 1.f / se;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] += v[c] * inv;
+    }
+    float u = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float pm = acc[c] / (float)T;
+      u += c < C ? pm * logf(pm + 1e-6f) : 0.f;
+    }
+    u = -u;
+    mask[i] = u < thr ? 1.f : 0.f;
+    if (uncertainty) uncertainty[i] = u;
+  }
+}
+
 // CutMix box masks (utils/utils.py:165-173): mask = invert ? 0 : 1, flipped once per box that covers the pixel
 __global__ __launch_bounds__(256) void box_masks_kernel(const int* __restrict__ rects, int n, int nb, int H, int W, int invert,
                                                         float* __restrict__ out) {
@@ -448,6 +501,24 @@ extern "C" int hpfg_softmax_mix(const float* t0, const float* t1, const float* f
   hipLaunchKernelGGL(softmax_mix_kernel, dim3(grid_for((long)n * H * W)), dim3(256), 0, (hipStream_t)stream, t0, t1, f, out_prob, (long)n * H * W,
                      (long)H * W, C);
   return hpfg_launch_status("softmax_mix_kernel");
+}
+
+extern "C" int hpfg_noise_add(const float* x, const float* noise, float* out, long n_src, long n_out, float scale, float lo, float hi,
+                              void* stream) {
+  HPFG_ARG_CHECK(x && noise && out && n_src > 0 && n_out > 0 && lo <= hi, "noise_add: bad args");
+  hipLaunchKernelGGL(noise_add_kernel, dim3(grid_for(n_out)), dim3(256), 0, (hipStream_t)stream, x, noise, out, n_src, n_out, scale, lo, hi);
+  return hpfg_launch_status("noise_add_kernel");
+}
+
+extern "C" int hpfg_uncertainty_mask(const HpfgPredBlocks* pb, int T, int S, int H, int W, int C, const float* threshold_dev, float* mask,
+                                     float* uncertainty, void* stream) {
+  HPFG_ARG_CHECK(pb && threshold_dev && mask && T > 0 && S > 0 && H > 0 && W > 0 && C >= 1 && C <= 8, "uncertainty_mask: bad args (C <= 8)");
+  HPFG_ARG_CHECK(pb->n_blocks >= 1 && pb->n_blocks <= 8 && pb->per_block > 0 && (long)pb->n_blocks * pb->per_block == (long)T * S,
+                 "uncertainty_mask: %d blocks of %d images do not hold T*S = %d*%d predictions", pb->n_blocks, pb->per_block, T, S);
+  for (int i = 0; i < pb->n_blocks; ++i) HPFG_ARG_CHECK(pb->p[i], "uncertainty_mask: block %d is NULL", i);
+  hipLaunchKernelGGL(uncertainty_mask_kernel, dim3(grid_for((long)S * H * W)), dim3(256), 0, (hipStream_t)stream, *pb, T, S, (long)H * W, C,
+                     threshold_dev, mask, uncertainty);
+  return hpfg_launch_status("uncertainty_mask_kernel");
 }
 
 extern "C" int hpfg_box_masks(const int* rects, int n, int n_boxes, int H, int W, int invert, float* out, void* stream) {

@@ -29,7 +29,7 @@ from .utils import (BoxMaskGenerator, build_lr_scheduler, build_optimizer, ema_a
 from .utils.loss import _nhwc
 
 # layout of the per-step scalar block (device fp32 [32])
-S_LR1, S_LR2, S_ALPHA, S_COEF_A, S_COEF_B = 0, 1, 2, 8, 16
+S_LR1, S_LR2, S_ALPHA, S_THRESH, S_COEF_A, S_COEF_B = 0, 1, 2, 3, 8, 16
 
 
 class StepScalars:
@@ -279,8 +279,7 @@ class ICTStep(_StepBase):
             t1 = self.ema_model(u1.contiguous())
         out = self.model(x)
         tp = softmax_mix(t0, t1, f)
-        pad = tp.new_zeros(nl, *tp.shape[1:])              # the loss indexes the target like the student batch; the labelled part is unused
-        res = seg_loss(out, target_label, nl, coef=self.sc.view(S_COEF_A, 8), teacher_prob=torch.cat([pad, tp], 0), dp=self.dp)
+        res = seg_loss(out, target_label, nl, coef=self.sc.view(S_COEF_A, 8), teacher_prob=tp, dp=self.dp)
         self.optimizer.zero_grad()
         self._loss_backward(res)
         self._reduce_grads(self.model)
@@ -297,6 +296,100 @@ class ICTStep(_StepBase):
         self.host_scalars(cur_itrs, cons_w)
         self.sc.push()
         r = self.device_step(label_img, target_label, unlabel_img, mix_factors)
+        self.after()
+        return r
+
+
+def noise_add(x: torch.Tensor, noise: torch.Tensor, scale: float = 0.1, lo: float = -0.2, hi: float = 0.2) -> torch.Tensor:
+    """x.repeat(k,1,1,1) + clamp(noise*scale, lo, hi) with k = noise.shape[0] // x.shape[0] (UAMT teacher inputs,
+    2019_07_MICCAI_Uncertainty_Aware_ACDC.py:130-131,137-142)."""
+    x, noise = x.contiguous(), noise.float().contiguous()
+    if noise.numel() % x.numel():
+        raise ValueError("noise must hold a whole number of copies of x")
+    out = torch.empty_like(noise)
+    L.check(L.load().hpfg_noise_add(L.ptr(x), L.ptr(noise), L.ptr(out), x.numel(), noise.numel(), scale, lo, hi,
+                                    torch.cuda.current_stream(x.device).cuda_stream), "noise_add")
+    return out
+
+
+def uncertainty_mask(pred_blocks, n_images: int, threshold_dev: torch.Tensor, want_uncertainty: bool = False):
+    """Entropy mask of UAMT (:144-151,162-163).  pred_blocks: teacher logits [k*n_images,C,H,W] each, stacked in the order the
+    reference fills `preds`; prediction t of image s is row t*n_images + s.  Returns mask [n_images,1,H,W] (and the entropy)."""
+    xs = [_nhwc(b.detach().float()) for b in pred_blocks]
+    per, H, W, Cc = xs[0].shape
+    if any(tuple(x.shape) != (per, H, W, Cc) for x in xs) or (len(xs) * per) % n_images:
+        raise ValueError("prediction blocks must have one shape and hold T*n_images predictions")
+    T = len(xs) * per // n_images
+    pb = L.PredBlocks()
+    for i, x in enumerate(xs):
+        pb.p[i] = x.data_ptr()
+    pb.n_blocks, pb.per_block = len(xs), per
+    dev = xs[0].device
+    mask = torch.empty(n_images, 1, H, W, dtype=torch.float32, device=dev)
+    unc = torch.empty(n_images, 1, H, W, dtype=torch.float32, device=dev) if want_uncertainty else None
+    L.check(L.load().hpfg_uncertainty_mask(C.byref(pb), T, n_images, H, W, Cc, L.ptr(threshold_dev), L.ptr(mask), L.ptr(unc),
+                                           torch.cuda.current_stream(dev).cuda_stream), "uncertainty_mask")
+    return (mask, unc) if want_uncertainty else mask
+
+
+class UAMTStep(_StepBase):
+    """Uncertainty-aware Mean Teacher (2019_07_MICCAI_Uncertainty_Aware_ACDC.py:110-170): student forward on
+    [labelled ; unlabelled], one noisy teacher forward for the consistency target, T=8 further noisy teacher predictions
+    (T/2 forwards of the doubled unlabelled batch, all in train mode like the reference), entropy of their mean softmax -> mask,
+    masked softmax-MSE + 0.5*(CE + Dice), SGD, EMA.  Recomposition of the hot-path kernels plus noise / entropy-mask kernels."""
+
+    T = 8
+
+    def __init__(self, model, ema_model, args, dp=None):
+        super().__init__(next(model.parameters()).device, dp)
+        self.model, self.ema_model, self.args = model, ema_model, args
+        self._attach(model)
+        self._attach(ema_model)
+        self.optimizer = build_optimizer(args=args, model=model)
+        self.lr_scheduler = build_lr_scheduler(args=args, optimizer=self.optimizer)
+        self.optimizer._lr_dev = self.sc.view(S_LR1)
+        self._set_grad_scale(self.optimizer)
+
+    def host_scalars(self, cur_itrs, cons_w=None):
+        import math
+        a = self.args
+        w = a.consistency * sigmoid_rampup(cur_itrs // 150, a.consistency_rampup) if cons_w is None else cons_w
+        h = self.sc.host
+        h[S_LR1] = self._lr(self.optimizer)
+        h[S_ALPHA] = ema_alpha(cur_itrs, a.ema_decay)
+        h[S_THRESH] = (0.75 + 0.25 * sigmoid_rampup(cur_itrs, a.total_itrs)) * math.log(2)          # :162
+        h[S_COEF_A:S_COEF_A + 5] = torch.tensor([0.5, 0.5, 0.0, 0.0, w])
+        return w
+
+    def draw_noise(self, unlabel_img):
+        """The reference's draws, in its order (:130, :142): one [Nu] field, then T/2 fields of [2*Nu] (torch device generator)."""
+        n0 = torch.randn_like(unlabel_img)
+        rest = [torch.randn(2 * unlabel_img.shape[0], *unlabel_img.shape[1:], device=unlabel_img.device) for _ in range(self.T // 2)]
+        return n0, rest
+
+    def device_step(self, label_img, target_label, unlabel_img, noise0, noises):
+        nl, nu = label_img.shape[0], unlabel_img.shape[0]
+        out = self.model(torch.cat([label_img, unlabel_img], 0))
+        with torch.no_grad():
+            ema_out = self.ema_model(noise_add(unlabel_img, noise0))
+            preds = [self.ema_model(noise_add(unlabel_img, nz)) for nz in noises]
+        mask = uncertainty_mask(preds, nu, self.sc.view(S_THRESH))
+        res = seg_loss(out, target_label, nl, coef=self.sc.view(S_COEF_A, 8), teacher_logits=ema_out, cons_mask=mask, dp=self.dp)
+        self.optimizer.zero_grad()
+        self._loss_backward(res)
+        self._reduce_grads(self.model)
+        self.optimizer.step(push_lr=False)
+        update_ema_variables(self.model, self.ema_model, self.args.ema_decay, 0, alpha_dev=self.sc.view(S_ALPHA))
+        return {"loss": res[0].detach(), "parts": res.detach(), "logits": out.detach(), "mask": mask, "t_logits": ema_out.detach()}
+
+    def after(self):
+        self.lr_scheduler.step()
+
+    def step(self, label_img, target_label, unlabel_img, cur_itrs, noise=None, cons_w=None):
+        n0, rest = self.draw_noise(unlabel_img) if noise is None else noise
+        self.host_scalars(cur_itrs, cons_w)
+        self.sc.push()
+        r = self.device_step(label_img, target_label, unlabel_img, n0, rest)
         self.after()
         return r
 

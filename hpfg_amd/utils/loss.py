@@ -35,7 +35,7 @@ def _labels_u8(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 class _SegLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, coef, labels0, labels1, t_logits, n_lab, is_prob, dp, t_is_prob=False):
+    def forward(ctx, logits, coef, labels0, labels1, t_logits, n_lab, is_prob, dp, t_is_prob=False, cons_mask=None):
         lib = L.load()
         if not logits.is_cuda:
             raise RuntimeError("hpfg_amd losses run on the HIP library only (no CPU fallback)")
@@ -56,12 +56,23 @@ class _SegLossFn(torch.autograd.Function):
         a.world = dp.world_size if dp is not None else 1
         a.input_is_prob = 1 if is_prob else 0
         a.teacher_is_prob = 1 if t_is_prob else 0
+        if t is not None:
+            if t.shape[0] == N - n_lab and n_lab > 0:
+                a.t_unlab_only = 1
+            elif t.shape[0] != N:
+                raise ValueError(f"consistency target has {t.shape[0]} images; expected {N} (whole batch) or {N - n_lab} (unlabelled part)")
+        cm = None
+        if cons_mask is not None:
+            cm = cons_mask.float().reshape(-1).contiguous()
+            if t is None or cm.numel() != (N - n_lab) * H * W:
+                raise ValueError("cons_mask needs a consistency target and one weight per unlabelled pixel")
+            a.cons_mask = L.ptr(cm)
         st = torch.cuda.current_stream(dev).cuda_stream
         L.check(lib.hpfg_seg_loss_partials(C.byref(a), st), "seg_loss_partials")
         if dp is not None and (dp.world_size > 1 or dp.force_sync):
             dp.allreduce_sum(sums)
         L.check(lib.hpfg_seg_loss_finalize(C.byref(a), st), "seg_loss_finalize")
-        ctx.args, ctx.keep = a, (x, t, labels0, labels1, coef, sums)
+        ctx.args, ctx.keep = a, (x, t, labels0, labels1, coef, sums, cm)
         ctx.shape = (N, H, W, Cc)
         return out
 
@@ -75,25 +86,28 @@ class _SegLossFn(torch.autograd.Function):
         a.dlogits = L.ptr(dl)
         gs = gout[0:1].contiguous()     # d(total)/d(out[0]); the other entries are detached diagnostics
         L.check(lib.hpfg_seg_loss_bwd(C.byref(a), L.ptr(gs), torch.cuda.current_stream(x.device).cuda_stream), "seg_loss_bwd")
-        return dl.permute(0, 3, 1, 2), None, None, None, None, None, None, None, None
+        return dl.permute(0, 3, 1, 2), None, None, None, None, None, None, None, None, None
 
 
 def seg_loss(logits: torch.Tensor, labels: Optional[torch.Tensor], n_lab: Optional[int] = None, *,
              coef: torch.Tensor, pseudo: Optional[torch.Tensor] = None, teacher_logits: Optional[torch.Tensor] = None,
-             is_prob: bool = False, dp=None, teacher_prob: Optional[torch.Tensor] = None) -> torch.Tensor:
+             is_prob: bool = False, dp=None, teacher_prob: Optional[torch.Tensor] = None,
+             cons_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused loss over logits [N,C,H,W].
 
     coef (device fp32 [8]) = [ce0, dice0, ce1, dice1, mse_w, 0, 0, 0]; images [0,n_lab) use ``labels`` (group 0),
     images [n_lab,N) use ``pseudo`` (group 1) and, if ``teacher_logits`` is given, the MSE between the two softmaxes.
-    ``teacher_prob`` ([N,C,H,W] probabilities, e.g. ICT's mixed teacher prediction) replaces ``teacher_logits`` as the MSE target.
+    ``teacher_prob`` (probabilities, e.g. ICT's mixed teacher prediction) replaces ``teacher_logits`` as the MSE target.  Either
+    target covers the whole batch [N,...] or just the unlabelled images [N-n_lab,...].  ``cons_mask`` ([N-n_lab,1,H,W] 0/1) turns
+    the mean into UAMT's masked form  sum(mask*d^2) / (2*sum(mask) + 1e-16)  (2019_07_MICCAI_Uncertainty_Aware_ACDC.py:160-164).
     Returns a device tensor [8] = [total, ce0, dice0, ce1, dice1, mse, 0, 0]; only [0] carries gradient.
     """
     N = logits.shape[0]
     n_lab = N if n_lab is None else int(n_lab)
     if teacher_prob is not None:
         assert teacher_logits is None
-        return _SegLossFn.apply(logits, coef, _labels_u8(labels), _labels_u8(pseudo), teacher_prob, n_lab, is_prob, dp, True)
-    return _SegLossFn.apply(logits, coef, _labels_u8(labels), _labels_u8(pseudo), teacher_logits, n_lab, is_prob, dp)
+        return _SegLossFn.apply(logits, coef, _labels_u8(labels), _labels_u8(pseudo), teacher_prob, n_lab, is_prob, dp, True, cons_mask)
+    return _SegLossFn.apply(logits, coef, _labels_u8(labels), _labels_u8(pseudo), teacher_logits, n_lab, is_prob, dp, False, cons_mask)
 
 
 def _coef(dev, vals: Sequence[float]) -> torch.Tensor:

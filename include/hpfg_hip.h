@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 106
+#define HPFG_VERSION 107
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -171,6 +171,10 @@ typedef struct HpfgLossArgs {
   int32_t world;            /* data-parallel world size (MSE / CE counts are global after the all-reduce) */
   int32_t input_is_prob;    /* 1: `logits` already holds probabilities (DiceLoss(softmax=False), diceloss.py:178); CE/MSE weights must be 0 */
   int32_t teacher_is_prob;  /* 1: `t_logits` already holds probabilities (ICT's mixed teacher prediction, 2022_02...ICT...py:126-137) */
+  int32_t t_unlab_only;     /* 1: `t_logits` covers images [n_lab,N) only; 0: it is indexed like `logits` (all N images) */
+  int32_t reserved0;
+  const float* cons_mask;   /* [N-n_lab][H][W] 0/1 weights of the consistency term, or NULL.  With a mask the term is
+                               sum(mask * d^2) / (2*sum(mask) + 1e-16)  (UAMT, 2019_07...Uncertainty_Aware...py:160-164) instead of the mean */
 } HpfgLossArgs;
 #define HPFG_LOSS_NSUM 32
 int hpfg_loss_blocks(int N, int H, int W);
@@ -204,6 +208,16 @@ int hpfg_box_masks(const int* rects, int n, int n_boxes, int H, int W, int inver
 int hpfg_mix_samples(const float* a, const float* b, const float* f, float* out, int n, long per_sample, void* stream);
 /* softmax(t0)*(1-f[s]) + softmax(t1)*f[s] over NHWC logits [n,H,W,C] (ICT mixed teacher prediction, :126-129) */
 int hpfg_softmax_mix(const float* t0, const float* t1, const float* f, float* out_prob, int n, int H, int W, int C, void* stream);
+/* UAMT teacher-input noise (2019_07_MICCAI_Uncertainty_Aware_ACDC.py:130,142): out[i] = x[i % n_src] + clamp(noise[i]*scale, lo, hi) */
+int hpfg_noise_add(const float* x, const float* noise, float* out, long n_src, long n_out, float scale, float lo, float hi, void* stream);
+/* UAMT uncertainty mask (:147-151,162-163): T stochastic teacher predictions (NHWC logits) of the same S images, prediction
+ * g = t*S + s stored in block g / per_block; mask[s,h,w] = (-sum_c pm*log(pm + 1e-6) < *threshold_dev), pm = mean_t softmax */
+typedef struct HpfgPredBlocks {
+  const float* p[8];
+  int32_t n_blocks, per_block;
+} HpfgPredBlocks;
+int hpfg_uncertainty_mask(const HpfgPredBlocks* pb, int T, int S, int H, int W, int C, const float* threshold_dev, float* mask /* [S,H,W] */,
+                          float* uncertainty /* [S,H,W] or NULL */, void* stream);
 /* CutMix image blend x1*(1-M)+xu*M (main.py:149) */
 int hpfg_cutmix_blend(const float* a, const float* b, const float* mask, float* out, long n, void* stream);
 

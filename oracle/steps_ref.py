@@ -115,6 +115,35 @@ def ict_step(st, ema, bufs, xl, yl, xu, mix, lr, cons_w, alpha, momentum=0.9, we
     return {"loss": float(loss.detach()), "sup": float(sup.detach()), "cons": float(cons.detach()), "logits": out.detach(), "target": target}
 
 
+def uamt_step(st, ema, bufs, xl, yl, xu, noise0, noises, threshold, lr, cons_w, alpha, momentum=0.9, weight_decay=1e-4,
+              masks_student=None, masks_teacher=None):
+    """Uncertainty-aware Mean Teacher, 2019_07_MICCAI_Uncertainty_Aware_ACDC.py:124-170.  noise0 [nu,...] and noises (T/2 fields of
+    [2*nu,...]) are the raw normal draws of :130 / :142; masks_teacher lists the dropout masks of the 1 + T/2 teacher forwards."""
+    names = _train_state(st)
+    nl, nu = xl.shape[0], xu.shape[0]
+    mt = masks_teacher or [None] * (1 + len(noises))
+    out = unet_ref.unet_forward(st, torch.cat([xl, xu], 0), True, masks_student)
+    soft = torch.softmax(out, 1)
+    with torch.no_grad():
+        ema_out = unet_ref.unet_forward(ema, xu + torch.clamp(noise0 * 0.1, -0.2, 0.2), True, mt[0])
+        xr = xu.repeat(2, 1, 1, 1)
+        preds = torch.cat([unet_ref.unet_forward(ema, xr + torch.clamp(nz * 0.1, -0.2, 0.2), True, mt[1 + i]) for i, nz in enumerate(noises)], 0)
+        T = preds.shape[0] // nu
+        pm = torch.softmax(preds, 1).reshape(T, nu, *preds.shape[1:]).mean(0)
+        unc = -1.0 * torch.sum(pm * torch.log(pm + 1e-6), dim=1, keepdim=True)
+    sup = losses_ref.med_sup_loss(out[:nl], yl)
+    dist = (soft[nl:] - torch.softmax(ema_out, 1)) ** 2
+    mask = (unc < threshold).float()
+    cons = torch.sum(mask * dist) / (2 * torch.sum(mask) + 1e-16)
+    loss = sup + cons_w * cons
+    g = _grads(loss, st, names)
+    _detach_state(st)
+    sgd_update(st, g, bufs, lr, momentum, weight_decay)
+    ema_update(ema, st, alpha)
+    return {"loss": float(loss.detach()), "sup": float(sup.detach()), "cons": float(cons.detach()), "logits": out.detach(), "mask": mask,
+            "uncertainty": unc, "t_logits": ema_out}
+
+
 def _grads_joint(loss, states_names):
     """One backward through several networks, like the reference's single loss.backward()."""
     flat = [st[n] for st, names in states_names for n in names]

@@ -9,7 +9,7 @@ import torch
 
 from hpfg_amd import engine as E
 from hpfg_amd.model import UNet, UNet_Plus
-from hpfg_amd.train import CPSStep, HPFGStep, ICTStep, MeanTeacherStep, SupervisedStep
+from hpfg_amd.train import CPSStep, HPFGStep, ICTStep, MeanTeacherStep, SupervisedStep, UAMTStep, noise_add, uncertainty_mask
 from hpfg_amd.utils import AttrDict
 from oracle import losses_ref
 from tests.helpers import maxerr
@@ -116,6 +116,75 @@ def test_ict_trace(golden_dir, math):
     assert np.abs(np.array(rows) - d["losses"]).max() < TOL, (rows, d["losses"])
     assert maxerr(r["logits"].cpu(), torch.from_numpy(d["student_logits_last"])) < logit_tol(math)
     assert maxerr(r["t_prob"].cpu(), torch.from_numpy(d["target_last"])) < TOL
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_uamt_trace(golden_dir, math):
+    """UAMT step against 2 iterations of the reference's own pieces (oracle/make_golden_uamt.py)."""
+    d = np.load(f"{golden_dir}/trace_uamt.npz")
+    torch.manual_seed(1337)
+    m = UNet(1, 4).to(DEV)
+    ema = UNet(1, 4).to(DEV)              # a second construction, as the driver builds its teacher (:86-87)
+    m.math = ema.math = math
+    for p in ema.parameters():
+        p.requires_grad = False
+    m.train()
+    ema.train()
+    st = UAMTStep(m, ema, _opt_args())
+    xl, yl, xu = (torch.from_numpy(d[k]).to(DEV) for k in ("xl", "yl", "xu"))
+    rows = []
+    for k in range(2):
+        nz = torch.from_numpy(d["noise"][k]).to(DEV)
+        m.external_dropout_masks = _masks(d, f"it{k}_f0_", 4, 32)
+        ema.external_dropout_masks = [_masks(d, f"it{k}_f1_", 2, 32)] + [_masks(d, f"it{k}_f{j}_", 4, 32) for j in range(2, 6)]
+        ema._ext_mask_idx = 0
+        st.host_scalars(k + 1, float(d["cons_w"]))
+        st.sc.host[3] = float(d["thresholds"][k])          # S_THRESH: the trace's threshold (see oracle/make_golden_uamt.py)
+        st.sc.push()
+        r = st.device_step(xl, yl, xu, nz[:2], [nz[2 + 4 * i:6 + 4 * i] for i in range(4)])
+        st.after()
+        p = r["parts"].cpu()
+        rows.append([float(r["loss"]), 0.5 * float(p[1]) + 0.5 * float(p[2]), float(p[5])])
+    rows, ref = np.array(rows), d["losses"]
+    assert np.abs(rows - ref).max() < TOL, (rows, ref)
+    assert np.abs(rows[:, 2] - ref[:, 2]).max() < 2e-4, (rows, ref)          # the masked consistency term on its own
+    want = np.unpackbits(d["mask_last"])[:2 * 32 * 32].reshape(2, 1, 32, 32)
+    assert int((r["mask"].cpu().numpy() != want).sum()) <= 8                  # entropy within float noise of the threshold
+    assert maxerr(r["logits"].cpu(), torch.from_numpy(d["student_logits_last"])) < logit_tol(math)
+
+
+def test_uamt_kernels_vs_oracle():
+    """noise_add, the entropy mask and the masked consistency loss / gradient against plain torch on random logits."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 1, 16, 24, generator=g)
+    nz = torch.randn(6, 1, 16, 24, generator=g)
+    got = noise_add(x.to(DEV), nz.to(DEV)).cpu()
+    assert torch.equal(got, x.repeat(2, 1, 1, 1) + torch.clamp(nz * 0.1, -0.2, 0.2))
+    T, S, Cc = 8, 3, 4
+    blocks = [torch.randn(2 * S, Cc, 16, 24, generator=g) * 2 for _ in range(T // 2)]
+    pm = torch.softmax(torch.cat(blocks, 0), 1).reshape(T, S, Cc, 16, 24).mean(0)
+    unc = -(pm * torch.log(pm + 1e-6)).sum(1, keepdim=True)
+    thr = float(unc.median())
+    mask, u = uncertainty_mask([b.to(DEV) for b in blocks], S, torch.tensor([thr], device=DEV), want_uncertainty=True)
+    assert maxerr(u.cpu(), unc) < 1e-5
+    sure = (unc - thr).abs() > 1e-5
+    assert torch.equal(mask.cpu()[sure], (unc < thr).float()[sure])
+    from hpfg_amd.utils import seg_loss
+    logits = torch.randn(5, Cc, 16, 24, generator=g)
+    tl = torch.randn(3, Cc, 16, 24, generator=g)
+    y = torch.randint(0, Cc, (2, 16, 24), generator=g)
+    mk = (unc < thr).float()
+    a = logits.clone().requires_grad_(True)
+    sm = torch.softmax(a, 1)
+    cons = (mk * (sm[2:] - torch.softmax(tl, 1)) ** 2).sum() / (2 * mk.sum() + 1e-16)
+    ref = losses_ref.med_sup_loss(a[:2], y) + 0.7 * cons
+    ref.backward()
+    b = logits.clone().to(DEV).requires_grad_(True)
+    res = seg_loss(b, y.to(DEV), 2, coef=torch.tensor([0.5, 0.5, 0, 0, 0.7, 0, 0, 0], dtype=torch.float32, device=DEV), teacher_logits=tl.to(DEV),
+                   cons_mask=mk.to(DEV))
+    res[0].backward()
+    assert abs(float(res[0]) - float(ref)) < 1e-5 and abs(float(res[5]) - float(cons)) < 1e-6
+    assert maxerr(b.grad.cpu(), a.grad) < 1e-6
 
 
 @pytest.mark.parametrize("math", ["f32", "bf16x3"])

@@ -139,6 +139,23 @@ def test_ict_trace(golden_dir):
     assert float((r["logits"] - torch.from_numpy(d["student_logits_last"])).abs().max()) < 1e-4
 
 
+def test_uamt_trace(golden_dir):
+    d = np.load(f"{golden_dir}/trace_uamt.npz")
+    st = unet_ref.init_state(1337, 1, 4)
+    ema, bufs = unet_ref.init_state(None, 1, 4), {}
+    xl, yl, xu = torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xu"])
+    rows = []
+    for k in range(2):
+        nz = torch.from_numpy(d["noise"][k])
+        mt = [_unpack_masks(d, f"it{k}_f1_", 2, 32)] + [_unpack_masks(d, f"it{k}_f{j}_", 4, 32) for j in range(2, 6)]
+        r = steps_ref.uamt_step(st, ema, bufs, xl, yl, xu, nz[:2], [nz[2 + 4 * i:6 + 4 * i] for i in range(4)], float(d["thresholds"][k]),
+                                laws_ref.medical_lr(k + 1, 0.01, 30000), float(d["cons_w"]), laws_ref.ema_alpha(k + 1, 0.99), 0.9, 1e-4,
+                                _unpack_masks(d, f"it{k}_f0_", 4, 32), mt)
+        rows.append([r["loss"], r["sup"], r["cons"]])
+    assert np.abs(np.array(rows) - d["losses"]).max() < 2e-5
+    assert float((r["uncertainty"] - torch.from_numpy(d["uncertainty_last"])).abs().max()) < 1e-5
+
+
 def test_cps_and_hpfg_traces(golden_dir):
     d = np.load(f"{golden_dir}/trace_cps.npz")
     torch.manual_seed(1337)
