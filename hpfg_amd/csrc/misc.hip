@@ -301,6 +301,11 @@ __global__ __launch_bounds__(256) void softmax_mix_kernel(const float* __restric
   }
 }
 
+// diagnostics: the 100 MHz chip-wide clock, written when the stream reaches this point (works inside a captured graph)
+__global__ void timestamp_kernel(unsigned long long* slot) {
+  if (threadIdx.x == 0) *slot = __builtin_amdgcn_s_memrealtime();
+}
+
 // UAMT (2019_07_MICCAI_Uncertainty_Aware_ACDC.py:130-147): input noise for the teacher passes, and the uncertainty mask
 // out[i] = x[i % n_src] + clamp(noise[i] * scale, lo, hi)   (unlabeled.repeat(2,1,1,1) + clamp(randn*0.1, -0.2, 0.2), :130,142)
 __global__ __launch_bounds__(256) void noise_add_kernel(const float* __restrict__ x, const float* __restrict__ noise, float* __restrict__ out,
@@ -501,6 +506,12 @@ extern "C" int hpfg_softmax_mix(const float* t0, const float* t1, const float* f
   hipLaunchKernelGGL(softmax_mix_kernel, dim3(grid_for((long)n * H * W)), dim3(256), 0, (hipStream_t)stream, t0, t1, f, out_prob, (long)n * H * W,
                      (long)H * W, C);
   return hpfg_launch_status("softmax_mix_kernel");
+}
+
+extern "C" int hpfg_timestamp(unsigned long long* slot, void* stream) {
+  HPFG_ARG_CHECK(slot, "timestamp: null slot");
+  hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slot);
+  return hpfg_launch_status("timestamp_kernel");
 }
 
 extern "C" int hpfg_noise_add(const float* x, const float* noise, float* out, long n_src, long n_out, float scale, float lo, float hi,

@@ -111,7 +111,9 @@ class UNetEngine:
         self._bwd_alloc = False
         self.x: Optional[torch.Tensor] = None
         self.world = 1
-        self.wgrad_overlap = os.environ.get("HPFG_WGRAD_OVERLAP", "0") == "1"   # measured: -3% (persistent dgrad grids fill the CUs)
+        # 0: wgrad on the main stream.  1: on a second stream, forked before the layer's dgrad (measured -7%: two heavy kernels
+        # contend).  2: forked AFTER the layer's dgrad is queued, so that it overlaps the light BatchNorm-backward kernels of the next layer.
+        self.wgrad_overlap = int(os.environ.get("HPFG_WGRAD_OVERLAP", "0"))
         self._side, self._side_used = None, False
         self.force_sync = False  # run the data-parallel code path (reduce -> all-reduce -> finalize) even with one rank (tests)
         self.math = L.MATH_F32      # L.MATH_BF16X3 selects the split-bf16 matrix-core kernels for conv forward / dgrad
@@ -353,6 +355,15 @@ class UNetEngine:
                                                   s.cout, st), "bn_bwd_finalize")
         return g
 
+    def _wgrad_dgrad(self, s: ConvSpec, g: L.Act, dgrad_out: torch.Tensor):
+        """Both gradients of layer s from the same dZ source (they only read it, so their order is free)."""
+        if self.wgrad_overlap == 2:
+            self._dgrad(s, g, dgrad_out)
+            self._wgrad(s, g)
+        else:
+            self._wgrad(s, g)
+            self._dgrad(s, g, dgrad_out)
+
     def _wgrad(self, s: ConvSpec, g: L.Act):
         """Weight gradient of layer s.  It is off the critical chain of backward (nothing downstream consumes it before the final
         slab reduction), so it is issued on a second HIP stream forked behind the kernels recorded so far and joined at the end."""
@@ -400,29 +411,25 @@ class UNetEngine:
         # ---- out_conv
         s = sp["decoder.out_conv"]
         g = self._act_plain(dlogits, self.ncls, s.h, s.w)
-        self._wgrad(s, g)
         L.check(self.lib.hpfg_channel_sum_partials(L.ptr(dlogits), self.ncls, N * s.h * s.w, self.ncls, L.ptr(self.csum_part[s.name]), st),
                 "channel_sum_partials")
-        self._dgrad(s, g, self.dA["decoder.up4.conv.conv_conv.4"])
+        self._wgrad_dgrad(s, g, self.dA["decoder.up4.conv.conv_conv.4"])
         # ---- decoder blocks, last to first
         for k in range(4, 0, -1):
             p = f"decoder.up{k}.conv.conv_conv"
             s2, s1, su = sp[f"{p}.4"], sp[f"{p}.0"], sp[f"decoder.up{k}.conv1x1"]
             g2 = self._bn_backward(s2)
-            self._wgrad(s2, g2)
-            self._dgrad(s2, g2, self.dA[s1.name])
+            self._wgrad_dgrad(s2, g2, self.dA[s1.name])
             g1 = self._bn_backward(s1)
-            self._wgrad(s1, g1)
-            self._dgrad(s1, g1, self.dcat[k])                      # [dSkip | dUp]
+            self._wgrad_dgrad(s1, g1, self.dcat[k])                # [dSkip | dUp]
             c2 = su.cout
             dup = self.dcat[k].view(-1)[c2:]                        # channel offset c2, pixel stride 2*c2
             L.check(self.lib.hpfg_upsample2x_bwd(L.ptr(dup), 2 * c2, L.ptr(self.dU[k]), N, su.h, su.w, c2, st), "upsample2x_bwd")
             gu = self._act_plain(self.dU[k], c2, su.h, su.w)
-            self._wgrad(su, gu)
             L.check(self.lib.hpfg_channel_sum_partials(L.ptr(self.dU[k]), c2, N * su.h * su.w, c2, L.ptr(self.csum_part[su.name]), st),
                     "channel_sum_partials")
             prev = enc_prefix(4) + ".4" if k == 1 else f"decoder.up{k - 1}.conv.conv_conv.4"
-            self._dgrad(su, gu, self.dA[prev])
+            self._wgrad_dgrad(su, gu, self.dA[prev])
         if dfeat4 is not None:
             self.dA[enc_prefix(4) + ".4"].add_(dfeat4)
         # ---- encoder blocks, deepest first
@@ -430,12 +437,12 @@ class UNetEngine:
             p = enc_prefix(lvl)
             s2, s1 = sp[f"{p}.4"], sp[f"{p}.0"]
             g2 = self._bn_backward(s2)
-            self._wgrad(s2, g2)
-            self._dgrad(s2, g2, self.dA[s1.name])
+            self._wgrad_dgrad(s2, g2, self.dA[s1.name])
             g1 = self._bn_backward(s1)
-            self._wgrad(s1, g1)
+            if lvl == 0:
+                self._wgrad(s1, g1)
             if lvl > 0:
-                self._dgrad(s1, g1, self.dP[lvl])
+                self._wgrad_dgrad(s1, g1, self.dP[lvl])
                 below = enc_prefix(lvl - 1) + ".4"
                 src = self._act_bn(below)
                 src.drop_p = 0.0

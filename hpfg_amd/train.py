@@ -72,10 +72,16 @@ class _StepBase:
     def __init__(self, dev, dp=None):
         self.dev, self.dp = dev, dp
         self.sc = StepScalars(dev)
+        # HPFG_STEP_MARKS=1: timestamp kernels at phase boundaries of the step (tools/stream_timeline.py); off by default
+        self.marks = torch.zeros(32, dtype=torch.int64, device=dev) if os.environ.get("HPFG_STEP_MARKS", "0") == "1" else None
         # the no-grad teacher forward is independent of the student forward: run it on a second HIP stream so that the two
         # kernel chains (and, data parallel, their small BatchNorm collectives) overlap; joins before the loss.
         self.overlap = os.environ.get("HPFG_OVERLAP", "1") == "1"
         self.side = torch.cuda.Stream(device=dev) if self.overlap else None
+
+    def _mark(self, i):
+        if self.marks is not None:
+            L.check(L.load().hpfg_timestamp(self.marks.data_ptr() + 8 * i, torch.cuda.current_stream(self.dev).cuda_stream), "timestamp")
 
     def _teacher_forward(self, ema_model, x):
         """ema_model(x) under no_grad, on the side stream when overlap is enabled.  Returns the teacher outputs."""
@@ -85,7 +91,9 @@ class _StepBase:
         cur = torch.cuda.current_stream(self.dev)
         self.side.wait_stream(cur)
         with torch.cuda.stream(self.side), torch.no_grad():
+            self._mark(2)
             out = ema_model(x)
+            self._mark(3)
         self._pending_join = True
         return out
 
@@ -188,12 +196,20 @@ class MeanTeacherStep(_StepBase):
         """Everything up to (not including) the gradient exchange."""
         nl = label_img.shape[0]
         x = torch.cat([label_img, unlabel_img], 0)
+        self._mark(0)
         t_out = self._teacher_forward(self.ema_model, x)
+        self._mark(1)
         out = self.model(x)
+        self._mark(4)
         self._join_teacher(t_out)
+        return self._loss_bwd(out, t_out, target_label, nl)
+
+    def _loss_bwd(self, out, t_out, target_label, nl):
+        self._mark(5)
         res = seg_loss(out, target_label, nl, coef=self.sc.view(S_COEF_A, 8), teacher_logits=t_out, dp=self.dp)
         self.optimizer.zero_grad()
         self._loss_backward(res)
+        self._mark(6)
         return {"loss": res[0].detach(), "parts": res.detach(), "logits": out.detach(), "t_logits": t_out}
 
     def exchange(self):
@@ -202,6 +218,7 @@ class MeanTeacherStep(_StepBase):
     def device_update(self):
         self.optimizer.step(push_lr=False)
         update_ema_variables(self.model, self.ema_model, self.args.ema_decay, 0, alpha_dev=self.sc.view(S_ALPHA))
+        self._mark(7)
 
     def device_step(self, label_img, target_label, unlabel_img):
         r = self.device_fwd_bwd(label_img, target_label, unlabel_img)

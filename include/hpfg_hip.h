@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 107
+#define HPFG_VERSION 108
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -208,6 +208,8 @@ int hpfg_box_masks(const int* rects, int n, int n_boxes, int H, int W, int inver
 int hpfg_mix_samples(const float* a, const float* b, const float* f, float* out, int n, long per_sample, void* stream);
 /* softmax(t0)*(1-f[s]) + softmax(t1)*f[s] over NHWC logits [n,H,W,C] (ICT mixed teacher prediction, :126-129) */
 int hpfg_softmax_mix(const float* t0, const float* t1, const float* f, float* out_prob, int n, int H, int W, int C, void* stream);
+/* diagnostics (tools/stream_timeline.py): *slot = s_memrealtime (100 MHz) when `stream` reaches this point; capturable */
+int hpfg_timestamp(unsigned long long* slot, void* stream);
 /* UAMT teacher-input noise (2019_07_MICCAI_Uncertainty_Aware_ACDC.py:130,142): out[i] = x[i % n_src] + clamp(noise[i]*scale, lo, hi) */
 int hpfg_noise_add(const float* x, const float* noise, float* out, long n_src, long n_out, float scale, float lo, float hi, void* stream);
 /* UAMT uncertainty mask (:147-151,162-163): T stochastic teacher predictions (NHWC logits) of the same S images, prediction
