@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ = range(7)
 LOSS_NSUM = 32
-VERSION = 108
+VERSION = 109
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -111,6 +111,8 @@ PROTOTYPES = {
     "hpfg_softmax_mix": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "hpfg_pool_scatter_add": (_i, [C.POINTER(Act), _p, _i, _p, _i, _i, _i, _i, _p]),
     "hpfg_upsample2x_bwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    "hpfg_upsample2x_bwd_sums": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),
+    "hpfg_upsample2x_bwd_blocks": (_i, [_i, _i, _i, _i]),
     "hpfg_loss_blocks": (_i, [_i, _i, _i]),
     "hpfg_seg_loss_partials": (_i, [C.POINTER(LossArgs), _p]),
     "hpfg_seg_loss_finalize": (_i, [C.POINTER(LossArgs), _p]),

@@ -161,12 +161,17 @@ __device__ inline void up_taps(int lo, int L, int* idx, float* wgt, int& cnt) {
 
 // The tap lists depend only on the low-res row / column: every workgroup builds both tables in LDS once (one table entry per
 // thread) instead of every thread re-deriving them for its pixel (that was ~170 VALU instructions per output float4).
+// (A tiled separable variant -- high-res patch staged once in LDS, vertical then horizontal pass -- was measured 1.4-1.8x SLOWER:
+// two 72 KB workgroups per CU keep too few loads in flight; this gather form runs 8 workgroups per CU and its re-reads hit L2.)
+// Optionally the per-channel sums of each workgroup's outputs go to csum[blockIdx][C]: the bias gradient of the 1x1 conv that
+// produced the low-res tensor (model/unet.py:50) is sum_p dU, and the slab reduction adds the rows in a fixed order.
 constexpr int UPB_MAXDIM = 512, UPB_TAPS = 6;
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dUp, int dup_ps, float* __restrict__ dU, int N, int Hl, int Wl,
-                                                           int C) {
+                                                           int C, float* __restrict__ csum) {
   __shared__ short t_idx[UPB_MAXDIM][UPB_TAPS];
   __shared__ float t_w[UPB_MAXDIM][UPB_TAPS];
   __shared__ unsigned char t_cnt[UPB_MAXDIM];
+  __shared__ float red[256 * 4];
   for (int e = threadIdx.x; e < Hl + Wl; e += 256) {
     int idx[8], cnt;
     float wgt[8];
@@ -182,7 +187,8 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
   __syncthreads();
   const int Q = C / 4, Ho = 2 * Hl, Wo = 2 * Wl;
   const long total = (long)N * Hl * Wl * Q;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  f32x4 csum4 = {0.f, 0.f, 0.f, 0.f};
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {      // 256 % Q == 0: a thread keeps its channel quad
     int q = (int)(i % Q);
     long pp = i / Q;
     int xl = (int)(pp % Wl), yl = (int)((pp / Wl) % Hl), n = (int)(pp / ((long)Wl * Hl));
@@ -197,6 +203,18 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
       }
     }
     *reinterpret_cast<f32x4*>(dU + pp * C + q * 4) = acc;
+    csum4 += acc;
+  }
+  if (csum) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[threadIdx.x * 4 + j] = csum4[j];
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+      const int q = threadIdx.x >> 2, j = threadIdx.x & 3;
+      float s = 0.f;
+      for (int k = q; k < 256; k += Q) s += red[k * 4 + j];           // fixed order
+      csum[(long)blockIdx.x * C + threadIdx.x] = s;
+    }
   }
 }
 
@@ -464,11 +482,22 @@ extern "C" int hpfg_pool_scatter_add(const HpfgAct* src, const float* dP, int dp
   return hpfg_launch_status("pool_scatter_kernel");
 }
 
-extern "C" int hpfg_upsample2x_bwd(const float* dUp, int dup_pstride, float* dU, int N, int Hl, int Wl, int C, void* stream) {
-  HPFG_ARG_CHECK(dUp && dU && C % 4 == 0 && N > 0 && Hl > 0 && Wl > 0 && Hl + Wl <= UPB_MAXDIM, "upsample2x_bwd: bad args");
-  long total = (long)N * Hl * Wl * (C / 4);
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dUp, dup_pstride, dU, N, Hl, Wl, C);
+extern "C" int hpfg_upsample2x_bwd_blocks(int N, int Hl, int Wl, int C) {
+  if (N < 1 || Hl < 1 || Wl < 1 || C < 4) return 0;
+  return grid_for((long)N * Hl * Wl * (C / 4), 1024);      // = rows of channel sums the slab reduction has to add: keep that chain short
+}
+
+extern "C" int hpfg_upsample2x_bwd_sums(const float* dUp, int dup_pstride, float* dU, int N, int Hl, int Wl, int C, float* csum_partials,
+                                        void* stream) {
+  HPFG_ARG_CHECK(dUp && dU && C % 4 == 0 && C >= 4 && N > 0 && Hl > 0 && Wl > 0 && Hl + Wl <= UPB_MAXDIM, "upsample2x_bwd: bad args");
+  HPFG_ARG_CHECK(!csum_partials || (C <= 256 && 256 % (C / 4) == 0), "upsample2x_bwd: channel sums need C/4 to divide 256 (C=%d)", C);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(hpfg_upsample2x_bwd_blocks(N, Hl, Wl, C)), dim3(256), 0, (hipStream_t)stream, dUp, dup_pstride, dU, N,
+                     Hl, Wl, C, csum_partials);
   return hpfg_launch_status("upsample_bwd_kernel");
+}
+
+extern "C" int hpfg_upsample2x_bwd(const float* dUp, int dup_pstride, float* dU, int N, int Hl, int Wl, int C, void* stream) {
+  return hpfg_upsample2x_bwd_sums(dUp, dup_pstride, dU, N, Hl, Wl, C, nullptr, stream);
 }
 
 extern "C" int hpfg_cutmix_blend(const float* a, const float* b, const float* mask, float* out, long n, void* stream) {

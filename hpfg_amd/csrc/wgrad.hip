@@ -60,11 +60,16 @@ __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const HpfgSlabDe
     f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
     if (vec && i + 3 < per) {
       int s = sl;
-      for (; s + 16 < d.S; s += 32) {
+      f32x4 t2 = t0, t3 = t0;
+      for (; s + 48 < d.S; s += 64) {                 // four independent rows in flight per thread (the chain is latency bound)
         t0 += *reinterpret_cast<const f32x4*>(d.slab + s * per + i);
         t1 += *reinterpret_cast<const f32x4*>(d.slab + (s + 16) * per + i);
+        t2 += *reinterpret_cast<const f32x4*>(d.slab + (s + 32) * per + i);
+        t3 += *reinterpret_cast<const f32x4*>(d.slab + (s + 48) * per + i);
       }
-      if (s < d.S) t0 += *reinterpret_cast<const f32x4*>(d.slab + s * per + i);
+      for (; s < d.S; s += 16) t0 += *reinterpret_cast<const f32x4*>(d.slab + s * per + i);
+      t0 += t2;
+      t1 += t3;
     } else {
       for (int s = sl; s < d.S; s += 16)
 #pragma unroll

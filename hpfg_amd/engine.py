@@ -318,7 +318,9 @@ class UNetEngine:
         # bias gradients of the convs without BatchNorm (1x1 convs, out_conv): their per-block channel sums are summed by the same
         # launch, as pseudo layers {taps 1, Cin 1} (one kernel less per bias)
         self.bias_layers = [s for s in self.order if not s.bn]
-        self.csum_part = {s.name: torch.empty(self.lib.hpfg_channel_sum_blocks(N * s.h * s.w, s.cout) * s.cout, **f32) for s in self.bias_layers}
+        self.csum_rows = {s.name: (self.lib.hpfg_upsample2x_bwd_blocks(N, s.h, s.w, s.cout) if s.taps == 1
+                                   else self.lib.hpfg_channel_sum_blocks(N * s.h * s.w, s.cout)) for s in self.bias_layers}
+        self.csum_part = {s.name: torch.empty(self.csum_rows[s.name] * s.cout, **f32) for s in self.bias_layers}
         descs = (L.SlabDesc * (len(self.order) + len(self.bias_layers)))()
         for d, s, sz in zip(descs, self.order, sizes):
             self.slab_of[s.name] = self.slab_all[off:off + sz]
@@ -329,7 +331,7 @@ class UNetEngine:
         for j, s in enumerate(self.bias_layers):
             d = descs[len(self.order) + j]
             d.slab, d.dw_oihw = L.ptr(self.csum_part[s.name]), L.ptr(self.grads[f"{s.name}.bias"])
-            d.S = self.lib.hpfg_channel_sum_blocks(N * s.h * s.w, s.cout)
+            d.S = self.csum_rows[s.name]
             d.taps, d.Cin, d.CinPad, d.Cout, d.CoutPad = 1, 1, 1, s.cout, s.cout
         self._slab_host = descs
         self._slab_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.dev)
@@ -424,10 +426,9 @@ class UNetEngine:
             self._wgrad_dgrad(s1, g1, self.dcat[k])                # [dSkip | dUp]
             c2 = su.cout
             dup = self.dcat[k].view(-1)[c2:]                        # channel offset c2, pixel stride 2*c2
-            L.check(self.lib.hpfg_upsample2x_bwd(L.ptr(dup), 2 * c2, L.ptr(self.dU[k]), N, su.h, su.w, c2, st), "upsample2x_bwd")
+            L.check(self.lib.hpfg_upsample2x_bwd_sums(L.ptr(dup), 2 * c2, L.ptr(self.dU[k]), N, su.h, su.w, c2, L.ptr(self.csum_part[su.name]), st),
+                    "upsample2x_bwd")                            # + per-workgroup channel sums of dU: the 1x1 conv's bias gradient
             gu = self._act_plain(self.dU[k], c2, su.h, su.w)
-            L.check(self.lib.hpfg_channel_sum_partials(L.ptr(self.dU[k]), c2, N * su.h * su.w, c2, L.ptr(self.csum_part[su.name]), st),
-                    "channel_sum_partials")
             prev = enc_prefix(4) + ".4" if k == 1 else f"decoder.up{k - 1}.conv.conv_conv.4"
             self._wgrad_dgrad(su, gu, self.dA[prev])
         if dfeat4 is not None:

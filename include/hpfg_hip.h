@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 108
+#define HPFG_VERSION 109
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -155,6 +155,10 @@ int hpfg_pool_scatter_add(const HpfgAct* src /* BNACT view of the pooled tensor'
                           float* dA, int da_pstride, int N, int Hp, int Wp, void* stream);
 /* bilinear x2 (align_corners) backward: dU[low res] = sum of taps of dUp (dUp has dup_pstride floats per pixel) */
 int hpfg_upsample2x_bwd(const float* dUp, int dup_pstride, float* dU, int N, int Hl, int Wl, int C, void* stream);
+/* same, and csum_partials[hpfg_upsample2x_bwd_blocks()][C] receives per-workgroup channel sums of dU (the bias gradient of the
+ * 1x1 conv in front of the upsample, model/unet.py:50; rows are summed by hpfg_slab_reduce_multi like hpfg_channel_sum_partials') */
+int hpfg_upsample2x_bwd_sums(const float* dUp, int dup_pstride, float* dU, int N, int Hl, int Wl, int C, float* csum_partials, void* stream);
+int hpfg_upsample2x_bwd_blocks(int N, int Hl, int Wl, int C);
 
 /* ---- losses (main.py:164-197, medloss.py:44-56, diceloss.py:155-191, Mean-Teacher :103-106) -------------- */
 typedef struct HpfgLossArgs {

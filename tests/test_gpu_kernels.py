@@ -183,15 +183,21 @@ def test_pool_scatter_and_upsample_bwd():
     ref[..., :C_] += yr.grad.permute(0, 2, 3, 1)
     assert maxerr(dAd.cpu(), ref) < 1e-6
     # upsample backward
-    for (hl, wl) in [(4, 6), (1, 1), (2, 2), (7, 7)]:
-        u = torch.randn(N, 8, hl, wl, generator=g, requires_grad=True)
+    for (hl, wl, cu) in [(4, 6, 8), (1, 1, 8), (2, 2, 8), (7, 7, 8), (28, 20, 16), (14, 9, 32), (9, 7, 64), (5, 6, 128)]:
+        u = torch.randn(N, cu, hl, wl, generator=g, requires_grad=True)
         up = F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=True)
-        gcat = torch.randn(N, 2 * hl, 2 * wl, 24, generator=g)  # channels [16,24) hold dUp, pixel stride 24
+        gcat = torch.randn(N, 2 * hl, 2 * wl, 16 + cu, generator=g)  # channels [16,16+cu) hold dUp, pixel stride 16+cu
         up.backward(nchw(gcat[..., 16:]))
         gd = gcat.to(DEV)
-        dU = torch.empty(N, hl, wl, 8, device=DEV)
-        L.check(L.load().hpfg_upsample2x_bwd(gd.view(-1)[16:].data_ptr(), 24, L.ptr(dU), N, hl, wl, 8, stream(DEV)), "upbwd")
-        assert maxerr(nchw(dU.cpu()), u.grad) < 1e-5, (hl, wl)
+        dU = torch.empty(N, hl, wl, cu, device=DEV)
+        L.check(L.load().hpfg_upsample2x_bwd(gd.view(-1)[16:].data_ptr(), 16 + cu, L.ptr(dU), N, hl, wl, cu, stream(DEV)), "upbwd")
+        assert maxerr(nchw(dU.cpu()), u.grad) < 1e-5, (hl, wl, cu)
+        rows = L.load().hpfg_upsample2x_bwd_blocks(N, hl, wl, cu)          # fused per-workgroup channel sums (1x1 conv bias gradient)
+        part = torch.empty(rows, cu, device=DEV)
+        dU2 = torch.empty_like(dU)
+        L.check(L.load().hpfg_upsample2x_bwd_sums(gd.view(-1)[16:].data_ptr(), 16 + cu, L.ptr(dU2), N, hl, wl, cu, L.ptr(part), stream(DEV)), "upbwd")
+        assert torch.equal(dU2, dU)
+        assert maxerr(part.sum(0).cpu(), u.grad.sum((0, 2, 3))) < 1e-3, (hl, wl, cu)
 
 
 def test_first_conv_and_channel_sum():
