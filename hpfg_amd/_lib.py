@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ = range(7)
 LOSS_NSUM = 32
-VERSION = 109
+VERSION = 110
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -91,6 +91,8 @@ PROTOTYPES = {
     "hpfg_dropout_mask": (_i, [_p, _l, _f, _u32, _p, _p]),
     "hpfg_bn_eval_table": (_i, [_p, _p, _p, _p, _f, _p, _i, _p]),
     "hpfg_bn_bwd_reduce": (_i, [C.POINTER(Act), _i, _i, _i, _p, _p]),
+    "hpfg_bn_bwd_reduce_pool": (_i, [C.POINTER(Act), _p, _i, _i, _i, _i, _p, _p]),
+    "hpfg_bn_bwd_pool_blocks": (_i, [_i, _i, _i, _i]),
     "hpfg_bn_bwd_blocks": (_i, [_i, _i, _i, _i]),
     "hpfg_bn_bwd_finalize": (_i, [_p, _i, _p, _d, _p, _p, _p, _p, _i, _p]),
     "hpfg_wgrad": (_i, [C.POINTER(WgradArgs), _p]),

@@ -169,6 +169,75 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(HpfgAct s, long npix
   }
 }
 
+// The same reduction for a layer whose output also feeds a MaxPool2d(2) (encoder block outputs, model/unet.py:37): its gradient is
+// dA (the skip path, already in place) + the max-pool backward of dP.  One pass does both: a thread takes a 2x2 window and a channel
+// quad, recomputes the arg-max from the raw output (first maximum in row-major window order, like the forward kernel's max and
+// torch's max_pool2d), adds dP there, writes the completed dA back for the dgrad / wgrad loaders, and accumulates the BatchNorm
+// sums from the registers.  Replaces pool_scatter_add + bn_bwd_reduce (one read of z and dA and one launch less).
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(HpfgAct s, const float* __restrict__ dP, int dp_ps, long npool, int Hp, int Wp,
+                                                                 float* __restrict__ partials) {
+  __shared__ float red[256 * 8];
+  const int C = s.C, Q = C >> 2, tid = threadIdx.x;
+  const int q = tid % Q, pl = tid / Q, PL = 256 / Q;
+  const int c = q * 4;
+  const float* t = s.bn + s.bn_coff + c;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(t + HPFG_BN_MEAN * s.bn_stride);
+  const f32x4 rs = *reinterpret_cast<const f32x4*>(t + HPFG_BN_RSTD * s.bn_stride);
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(t + HPFG_BN_SCALE * s.bn_stride);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(t + HPFG_BN_SHIFT * s.bn_stride);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+  float* dA = const_cast<float*>(s.aux);
+  for (long pp = (long)blockIdx.x * PL + pl; pp < npool; pp += (long)gridDim.x * PL) {
+    const int xp = (int)(pp % Wp), yp = (int)((pp / Wp) % Hp), n = (int)(pp / ((long)Wp * Hp));
+    const long p00 = (long)(n * s.Hs + 2 * yp) * s.Ws + 2 * xp;
+    const long pos[4] = {p00, p00 + 1, p00 + s.Ws, p00 + s.Ws + 1};
+    f32x4 z[4], g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      z[k] = *reinterpret_cast<const f32x4*>(s.z + pos[k] * s.pstride + c);
+      g[k] = *reinterpret_cast<const f32x4*>(dA + pos[k] * s.aux_pstride + c);
+    }
+    const f32x4 gp = *reinterpret_cast<const f32x4*>(dP + pp * dp_ps + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float y[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = z[k][j] * sc[j] + sh[j];
+      float best = lrelu(y[0]);
+      int bi = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const float v = lrelu(y[k]);
+        if (v > best) {
+          best = v;
+          bi = k;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        g[k][j] += bi == k ? gp[j] : 0.f;
+        const float gg = y[k] > 0.f ? g[k][j] : HPFG_LEAKY * g[k][j];
+        a[j] += gg;
+        b[j] += gg * ((z[k][j] - mu[j]) * rs[j]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(dA + pos[k] * s.aux_pstride + c) = g[k];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[tid * 8 + j] = a[j];
+    red[tid * 8 + 4 + j] = b[j];
+  }
+  __syncthreads();
+  for (int o = tid; o < 2 * C; o += 256) {
+    const int which = o / C, cc = o % C, qq = cc >> 2, j = cc & 3;
+    float acc = 0.f;
+    for (int l = 0; l < PL; ++l) acc += red[(l * Q + qq) * 8 + which * 4 + j];
+    partials[((long)blockIdx.x * 2 + which) * C + cc] = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, const double* __restrict__ sums,
                                                               double count, const float* __restrict__ gamma, float* __restrict__ bn,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
@@ -246,6 +315,25 @@ extern "C" int hpfg_bn_bwd_reduce(const HpfgAct* g, int N, int H, int W, float* 
   int nblk = hpfg_bn_bwd_blocks(N, H, W, g->C);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *g, npix, partials);
   return hpfg_launch_status("bn_bwd_reduce_kernel");
+}
+
+extern "C" int hpfg_bn_bwd_pool_blocks(int N, int Hp, int Wp, int C) {
+  const long npool = (long)N * Hp * Wp;
+  const int PL = 256 / (C / 4);
+  long want = (npool + (long)PL * 4 - 1) / ((long)PL * 4);      // ~4 windows = 16 pixels per thread, like hpfg_bn_bwd_blocks
+  if (want < 1) want = 1;
+  return (int)(want > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : want);
+}
+
+extern "C" int hpfg_bn_bwd_reduce_pool(const HpfgAct* g, const float* dP, int dp_pstride, int N, int Hp, int Wp, float* partials, void* stream) {
+  HPFG_ARG_CHECK(g && dP && partials && g->mode == HPFG_ACT_DZ && g->z && g->aux && g->bn, "bn_bwd_reduce_pool: needs a DZ source and dP");
+  HPFG_ARG_CHECK(g->C % 4 == 0 && g->C >= 4 && g->C <= 1024 && 256 % (g->C / 4) == 0, "bn_bwd_reduce_pool: unsupported C=%d", g->C);
+  HPFG_ARG_CHECK(g->Hs == 2 * Hp && g->Ws == 2 * Wp && N > 0, "bn_bwd_reduce_pool: the source must be exactly twice the pooled size");
+  HPFG_ARG_CHECK(g->drop_p == 0.f, "bn_bwd_reduce_pool: a pooled block output has no dropout behind it");
+  HPFG_ARG_CHECK(dp_pstride % 4 == 0 && g->aux_pstride % 4 == 0 && g->pstride % 4 == 0, "bn_bwd_reduce_pool: pixel strides must be multiples of 4");
+  hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(hpfg_bn_bwd_pool_blocks(N, Hp, Wp, g->C)), dim3(256), 0, (hipStream_t)stream, *g, dP, dp_pstride,
+                     (long)N * Hp * Wp, Hp, Wp, partials);
+  return hpfg_launch_status("bn_bwd_reduce_pool_kernel");
 }
 
 extern "C" int hpfg_bn_bwd_finalize(const float* partials, int nblk, const double* sums, double count, const float* gamma, float* bn,

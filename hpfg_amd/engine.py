@@ -337,12 +337,18 @@ class UNetEngine:
         self._slab_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.dev)
         self._bwd_alloc = True
 
-    def _bn_backward(self, s: ConvSpec):
-        """BatchNorm/LeakyReLU/Dropout backward statistics of layer s -> k1,k2,k3 rows + dgamma/dbeta."""
+    def _bn_backward(self, s: ConvSpec, pooled_grad: Optional[torch.Tensor] = None):
+        """BatchNorm/LeakyReLU/Dropout backward statistics of layer s -> k1,k2,k3 rows + dgamma/dbeta.
+        pooled_grad: gradient w.r.t. MaxPool2d(2)(this layer's activation) [N,h/2,w/2,C]; it is scattered into dA by the same pass."""
         st = self._stream()
         g = self._act_dz(s.name, self.dA[s.name], self.dA_ps[s.name])
-        nblk = self.lib.hpfg_bn_bwd_blocks(self.N, s.h, s.w, s.cout)
-        L.check(self.lib.hpfg_bn_bwd_reduce(C.byref(g), self.N, s.h, s.w, L.ptr(self.partials), st), f"bn_bwd_reduce[{s.name}]")
+        if pooled_grad is not None:
+            nblk = self.lib.hpfg_bn_bwd_pool_blocks(self.N, s.h // 2, s.w // 2, s.cout)
+            L.check(self.lib.hpfg_bn_bwd_reduce_pool(C.byref(g), L.ptr(pooled_grad), s.cout, self.N, s.h // 2, s.w // 2, L.ptr(self.partials), st),
+                    f"bn_bwd_reduce_pool[{s.name}]")
+        else:
+            nblk = self.lib.hpfg_bn_bwd_blocks(self.N, s.h, s.w, s.cout)
+            L.check(self.lib.hpfg_bn_bwd_reduce(C.byref(g), self.N, s.h, s.w, L.ptr(self.partials), st), f"bn_bwd_reduce[{s.name}]")
         count = float(self.N * s.h * s.w * self.world)
         gam = self.params[f"{s.bn}.weight"]
         dg, db = self.grads[f"{s.bn}.weight"], self.grads[f"{s.bn}.bias"]
@@ -437,18 +443,14 @@ class UNetEngine:
         for lvl in range(4, -1, -1):
             p = enc_prefix(lvl)
             s2, s1 = sp[f"{p}.4"], sp[f"{p}.0"]
-            g2 = self._bn_backward(s2)
+            # a block output below the bottleneck also fed the max-pool of the next level: its dP is folded in by the reduction pass
+            g2 = self._bn_backward(s2, self.dP[lvl + 1] if lvl < 4 else None)
             self._wgrad_dgrad(s2, g2, self.dA[s1.name])
             g1 = self._bn_backward(s1)
             if lvl == 0:
                 self._wgrad(s1, g1)
             if lvl > 0:
                 self._wgrad_dgrad(s1, g1, self.dP[lvl])
-                below = enc_prefix(lvl - 1) + ".4"
-                src = self._act_bn(below)
-                src.drop_p = 0.0
-                L.check(self.lib.hpfg_pool_scatter_add(C.byref(src), L.ptr(self.dP[lvl]), s1.cin, L.ptr(self.dA[below]), self.dA_ps[below],
-                                                       N, s1.h, s1.w, st), "pool_scatter_add")
         if self._side_used:
             torch.cuda.current_stream(self.dev).wait_stream(self._side)
             self._side_used = False

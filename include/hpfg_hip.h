@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 109
+#define HPFG_VERSION 110
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -137,6 +137,11 @@ int hpfg_dropout_mask(uint8_t* out, long n_elems, float p, uint32_t seed, const 
 int hpfg_bn_bwd_reduce(const HpfgAct* g /* mode DZ; k rows unused */, int N, int H, int W, float* partials, void* stream);
 int hpfg_bn_bwd_blocks(int N, int H, int W, int C);
 /* finalize: dgamma, dbeta (BatchNorm backward) and table rows k1,k2,k3 so that dz = k1*g + k2*z + k3 */
+/* the same for a layer whose output also went through MaxPool2d(2) (model/unet.py:37): first dA += maxpool_backward(dP) in place
+ * (arg-max recomputed from the raw output), then the sums -- replaces hpfg_pool_scatter_add + hpfg_bn_bwd_reduce in one pass */
+int hpfg_bn_bwd_reduce_pool(const HpfgAct* g /* DZ source at the un-pooled size */, const float* dP, int dp_pstride, int N, int Hp, int Wp,
+                            float* partials /* [hpfg_bn_bwd_pool_blocks()][2][C] */, void* stream);
+int hpfg_bn_bwd_pool_blocks(int N, int Hp, int Wp, int C);
 int hpfg_bn_bwd_finalize(const float* partials, int nblk, const double* sums, double count, const float* gamma,
                          float* bn, float* dgamma, float* dbeta, int C, void* stream);
 int hpfg_wgrad(const HpfgWgradArgs* args, void* stream);

@@ -200,6 +200,35 @@ def test_pool_scatter_and_upsample_bwd():
         assert maxerr(part.sum(0).cpu(), u.grad.sum((0, 2, 3))) < 1e-3, (hl, wl, cu)
 
 
+def test_bn_bwd_reduce_pool_equals_scatter_then_reduce():
+    """The fused pass (max-pool backward folded into the BatchNorm-backward reduction) against the two separate kernels."""
+    lib = L.load()
+    for (N, H, W, C_) in [(2, 8, 12, 16), (3, 4, 4, 128), (1, 6, 10, 32)]:
+        g = torch.Generator().manual_seed(C_ + H)
+        z = torch.randn(N, H, W, C_, generator=g).to(DEV)
+        tab = _bn_table(C_, 9).to(DEV)
+        dP = torch.randn(N, H // 2, W // 2, C_, generator=g).to(DEV)
+        base = torch.randn(N, H, W, C_ + 16, generator=g).to(DEV)      # dA is the first C_ channels of a wider (concat) buffer
+        two, one = base.clone(), base.clone()
+
+        def act(dA):
+            a = L.Act()
+            a.z, a.bn, a.aux, a.mode, a.C = L.ptr(z), L.ptr(tab), L.ptr(dA), L.ACT_DZ, C_
+            a.Hs, a.Ws, a.pstride, a.aux_pstride, a.bn_stride = H, W, C_, C_ + 16, C_
+            return a
+        src = L.Act()
+        src.z, src.bn, src.mode, src.C, src.Hs, src.Ws, src.pstride, src.bn_stride = L.ptr(z), L.ptr(tab), L.ACT_BNACT, C_, H, W, C_, C_
+        L.check(lib.hpfg_pool_scatter_add(C.byref(src), L.ptr(dP), C_, L.ptr(two), C_ + 16, N, H // 2, W // 2, stream(DEV)), "scatter")
+        nb2 = lib.hpfg_bn_bwd_blocks(N, H, W, C_)
+        p2 = torch.zeros(nb2, 2, C_, device=DEV)
+        L.check(lib.hpfg_bn_bwd_reduce(C.byref(act(two)), N, H, W, L.ptr(p2), stream(DEV)), "reduce")
+        nb1 = lib.hpfg_bn_bwd_pool_blocks(N, H // 2, W // 2, C_)
+        p1 = torch.zeros(nb1, 2, C_, device=DEV)
+        L.check(lib.hpfg_bn_bwd_reduce_pool(C.byref(act(one)), L.ptr(dP), C_, N, H // 2, W // 2, L.ptr(p1), stream(DEV)), "fused")
+        assert torch.equal(one, two)                                    # same arg-max rule, same in-place sum
+        assert maxerr(p1.sum(0).cpu(), p2.sum(0).cpu()) < 1e-3 * max(1.0, float(p2.sum(0).abs().max()))
+
+
 def test_first_conv_and_channel_sum():
     lib = L.load()
     for (N, H, W, cin) in [(2, 32, 32, 1), (2, 16, 48, 3)]:
