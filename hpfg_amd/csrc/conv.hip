@@ -136,6 +136,14 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
   HPFG_ARG_CHECK(a->a1.mode == HPFG_ACT_NONE || a->a0.C % 16 == 0, "conv_fwd: concat needs a0.C %% 16 == 0");
   HPFG_ARG_CHECK(a->out_pstride >= a->Cout, "conv_fwd: out_pstride < Cout");
   hipStream_t st = (hipStream_t)stream;
+  if (a->bwd_stats) {
+    const int kind = hpfg_kind_of(a->a0, a->a1);
+    HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && (kind == HPFG_KIND_DZ || kind == HPFG_KIND_PLAIN),
+                   "conv_fwd: bwd_stats is a dgrad feature of the bf16x3 kernels (DZ or PLAIN source)");
+    HPFG_ARG_CHECK(a->stat_partials && a->bwd_of.z && a->bwd_of.bn && !a->bias, "conv_fwd: bwd_stats needs stat_partials, bwd_of.z / .bn and no bias");
+    HPFG_ARG_CHECK(a->bwd_of.C == a->Cout && a->Cout == a->CoutPad && a->bwd_of.Hs == a->H && a->bwd_of.Ws == a->W && a->bwd_of.pstride % 4 == 0,
+                   "conv_fwd: bwd_of must describe a layer with C == Cout == CoutPad (%d/%d/%d) at the output size", a->bwd_of.C, a->Cout, a->CoutPad);
+  }
   if ((a->math & 0xff) == HPFG_MATH_BF16X3) {
     switch (hpfg_kind_of(a->a0, a->a1)) {
       case HPFG_KIND_PLAIN: return hpfg_conv16_launch_plain(*a, st, rows_only);

@@ -93,12 +93,19 @@ __device__ __forceinline__ void conv16_load_bias(const HpfgConvArgs& p, f32x4 (&
   }
 }
 
-template <class C>
+// BWD_OK (dgrad kernels: DZ / PLAIN sources): with p.bwd_stats the tile is the finished gradient w.r.t. the activated output of the
+// BatchNorm layer p.bwd_of, and (s1, s2) collect that layer's backward sums  sum(g), sum(g * xhat)  with
+// g = out * dropout * LeakyReLU'(bn(z))  -- the separate streaming pass over (dA, z) of hpfg_bn_bwd_reduce, done while the tile is
+// still in registers (it costs one read of z instead of a read of both tensors, and a launch).
+template <class C, bool BWD_OK = false>
 __device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (&acc)[C::MI][C::NI], f32x4 (&s1)[C::NI], f32x4 (&s2)[C::NI],
                                                   const f32x4 (&bias)[C::NI], int lane, int wm, int nt0, int n, int ty0, int tx0,
                                                   bool reload_bias = false) {
   const int H = p.H, W = p.W;
   const bool vec = (p.Cout & 3) == 0 && (p.out_pstride & 3) == 0;
+  const bool bwd = BWD_OK && p.bwd_stats;
+  ActCtx bcx;
+  if (bwd) bcx = make_ctx(p.bwd_of);
 #pragma unroll
   for (int j = 0; j < C::NI; ++j) {
     const int co = (nt0 + j) * 16 + (lane >> 4) * 4;
@@ -106,6 +113,12 @@ __device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (
     if (reload_bias) {      // register-starved kernels keep no copy across the k-loop
       b = f32x4{0.f, 0.f, 0.f, 0.f};
       if (p.bias && co < p.CoutPad) b = ld4(p.bias, co);
+    }
+    f32x4 tsc, tsh;      // only the sign of bn(z) is needed here: sum(g*xhat) = rstd * (sum(g*z) - mean * sum(g)) is finished in the flush
+    if (bwd && co < p.Cout) {
+      const float* tb = p.bwd_of.bn + p.bwd_of.bn_coff + co;
+      tsc = ld4(tb, HPFG_BN_SCALE * p.bwd_of.bn_stride);
+      tsh = ld4(tb, HPFG_BN_SHIFT * p.bwd_of.bn_stride);
     }
 #pragma unroll
     for (int m = 0; m < C::MI; ++m) {
@@ -124,8 +137,22 @@ __device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (
             else v[r] = 0.f;
           }
         }
-        s1[j] += v;
-        s2[j] += v * v;
+        if (bwd) {
+          const long pix = ((long)n * H + gy) * W + gx;
+          const f32x4 z = *reinterpret_cast<const f32x4*>(p.bwd_of.z + pix * p.bwd_of.pstride + co);
+          uint32_t km = 0xFu;
+          if (p.bwd_of.drop_p > 0.f) km = keep4(p.bwd_of, bcx, (uint32_t)(pix * p.bwd_of.C + co));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float gg = (km >> r) & 1u ? v[r] * bcx.inv_keep : 0.f;
+            gg = z[r] * tsc[r] + tsh[r] > 0.f ? gg : HPFG_LEAKY * gg;
+            s1[j][r] += gg;
+            s2[j][r] += gg * z[r];
+          }
+        } else {
+          s1[j] += v;
+          s2[j] += v * v;
+        }
       }
     }
   }
@@ -133,7 +160,7 @@ __device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (
 
 // Reduce the per-lane partial sums over the 16 pixel lanes and the WM waves that share output channels; row `row` of
 // stat_partials ([rows][2][CoutPad]) receives this workgroup's sum(z), sum(z^2).
-template <class C>
+template <class C, bool BWD = false>
 __device__ __forceinline__ void conv16_flush_stats(const HpfgConvArgs& p, f32x4 (&s1)[C::NI], f32x4 (&s2)[C::NI], float* ldsf, int tid, int lane, int wm,
                                                    int wn, int cb, int row) {
   if (!p.stat_partials || (p.math & 0x1000)) return;
@@ -165,6 +192,13 @@ __device__ __forceinline__ void conv16_flush_stats(const HpfgConvArgs& p, f32x4 
 #pragma unroll
     for (int w = 0; w < C::WM; ++w) t += ldsf[(which * C::WM + w) * C::BN + cl];
     const int co = cb * C::BN + cl;
+    if (BWD && p.bwd_stats && which == 1 && co < p.Cout) {       // sum(g*z) -> sum(g*xhat)
+      float sg = 0.f;
+#pragma unroll
+      for (int w = 0; w < C::WM; ++w) sg += ldsf[w * C::BN + cl];
+      const float* tb = p.bwd_of.bn + p.bwd_of.bn_coff + co;
+      t = tb[HPFG_BN_RSTD * p.bwd_of.bn_stride] * (t - tb[HPFG_BN_MEAN * p.bwd_of.bn_stride] * sg);
+    }
     if (co < p.CoutPad) p.stat_partials[((long)row * 2 + which) * p.CoutPad + co] = t;
   }
 }
@@ -218,7 +252,9 @@ constexpr int wg_per_cu() {
 #define HPFG_TR_REAL(ID)
 #endif
 
-template <class C, int KIND>
+// BWD: the dgrad variant whose epilogue also produces the BatchNorm-backward sums of the layer below (p.bwd_stats); a separate
+// instantiation so that the plain kernels keep their register budget.
+template <class C, int KIND, bool BWD = false>
 __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   static_assert(C::TAPS == 9, "persistent kernel is the 3x3 path");
   constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
@@ -495,7 +531,7 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
       __syncthreads();
       HPFG_TR(8)
     }
-    conv16_store_tile<C>(p, acc, s1, s2, bias, lane, wm, nt0, n, ty0, tx0, TIGHT);
+    conv16_store_tile<C, BWD>(p, acc, s1, s2, bias, lane, wm, nt0, n, ty0, tx0, TIGHT);
     HPFG_TR(9)
 #pragma unroll
     for (int m = 0; m < C::MI; ++m)
@@ -517,13 +553,13 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
     ty0 = tyi * C::TH;
     tx0 = txi * C::TW;
   }
-  conv16_flush_stats<C>(p, s1, s2, ldsf, tid, lane, wm, wn, cb, (int)blockIdx.x);
+  conv16_flush_stats<C, BWD>(p, s1, s2, ldsf, tid, lane, wm, wn, cb, (int)blockIdx.x);
   HPFG_TR(10)
   HPFG_TR_REAL(12)
 }
 
 // 1x1: one tile per workgroup, K = 32 input channels per MFMA step, no halo.
-template <class C, int KIND>
+template <class C, int KIND, bool BWD = false>
 __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   static_assert(C::TAPS == 1, "1x1 path");
   constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
@@ -591,9 +627,9 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int
   }
   f32x4 bias[C::NI];       // per-workgroup constant: fetched once, not per tile in the epilogue
   conv16_load_bias<C>(p, bias, lane, nt0);
-  conv16_store_tile<C>(p, acc, s1, s2, bias, lane, wm, nt0, n, ty0, tx0);
+  conv16_store_tile<C, BWD>(p, acc, s1, s2, bias, lane, wm, nt0, n, ty0, tx0);
   __syncthreads();
-  conv16_flush_stats<C>(p, s1, s2, ldsf, tid, lane, wm, wn, cb, n * (tiles_x * tiles_y) + tile);
+  conv16_flush_stats<C, BWD>(p, s1, s2, ldsf, tid, lane, wm, wn, cb, n * (tiles_x * tiles_y) + tile);
 }
 
 // number of stat_partials rows the kernel for this configuration writes (persistent 3x3: one per workgroup)
@@ -624,7 +660,7 @@ template <class C, int KIND>
 int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   int tx = (a.W + C::TW - 1) / C::TW, ty = (a.H + C::TH - 1) / C::TH;
   bool ws = false;
-  if constexpr (C::TAPS == 9) ws = ws_enabled<C, KIND>() && a.a0.C + a.a1.C <= WS_CT;
+  if constexpr (C::TAPS == 9) ws = ws_enabled<C, KIND>() && a.a0.C + a.a1.C <= WS_CT && !a.bwd_stats;
   if (rows_only) {
     if constexpr (C::TAPS == 9) *rows_only = ws ? ws_grid<C, KIND>(a) : persistent_grid<C, KIND>(a);
     else *rows_only = tx * ty * a.N;
@@ -637,9 +673,21 @@ int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
       return hpfg_launch_status("conv_ws_kernel");
     }
     dim3 grid((unsigned)persistent_grid<C, KIND>(a), a.CoutPad / C::BN);
+    if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLAIN) {
+      if (a.bwd_stats) {
+        hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND, true>), grid, dim3(256), 0, st, a, tx, ty);
+        return hpfg_launch_status("conv_bf16x3_kernel<bwd stats>");
+      }
+    }
     hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND>), grid, dim3(256), 0, st, a, tx, ty);
   } else {
     dim3 grid(tx * ty, a.N, a.CoutPad / C::BN);
+    if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLAIN) {
+      if (a.bwd_stats) {
+        hipLaunchKernelGGL((conv1x1_bf16x3_kernel<C, KIND, true>), grid, dim3(256), 0, st, a, tx, ty);
+        return hpfg_launch_status("conv1x1_bf16x3_kernel<bwd stats>");
+      }
+    }
     hipLaunchKernelGGL((conv1x1_bf16x3_kernel<C, KIND>), grid, dim3(256), 0, st, a, tx, ty);
   }
   return hpfg_launch_status("conv_bf16x3_kernel");

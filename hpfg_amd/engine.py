@@ -114,6 +114,9 @@ class UNetEngine:
         # 0: wgrad on the main stream.  1: on a second stream, forked before the layer's dgrad (measured -7%: two heavy kernels
         # contend).  2: forked AFTER the layer's dgrad is queued, so that it overlaps the light BatchNorm-backward kernels of the next layer.
         self.wgrad_overlap = int(os.environ.get("HPFG_WGRAD_OVERLAP", "0"))
+        # BatchNorm-backward sums of the layer below from the dgrad epilogue (bf16x3 kernels) instead of a streaming pass of their own
+        self.fuse_bwd_stats = os.environ.get("HPFG_FUSE_BWD_STATS", "1") == "1"
+        self._fused_rows: Dict[str, int] = {}
         self._side, self._side_used = None, False
         self.force_sync = False  # run the data-parallel code path (reduce -> all-reduce -> finalize) even with one rank (tests)
         self.math = L.MATH_F32      # L.MATH_BF16X3 selects the split-bf16 matrix-core kernels for conv forward / dgrad
@@ -342,7 +345,11 @@ class UNetEngine:
         pooled_grad: gradient w.r.t. MaxPool2d(2)(this layer's activation) [N,h/2,w/2,C]; it is scattered into dA by the same pass."""
         st = self._stream()
         g = self._act_dz(s.name, self.dA[s.name], self.dA_ps[s.name])
-        if pooled_grad is not None:
+        fused = self._fused_rows.pop(s.name, None)
+        if fused is not None:          # the dgrad that produced dA already left the sums in self.partials
+            assert pooled_grad is None
+            nblk = fused
+        elif pooled_grad is not None:
             nblk = self.lib.hpfg_bn_bwd_pool_blocks(self.N, s.h // 2, s.w // 2, s.cout)
             L.check(self.lib.hpfg_bn_bwd_reduce_pool(C.byref(g), L.ptr(pooled_grad), s.cout, self.N, s.h // 2, s.w // 2, L.ptr(self.partials), st),
                     f"bn_bwd_reduce_pool[{s.name}]")
@@ -363,14 +370,14 @@ class UNetEngine:
                                                   s.cout, st), "bn_bwd_finalize")
         return g
 
-    def _wgrad_dgrad(self, s: ConvSpec, g: L.Act, dgrad_out: torch.Tensor):
+    def _wgrad_dgrad(self, s: ConvSpec, g: L.Act, dgrad_out: torch.Tensor, stats_for: Optional[str] = None):
         """Both gradients of layer s from the same dZ source (they only read it, so their order is free)."""
         if self.wgrad_overlap == 2:
-            self._dgrad(s, g, dgrad_out)
+            self._dgrad(s, g, dgrad_out, stats_for)
             self._wgrad(s, g)
         else:
             self._wgrad(s, g)
-            self._dgrad(s, g, dgrad_out)
+            self._dgrad(s, g, dgrad_out, stats_for)
 
     def _wgrad(self, s: ConvSpec, g: L.Act):
         """Weight gradient of layer s.  It is off the critical chain of backward (nothing downstream consumes it before the final
@@ -394,8 +401,11 @@ class UNetEngine:
         wa.math = self.math
         L.check(self.lib.hpfg_wgrad(C.byref(wa), stream), f"wgrad[{s.name}]")
 
-    def _dgrad(self, s: ConvSpec, g: L.Act, out: torch.Tensor):
-        """out [N,h,w,cin] = conv-transpose of dZ with this layer's weights."""
+    def _dgrad(self, s: ConvSpec, g: L.Act, out: torch.Tensor, stats_for: Optional[str] = None):
+        """out [N,h,w,cin] = conv-transpose of dZ with this layer's weights.
+        stats_for: name of the BatchNorm layer whose activated output `out` is the COMPLETE gradient of (this conv is its only
+        consumer): the bf16x3 kernel's epilogue then also leaves that layer's backward sums in self.partials, and the following
+        _bn_backward(stats_for) skips its own streaming pass over (dA, z)."""
         ca = L.ConvArgs()
         ca.a0, ca.a1 = g, L.Act()
         ca.math = self.math
@@ -403,6 +413,12 @@ class UNetEngine:
         ca.bias, ca.out, ca.stat_partials = None, L.ptr(out), None
         ca.out_pstride, ca.Cout, ca.CoutPad = s.cin, s.cin, s.cin_pad
         ca.N, ca.H, ca.W, ca.taps = self.N, s.h, s.w, s.taps
+        if stats_for is not None and self.math == L.MATH_BF16X3 and self.fuse_bwd_stats and s.cin == s.cin_pad:
+            ca.bwd_stats, ca.bwd_of, ca.stat_partials = 1, self._act_dz(stats_for, out, s.cin), L.ptr(self.partials)
+            rows = self.lib.hpfg_conv_stat_rows(C.byref(ca))
+            if rows <= 0 or rows * 2 * s.cin > self.partials.numel():
+                raise RuntimeError(f"dgrad[{s.name}]: {rows} rows of backward sums do not fit the partials workspace")
+            self._fused_rows[stats_for] = rows
         L.check(self.lib.hpfg_conv_fwd(C.byref(ca), self._stream()), f"dgrad[{s.name}]")
 
     def backward(self, dlogits: torch.Tensor, dfeat4: Optional[torch.Tensor] = None):
@@ -421,13 +437,13 @@ class UNetEngine:
         g = self._act_plain(dlogits, self.ncls, s.h, s.w)
         L.check(self.lib.hpfg_channel_sum_partials(L.ptr(dlogits), self.ncls, N * s.h * s.w, self.ncls, L.ptr(self.csum_part[s.name]), st),
                 "channel_sum_partials")
-        self._wgrad_dgrad(s, g, self.dA["decoder.up4.conv.conv_conv.4"])
+        self._wgrad_dgrad(s, g, self.dA["decoder.up4.conv.conv_conv.4"], "decoder.up4.conv.conv_conv.4")
         # ---- decoder blocks, last to first
         for k in range(4, 0, -1):
             p = f"decoder.up{k}.conv.conv_conv"
             s2, s1, su = sp[f"{p}.4"], sp[f"{p}.0"], sp[f"decoder.up{k}.conv1x1"]
             g2 = self._bn_backward(s2)
-            self._wgrad_dgrad(s2, g2, self.dA[s1.name])
+            self._wgrad_dgrad(s2, g2, self.dA[s1.name], s1.name)
             g1 = self._bn_backward(s1)
             self._wgrad_dgrad(s1, g1, self.dcat[k])                # [dSkip | dUp]
             c2 = su.cout
@@ -436,7 +452,8 @@ class UNetEngine:
                     "upsample2x_bwd")                            # + per-workgroup channel sums of dU: the 1x1 conv's bias gradient
             gu = self._act_plain(self.dU[k], c2, su.h, su.w)
             prev = enc_prefix(4) + ".4" if k == 1 else f"decoder.up{k - 1}.conv.conv_conv.4"
-            self._wgrad_dgrad(su, gu, self.dA[prev])
+            # the 1x1 conv is the only consumer of the block output below (the bottleneck also feeds the dense head of UNet_Plus)
+            self._wgrad_dgrad(su, gu, self.dA[prev], prev if (k > 1 or dfeat4 is None) else None)
         if dfeat4 is not None:
             self.dA[enc_prefix(4) + ".4"].add_(dfeat4)
         # ---- encoder blocks, deepest first
@@ -445,7 +462,7 @@ class UNetEngine:
             s2, s1 = sp[f"{p}.4"], sp[f"{p}.0"]
             # a block output below the bottleneck also fed the max-pool of the next level: its dP is folded in by the reduction pass
             g2 = self._bn_backward(s2, self.dP[lvl + 1] if lvl < 4 else None)
-            self._wgrad_dgrad(s2, g2, self.dA[s1.name])
+            self._wgrad_dgrad(s2, g2, self.dA[s1.name], s1.name)
             g1 = self._bn_backward(s1)
             if lvl == 0:
                 self._wgrad(s1, g1)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 110
+#define HPFG_VERSION 111
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -70,6 +70,11 @@ typedef struct HpfgConvArgs {
   int32_t taps;         /* 9 (3x3, pad 1) or 1 (1x1) */
   int32_t math;         /* HPFG_MATH_F32: exact fp32 MFMA, wpk = fp32 fragments; HPFG_MATH_BF16X3: split-bf16 MFMA (hi*hi+hi*lo+lo*hi,
                            fp32 accumulate), wpk = the wpk16_* buffer of hpfg_pack_weights */
+  int32_t bwd_stats;    /* dgrad only (BF16X3, DZ or PLAIN source): 1 = `out` is the COMPLETE gradient w.r.t. the activated output of the
+                           BatchNorm layer described by `bwd_of`; stat_partials then receives that layer's backward sums
+                           sum(g), sum(g*xhat)  (g = out * LeakyReLU' * dropout) instead of sum(z), sum(z*z) -- what hpfg_bn_bwd_reduce
+                           would compute in a pass of its own; feed the rows to hpfg_bn_bwd_finalize */
+  HpfgAct bwd_of;       /* that layer: z, its table (mean, rstd, scale, shift rows), dropout fields; C == Cout, Hs x Ws == H x W */
 } HpfgConvArgs;
 
 typedef struct HpfgWgradArgs {
