@@ -115,7 +115,7 @@ class UNetEngine:
         # contend).  2: forked AFTER the layer's dgrad is queued, so that it overlaps the light BatchNorm-backward kernels of the next layer.
         self.wgrad_overlap = int(os.environ.get("HPFG_WGRAD_OVERLAP", "0"))
         # BatchNorm-backward sums of the layer below from the dgrad epilogue (bf16x3 kernels) instead of a streaming pass of their own
-        self.fuse_bwd_stats = os.environ.get("HPFG_FUSE_BWD_STATS", "1") == "1"
+        self.fuse_bwd_stats = int(os.environ.get("HPFG_FUSE_BWD_STATS", "1"))      # 2: also the register-starved 32-channel instantiation
         self._fused_rows: Dict[str, int] = {}
         self._side, self._side_used = None, False
         self.force_sync = False  # run the data-parallel code path (reduce -> all-reduce -> finalize) even with one rank (tests)
@@ -413,7 +413,9 @@ class UNetEngine:
         ca.bias, ca.out, ca.stat_partials = None, L.ptr(out), None
         ca.out_pstride, ca.Cout, ca.CoutPad = s.cin, s.cin, s.cin_pad
         ca.N, ca.H, ca.W, ca.taps = self.N, s.h, s.w, s.taps
-        if stats_for is not None and self.math == L.MATH_BF16X3 and self.fuse_bwd_stats and s.cin == s.cin_pad:
+        # (not for the 32-channel slices of 16x16-pixel tiles: that instantiation is out of registers and the extra epilogue spills)
+        spills = s.taps == 9 and s.cin_pad % 32 == 0 and s.h % 16 == 0 and s.w % 16 == 0
+        if stats_for is not None and self.math == L.MATH_BF16X3 and self.fuse_bwd_stats and s.cin == s.cin_pad and (not spills or self.fuse_bwd_stats == 2):
             ca.bwd_stats, ca.bwd_of, ca.stat_partials = 1, self._act_dz(stats_for, out, s.cin), L.ptr(self.partials)
             rows = self.lib.hpfg_conv_stat_rows(C.byref(ca))
             if rows <= 0 or rows * 2 * s.cin > self.partials.numel():
