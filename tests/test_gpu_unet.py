@@ -14,7 +14,13 @@ from tests.helpers import engine_masks, maxerr, nchw, state_from_module
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
-CASES = [(2, 32, 1, 4, 1), (3, 48, 3, 2, 1337), (2, 64, 1, 4, 5)]
+# (n, hw, in_ch, ncls, seed); hw may be (h, w).  The last three are edge shapes: one image, a non-square batch, and the smallest
+# input the five-level encoder admits that still leaves BatchNorm more than one sample per channel at the bottleneck.
+CASES = [(2, 32, 1, 4, 1), (3, 48, 3, 2, 1337), (2, 64, 1, 4, 5), (1, (32, 64), 1, 4, 11), (2, (48, 16), 3, 3, 12), (4, 16, 1, 2, 13)]
+
+
+def _hw(hw):
+    return (hw, hw) if isinstance(hw, int) else hw
 
 
 def _engine(m):
@@ -29,11 +35,12 @@ def test_forward_train_every_layer(n, hw, in_ch, ncls, seed, math):
     m.math = math
     m.train()
     st = state_from_module(m)
-    x, _ = synth_batch(100 + seed, n, hw, hw, in_ch, ncls, cell=8)
+    h, w = _hw(hw)
+    x, _ = synth_batch(100 + seed, n, h, w, in_ch, ncls, cell=8)
     with torch.no_grad():
         out = m(x.to(DEV))
     eng = _engine(m)
-    masks = engine_masks(eng, m._seed_counter, n, hw, hw)
+    masks = engine_masks(eng, m._seed_counter, n, h, w)
     taps = {}
     with torch.no_grad():
         ref = unet_ref.unet_forward(st, x, True, masks, taps=taps)
@@ -49,11 +56,12 @@ def test_forward_train_every_layer(n, hw, in_ch, ncls, seed, math):
             assert int(sd[k]) == int(st[k]) == 1
 
 
-@pytest.mark.parametrize("n,hw,in_ch,ncls,seed", CASES[:2])
+@pytest.mark.parametrize("n,hw,in_ch,ncls,seed", CASES[:2] + CASES[3:5])
 def test_forward_eval_matches_oracle(n, hw, in_ch, ncls, seed):
     torch.manual_seed(seed)
     m = UNet(in_ch, ncls).to(DEV)
-    x, _ = synth_batch(7, n, hw, hw, in_ch, ncls, cell=8)
+    h, w = _hw(hw)
+    x, _ = synth_batch(7, n, h, w, in_ch, ncls, cell=8)
     m.train()
     with torch.no_grad():
         m(x.to(DEV))            # move the running statistics away from their initial values
@@ -73,12 +81,13 @@ def test_backward_all_parameter_gradients(n, hw, in_ch, ncls, seed, math):
     m.math = math
     m.train()
     st = state_from_module(m)
-    x, lab = synth_batch(100 + seed, n, hw, hw, in_ch, ncls, cell=8)
+    h, w = _hw(hw)
+    x, lab = synth_batch(100 + seed, n, h, w, in_ch, ncls, cell=8)
     out = m(x.to(DEV))
     loss = Med_Sup_Loss(ncls)(out, lab.to(DEV))
     loss.backward()
     eng = _engine(m)
-    masks = engine_masks(eng, m._seed_counter, n, hw, hw)
+    masks = engine_masks(eng, m._seed_counter, n, h, w)
     names = steps_ref._train_state(st)
     ro = unet_ref.unet_forward(st, x, True, masks)
     rl = losses_ref.med_sup_loss(ro, lab.long())
