@@ -156,6 +156,33 @@ def test_uamt_trace(golden_dir):
     assert float((r["uncertainty"] - torch.from_numpy(d["uncertainty_last"])).abs().max()) < 1e-5
 
 
+def test_segformer_oracle_matches_reference_fixture(golden_dir):
+    """Groundwork for SURVEY.md section 8f row 1: oracle.segformer_ref against outputs of the reference's own SegFormer-B0."""
+    from oracle import segformer_ref as S
+    d = np.load(f"{golden_dir}/segformer_b0.npz")
+    st = S.init_state(1337, 1, 4)
+    assert sum(v.numel() for k, v in st.items() if v.is_floating_point() and "running" not in k) == int(d["n_params"]) == 3712036
+    x, y = torch.from_numpy(d["x"]), torch.from_numpy(d["y"]).long()
+    with torch.no_grad():
+        assert float((S.segformer_forward(st, x, False) - torch.from_numpy(d["eval_logits"])).abs().max()) < 2e-5
+    torch.manual_seed(99)
+    dp, mask = S.draw_randomness(2)
+    names = [k for k in st if st[k].is_floating_point() and "running" not in k]
+    for k in names:
+        st[k] = st[k].clone().requires_grad_(True)
+    taps = {}
+    out = S.segformer_forward(st, x, True, dp, mask, taps=taps)
+    assert float((out - torch.from_numpy(d["train_logits"])).abs().max()) < 2e-5
+    assert float((taps["stage4"] - torch.from_numpy(d["stage4"])).abs().max()) < 2e-5
+    loss = losses_ref.med_sup_loss(out, y)
+    assert abs(float(loss) - float(d["loss"])) < 1e-6
+    gs = torch.autograd.grad(loss, [st[k] for k in names])
+    for k, g in zip(names, gs):
+        ref = d["g:" + k]
+        got = np.array([float(g.sum()), float(g.abs().sum()), float(g.abs().max())])
+        assert np.abs(got - ref).max() < 1e-4 * max(1.0, float(np.abs(ref).max())), k
+
+
 def test_cps_and_hpfg_traces(golden_dir):
     d = np.load(f"{golden_dir}/trace_cps.npz")
     torch.manual_seed(1337)
