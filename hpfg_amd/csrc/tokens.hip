@@ -1,0 +1,426 @@
+// Token-layout ([B, N, C] == NHWC) kernels of the SegFormer branch (reference model/segformer.py):
+//   LayerNorm forward / backward                      nn.LayerNorm(dim), eps 1e-5         (segformer.py:107,174,192,195,232-244)
+//   attention core softmax(q k^T * scale) v, fwd/bwd  Attention.forward :122-126; at most 64 keys (49 at 224x224), head dim 32
+//   depthwise 3x3 conv + exact GELU, fwd/bwd          DWConv :139-146 + F.gelu in MLP.forward :156
+// First version: plain fp32, one pass per op, sized for correctness and coalescing (16-byte accesses along C); the GEMM-shaped parts
+// of the branch (q / kv / proj / fc1 / fc2 / head projections) are library GEMMs on the host side.
+#include "common.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;
+
+// ---- LayerNorm: one wave per row, C <= 1024, C % 4 == 0 ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                     float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * C;
+  f32x4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    v[k] = c < C ? *reinterpret_cast<const f32x4*>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  const float mu = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    if (c < C)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q += (v[k][j] - mu) * (v[k][j] - mu);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+  const float rs = rsqrtf(q / (float)C + LN_EPS);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    if (c < C) {
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c), bb = *reinterpret_cast<const f32x4*>(b + c);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[k][j] - mu) * rs * gg[j] + bb[j];
+      *reinterpret_cast<f32x4*>(y + row * C + c) = o;
+    }
+  }
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+}
+
+// dx per row; per-workgroup partial sums of dgamma / dbeta in part[blockIdx][2][C] (summed by ln_param_reduce_kernel in a fixed order)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ g,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
+                                                     float* __restrict__ part, long rows, int C, int rows_per_wg) {
+  __shared__ float red[4][2][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 ag[4], ab[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ag[k] = ab[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long r0 = (long)blockIdx.x * rows_per_wg;
+  for (long row = r0 + wave; row < r0 + rows_per_wg && row < rows; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[4], dg[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      xh[k] = dg[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < C) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * C + c), dv = *reinterpret_cast<const f32x4*>(dy + row * C + c);
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[k][j] = (xv[j] - mu) * rs;
+          dg[k][j] = dv[j] * gg[j];
+          s1 += dg[k][j];
+          s2 += dg[k][j] * xh[k][j];
+          ag[k][j] += dv[j] * xh[k][j];
+          ab[k][j] += dv[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < C) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rs * (dg[k][j] - m1 - xh[k][j] * m2);
+        *reinterpret_cast<f32x4*>(dx + row * C + c) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    if (c < C)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        red[wave][0][c + j] = ag[k][j];
+        red[wave][1][c + j] = ab[k][j];
+      }
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * C; o += 256) {
+    const int which = o / C, c = o % C;
+    part[((long)blockIdx.x * 2 + which) * C + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+  }
+}
+
+__global__ __launch_bounds__(64) void col_reduce_kernel(const float* __restrict__ part, int nblk, int stride, float* __restrict__ out) {
+  const int c = blockIdx.x;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 64) a += (double)part[(long)i * stride + c];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+  if (threadIdx.x == 0) out[c] = (float)a;
+}
+
+// ---- attention core: thread per query, K / V of one (batch, head) in LDS; M <= 64 keys, head dim 32 ---------------------------------
+constexpr int AD = 32, AM = 64;
+// q [B,N,h,32] (row stride C = h*32), kv [B,M,2,h,32] (the kv Linear's output), out [B,N,h,32]
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ kv, float* __restrict__ out, int N, int M,
+                                                       int heads, float scale) {
+  __shared__ float ks[AM][AD], vs[AM][AD];
+  const int b = blockIdx.z, h = blockIdx.y, C = heads * AD;
+  for (int e = threadIdx.x; e < M * AD; e += 256) {
+    const int j = e / AD, c = e % AD;
+    ks[j][c] = kv[(((long)b * M + j) * 2 + 0) * C + h * AD + c];
+    vs[j][c] = kv[(((long)b * M + j) * 2 + 1) * C + h * AD + c];
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float qv[AD], s[AM];
+  const float* qp = q + ((long)b * N + i) * C + h * AD;
+#pragma unroll
+  for (int c = 0; c < AD; c += 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(qp + c);
+    qv[c] = t[0]; qv[c + 1] = t[1]; qv[c + 2] = t[2]; qv[c + 3] = t[3];
+  }
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < AM; ++j) {
+    float d = 0.f;
+    if (j < M)
+#pragma unroll
+      for (int c = 0; c < AD; ++c) d += qv[c] * ks[j][c];
+    s[j] = j < M ? d * scale : -3.0e38f;
+    mx = fmaxf(mx, s[j]);
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int j = 0; j < AM; ++j) {
+    s[j] = j < M ? expf(s[j] - mx) : 0.f;
+    den += s[j];
+  }
+  const float inv = 1.f / den;
+  float o[AD];
+#pragma unroll
+  for (int c = 0; c < AD; ++c) o[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < AM; ++j)
+    if (j < M) {
+      const float p = s[j] * inv;
+#pragma unroll
+      for (int c = 0; c < AD; ++c) o[c] += p * vs[j][c];
+    }
+  float* op = out + ((long)b * N + i) * C + h * AD;
+#pragma unroll
+  for (int c = 0; c < AD; c += 4) *reinterpret_cast<f32x4*>(op + c) = f32x4{o[c], o[c + 1], o[c + 2], o[c + 3]};
+}
+
+// backward per query: recompute P, then dq (in place of nothing else to reduce) and the two [B,h,N,M] matrices P and dS that the host
+// turns into dV = P^T dO and dK = scale * dS^T Q with library GEMMs.
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ kv, const float* __restrict__ dout,
+                                                       float* __restrict__ dq, float* __restrict__ P, float* __restrict__ dS, int N, int M, int heads,
+                                                       float scale) {
+  __shared__ float ks[AM][AD], vs[AM][AD];
+  const int b = blockIdx.z, h = blockIdx.y, C = heads * AD;
+  for (int e = threadIdx.x; e < M * AD; e += 256) {
+    const int j = e / AD, c = e % AD;
+    ks[j][c] = kv[(((long)b * M + j) * 2 + 0) * C + h * AD + c];
+    vs[j][c] = kv[(((long)b * M + j) * 2 + 1) * C + h * AD + c];
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float qv[AD], dov[AD], s[AM];
+  const float* qp = q + ((long)b * N + i) * C + h * AD;
+  const float* dp = dout + ((long)b * N + i) * C + h * AD;
+#pragma unroll
+  for (int c = 0; c < AD; c += 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(qp + c), u = *reinterpret_cast<const f32x4*>(dp + c);
+    qv[c] = t[0]; qv[c + 1] = t[1]; qv[c + 2] = t[2]; qv[c + 3] = t[3];
+    dov[c] = u[0]; dov[c + 1] = u[1]; dov[c + 2] = u[2]; dov[c + 3] = u[3];
+  }
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < AM; ++j) {
+    float d = 0.f;
+    if (j < M)
+#pragma unroll
+      for (int c = 0; c < AD; ++c) d += qv[c] * ks[j][c];
+    s[j] = j < M ? d * scale : -3.0e38f;
+    mx = fmaxf(mx, s[j]);
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int j = 0; j < AM; ++j) {
+    s[j] = j < M ? expf(s[j] - mx) : 0.f;
+    den += s[j];
+  }
+  const float inv = 1.f / den;
+  float dsum = 0.f, dpj[AM];
+#pragma unroll
+  for (int j = 0; j < AM; ++j) {
+    s[j] *= inv;
+    float d = 0.f;
+    if (j < M)
+#pragma unroll
+      for (int c = 0; c < AD; ++c) d += dov[c] * vs[j][c];
+    dpj[j] = d;
+    dsum += s[j] * d;
+  }
+  float dqv[AD];
+#pragma unroll
+  for (int c = 0; c < AD; ++c) dqv[c] = 0.f;
+  float* Pr = P + (((long)b * heads + h) * N + i) * M;
+  float* Sr = dS + (((long)b * heads + h) * N + i) * M;
+#pragma unroll
+  for (int j = 0; j < AM; ++j)
+    if (j < M) {
+      const float ds = s[j] * (dpj[j] - dsum);
+      Pr[j] = s[j];
+      Sr[j] = ds;
+#pragma unroll
+      for (int c = 0; c < AD; ++c) dqv[c] += ds * ks[j][c];
+    }
+  float* qo = dq + ((long)b * N + i) * C + h * AD;
+#pragma unroll
+  for (int c = 0; c < AD; c += 4) *reinterpret_cast<f32x4*>(qo + c) = f32x4{dqv[c] * scale, dqv[c + 1] * scale, dqv[c + 2] * scale, dqv[c + 3] * scale};
+}
+
+// ---- depthwise 3x3 (pad 1) + exact GELU on [B,H,W,C], C % 4 == 0; weights transposed to [9][C] -------------------------------------
+__device__ inline float gelu_f(float u) { return 0.5f * u * (1.f + erff(u * 0.70710678118654752f)); }
+__device__ inline float gelu_grad(float u) {
+  return 0.5f * (1.f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * expf(-0.5f * u * u);
+}
+
+__device__ inline f32x4 dw_at(const float* __restrict__ x, const float* __restrict__ w9, const float* __restrict__ bias, int b, int y, int xx, int c,
+                              int H, int W, int C) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, x2 = xx + t % 3 - 1;
+    if (yy >= 0 && yy < H && x2 >= 0 && x2 < W) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long)b * H + yy) * W + x2) * C + c);
+      const f32x4 ww = *reinterpret_cast<const f32x4*>(w9 + t * C + c);
+      a += v * ww;
+    }
+  }
+  return a;
+}
+
+__global__ __launch_bounds__(256) void dwgelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w9, const float* __restrict__ bias,
+                                                         float* __restrict__ y, int B, int H, int W, int C) {
+  const int Q = C / 4;
+  const long total = (long)B * H * W * Q;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % Q) * 4;
+    const long p = i / Q;
+    const int xx = (int)(p % W), yy = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+    const f32x4 u = dw_at(x, w9, bias, b, yy, xx, c, H, W, C);
+    *reinterpret_cast<f32x4*>(y + p * C + c) = f32x4{gelu_f(u[0]), gelu_f(u[1]), gelu_f(u[2]), gelu_f(u[3])};
+  }
+}
+
+// du = dy * gelu'(u) (u recomputed), plus per-workgroup partial sums of dbias and dweight[9] in part[blockIdx][10][C]
+__global__ __launch_bounds__(256) void dwgelu_bwd_du_kernel(const float* __restrict__ x, const float* __restrict__ w9, const float* __restrict__ bias,
+                                                            const float* __restrict__ dy, float* __restrict__ du, float* __restrict__ part, int B, int H,
+                                                            int W, int C) {
+  __shared__ float red[256 * 4];
+  const int Q = C / 4;                       // 256 % Q == 0 or Q % 256 == 0 is NOT required: a thread's channel quad changes per item,
+  const long total = (long)B * H * W * Q;    // so the partial sums are accumulated per (item % Q) through LDS below
+  // each workgroup owns a contiguous range of pixels and loops over channel quads inside: thread t <-> quad (t % Qw), pixel lane t / Qw
+  const int Qw = Q < 256 ? Q : 256;          // quads handled concurrently
+  const int PL = 256 / Qw;                   // pixel lanes
+  const long npix = (long)B * H * W;
+  const long per = (npix + gridDim.x - 1) / gridDim.x;
+  const long p0 = (long)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
+  const int ql = threadIdx.x % Qw, pl = threadIdx.x / Qw;
+  (void)total;
+  for (int qb = 0; qb < Q; qb += Qw) {
+    const int c = (qb + ql) * 4;
+    f32x4 acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (pl < PL && qb + ql < Q)
+      for (long p = p0 + pl; p < p1; p += PL) {
+        const int xx = (int)(p % W), yy = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+        const f32x4 u = dw_at(x, w9, bias, b, yy, xx, c, H, W, C);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + p * C + c);
+        const f32x4 g = f32x4{d[0] * gelu_grad(u[0]), d[1] * gelu_grad(u[1]), d[2] * gelu_grad(u[2]), d[3] * gelu_grad(u[3])};
+        *reinterpret_cast<f32x4*>(du + p * C + c) = g;
+        acc[9] += g;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
+          if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) acc[t] += g * *reinterpret_cast<const f32x4*>(x + (((long)b * H + y2) * W + x2) * C + c);
+        }
+      }
+    for (int t = 0; t < 10; ++t) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[threadIdx.x * 4 + j] = acc[t][j];
+      __syncthreads();
+      for (int o = threadIdx.x; o < Qw * 4 && qb * 4 + o < C; o += 256) {
+        const int qq = o >> 2, j = o & 3;
+        float s = 0.f;
+        for (int l = 0; l < PL; ++l) s += red[(l * Qw + qq) * 4 + j];
+        part[((long)blockIdx.x * 10 + t) * C + qb * 4 + o] = s;
+      }
+    }
+  }
+}
+
+// dx = transpose of the depthwise conv applied to du
+__global__ __launch_bounds__(256) void dw_bwd_dx_kernel(const float* __restrict__ du, const float* __restrict__ w9, float* __restrict__ dx, int B, int H,
+                                                        int W, int C) {
+  const int Q = C / 4;
+  const long total = (long)B * H * W * Q;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % Q) * 4;
+    const long p = i / Q;
+    const int xx = (int)(p % W), yy = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int y2 = yy - (t / 3 - 1), x2 = xx - (t % 3 - 1);      // output pixel that read this input through tap t
+      if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W)
+        a += *reinterpret_cast<const f32x4*>(du + (((long)b * H + y2) * W + x2) * C + c) * *reinterpret_cast<const f32x4*>(w9 + t * C + c);
+    }
+    *reinterpret_cast<f32x4*>(dx + p * C + c) = a;
+  }
+}
+
+inline int grid_cap(long total, int cap) {
+  long b = (total + 255) / 256;
+  if (b < 1) b = 1;
+  return (int)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+extern "C" int hpfg_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long rows, int C, void* stream) {
+  HPFG_ARG_CHECK(x && gamma && beta && y && mean && rstd && rows > 0 && C % 4 == 0 && C >= 4 && C <= 1024, "ln_fwd: bad args (C %% 4 == 0, C <= 1024)");
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, rows, C);
+  return hpfg_launch_status("ln_fwd_kernel");
+}
+
+extern "C" int hpfg_ln_bwd_blocks(long rows) {
+  long b = (rows + 63) / 64;
+  return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+}
+
+extern "C" int hpfg_ln_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma,
+                           float* dbeta, float* partials, long rows, int C, void* stream) {
+  HPFG_ARG_CHECK(x && dy && gamma && mean && rstd && dx && dgamma && dbeta && partials && rows > 0 && C % 4 == 0 && C >= 4 && C <= 1024,
+                 "ln_bwd: bad args");
+  const int nblk = hpfg_ln_bwd_blocks(rows);
+  const int per = (int)((rows + nblk - 1) / nblk);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, dy, gamma, mean, rstd, dx, partials, rows, C, per);
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials, nblk, 2 * C, dgamma);
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials + C, nblk, 2 * C, dbeta);
+  return hpfg_launch_status("ln_bwd_kernel");
+}
+
+extern "C" int hpfg_attn_fwd(const float* q, const float* kv, float* out, int B, int N, int M, int heads, float scale, void* stream) {
+  HPFG_ARG_CHECK(q && kv && out && B > 0 && N > 0 && M > 0 && M <= AM && heads > 0, "attn_fwd: bad args (at most %d keys, head dim %d)", AM, AD);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 255) / 256, heads, B), dim3(256), 0, (hipStream_t)stream, q, kv, out, N, M, heads, scale);
+  return hpfg_launch_status("attn_fwd_kernel");
+}
+
+extern "C" int hpfg_attn_bwd(const float* q, const float* kv, const float* dout, float* dq, float* P, float* dS, int B, int N, int M, int heads,
+                             float scale, void* stream) {
+  HPFG_ARG_CHECK(q && kv && dout && dq && P && dS && B > 0 && N > 0 && M > 0 && M <= AM && heads > 0, "attn_bwd: bad args");
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3((N + 255) / 256, heads, B), dim3(256), 0, (hipStream_t)stream, q, kv, dout, dq, P, dS, N, M, heads, scale);
+  return hpfg_launch_status("attn_bwd_kernel");
+}
+
+extern "C" int hpfg_dwgelu_fwd(const float* x, const float* w9, const float* bias, float* y, int B, int H, int W, int C, void* stream) {
+  HPFG_ARG_CHECK(x && w9 && bias && y && B > 0 && H > 0 && W > 0 && C % 4 == 0 && C >= 4, "dwgelu_fwd: bad args");
+  hipLaunchKernelGGL(dwgelu_fwd_kernel, dim3(grid_cap((long)B * H * W * (C / 4), 8192)), dim3(256), 0, (hipStream_t)stream, x, w9, bias, y, B, H, W, C);
+  return hpfg_launch_status("dwgelu_fwd_kernel");
+}
+
+extern "C" int hpfg_dwgelu_bwd_blocks(int B, int H, int W) {
+  long b = ((long)B * H * W + 127) / 128;
+  return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+
+extern "C" int hpfg_dwgelu_bwd(const float* x, const float* w9, const float* bias, const float* dy, float* du, float* dx, float* dw9, float* dbias,
+                               float* partials, int B, int H, int W, int C, void* stream) {
+  HPFG_ARG_CHECK(x && w9 && bias && dy && du && dx && dw9 && dbias && partials && B > 0 && H > 0 && W > 0 && C % 4 == 0 && C >= 4, "dwgelu_bwd: bad args");
+  const int nblk = hpfg_dwgelu_bwd_blocks(B, H, W);
+  hipLaunchKernelGGL(dwgelu_bwd_du_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, w9, bias, dy, du, partials, B, H, W, C);
+  hipLaunchKernelGGL(dw_bwd_dx_kernel, dim3(grid_cap((long)B * H * W * (C / 4), 8192)), dim3(256), 0, (hipStream_t)stream, du, w9, dx, B, H, W, C);
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(9 * C), dim3(64), 0, (hipStream_t)stream, partials, nblk, 10 * C, dw9);
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials + 9 * C, nblk, 10 * C, dbias);
+  return hpfg_launch_status("dwgelu_bwd_kernel");
+}

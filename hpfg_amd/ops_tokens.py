@@ -1,0 +1,125 @@
+"""Autograd bindings of the token-layout HIP kernels (csrc/tokens.hip) used by the SegFormer branch: LayerNorm, the attention core
+softmax(q k^T) v, and depthwise-3x3 + GELU.  Device tensors only; the library raises if it is missing (no fallback)."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+def _st(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"hpfg_amd.{what} runs on the HIP library only (no CPU fallback)")
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        _need_gpu(x, "layer_norm")
+        lib = L.load()
+        xc = x.contiguous().float()
+        C_ = xc.shape[-1]
+        rows = xc.numel() // C_
+        y = torch.empty_like(xc)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        L.check(lib.hpfg_ln_fwd(L.ptr(xc), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean), L.ptr(rstd), rows, C_, _st(x)), "ln_fwd")
+        ctx.save_for_backward(xc, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        x, gamma, mean, rstd = ctx.saved_tensors
+        C_ = x.shape[-1]
+        rows = x.numel() // C_
+        dyc = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        part = torch.empty(lib.hpfg_ln_bwd_blocks(rows) * 2 * C_, dtype=torch.float32, device=x.device)
+        L.check(lib.hpfg_ln_bwd(L.ptr(x), L.ptr(dyc), L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(part), rows, C_,
+                                _st(x)), "ln_bwd")
+        return dx, dg, db
+
+
+def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    """nn.LayerNorm(C) with eps 1e-5 over the last dimension."""
+    return _LayerNorm.apply(x, gamma, beta)
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, kv, heads, scale):
+        _need_gpu(q, "attention")
+        lib = L.load()
+        qc, kvc = q.contiguous().float(), kv.contiguous().float()
+        B, N, C_ = qc.shape
+        M = kvc.shape[1]
+        out = torch.empty_like(qc)
+        L.check(lib.hpfg_attn_fwd(L.ptr(qc), L.ptr(kvc), L.ptr(out), B, N, M, heads, scale, _st(q)), "attn_fwd")
+        ctx.save_for_backward(qc, kvc)
+        ctx.heads, ctx.scale = heads, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.load()
+        q, kv = ctx.saved_tensors
+        B, N, C_ = q.shape
+        M, h = kv.shape[1], ctx.heads
+        d = C_ // h
+        do = dout.contiguous()
+        dq = torch.empty_like(q)
+        P = torch.empty(B, h, N, M, dtype=torch.float32, device=q.device)
+        dS = torch.empty_like(P)
+        L.check(lib.hpfg_attn_bwd(L.ptr(q), L.ptr(kv), L.ptr(do), L.ptr(dq), L.ptr(P), L.ptr(dS), B, N, M, h, ctx.scale, _st(q)), "attn_bwd")
+        # dV = P^T dO, dK = scale * dS^T Q : plain batched GEMMs (library)
+        doh = do.view(B, N, h, d).permute(0, 2, 1, 3)
+        qh = q.view(B, N, h, d).permute(0, 2, 1, 3)
+        dv = torch.matmul(P.transpose(-1, -2), doh)                    # [B,h,M,d]
+        dk = torch.matmul(dS.transpose(-1, -2), qh) * ctx.scale
+        dkv = torch.stack([dk, dv], 0).permute(1, 3, 0, 2, 4).reshape(B, M, 2 * C_)      # -> [B,M,2,h,d]
+        return dq, dkv, None, None
+
+
+def attention(q: torch.Tensor, kv: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """softmax(scale * q k^T) v per head.  q [B,N,C], kv [B,M,2C] laid out [.., 2, heads, C/heads] (the kv Linear's output); C/heads == 32."""
+    assert q.shape[-1] // heads == 32 and kv.shape[-1] == 2 * q.shape[-1] and kv.shape[1] <= 64
+    return _Attention.apply(q, kv, heads, scale)
+
+
+class _DWGelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_gpu(x, "dwconv_gelu")
+        lib = L.load()
+        xc = x.contiguous().float()
+        B, H, W, C_ = xc.shape
+        w9 = weight.reshape(C_, 9).t().contiguous()
+        y = torch.empty_like(xc)
+        L.check(lib.hpfg_dwgelu_fwd(L.ptr(xc), L.ptr(w9), L.ptr(bias), L.ptr(y), B, H, W, C_, _st(x)), "dwgelu_fwd")
+        ctx.save_for_backward(xc, w9, bias)
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        x, w9, bias = ctx.saved_tensors
+        B, H, W, C_ = x.shape
+        dyc = dy.contiguous()
+        du, dx = torch.empty_like(x), torch.empty_like(x)
+        dw9, db = torch.empty_like(w9), torch.empty_like(bias)
+        part = torch.empty(lib.hpfg_dwgelu_bwd_blocks(B, H, W) * 10 * C_, dtype=torch.float32, device=x.device)
+        L.check(lib.hpfg_dwgelu_bwd(L.ptr(x), L.ptr(w9), L.ptr(bias), L.ptr(dyc), L.ptr(du), L.ptr(dx), L.ptr(dw9), L.ptr(db), L.ptr(part), B, H, W, C_,
+                                    _st(x)), "dwgelu_bwd")
+        return dx, dw9.t().reshape(ctx.wshape), db
+
+
+def dwconv_gelu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """gelu(depthwise_conv3x3(x) + bias) on x [B,H,W,C] (NHWC); weight [C,1,3,3] as nn.Conv2d(C, C, 3, 1, 1, groups=C) holds it."""
+    return _DWGelu.apply(x, weight, bias)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 111
+#define HPFG_VERSION 112
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -236,6 +236,24 @@ int hpfg_uncertainty_mask(const HpfgPredBlocks* pb, int T, int S, int H, int W, 
                           float* uncertainty /* [S,H,W] or NULL */, void* stream);
 /* CutMix image blend x1*(1-M)+xu*M (main.py:149) */
 int hpfg_cutmix_blend(const float* a, const float* b, const float* mask, float* out, long n, void* stream);
+
+/* ---- token-layout ops of the SegFormer branch (model/segformer.py).  [B,N,C] tokens == NHWC pixels. --- */
+/* nn.LayerNorm(C) (eps 1e-5) over the last dimension (segformer.py:107,174,192,195,232-244); mean / rstd [rows] are kept for backward */
+int hpfg_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long rows, int C, void* stream);
+int hpfg_ln_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
+                float* partials /* [hpfg_ln_bwd_blocks(rows)][2][C] */, long rows, int C, void* stream);
+int hpfg_ln_bwd_blocks(long rows);
+/* Attention.forward :122-126 without its Linear layers: out[b,i,h,:] = softmax_j(scale * q[b,i,h,:].k[b,j,h,:]) v[b,j,h,:];
+ * q [B,N,heads,32], kv [B,M,2,heads,32] (the kv Linear's output as reshaped at :120), M <= 64 keys, head dim 32 */
+int hpfg_attn_fwd(const float* q, const float* kv, float* out, int B, int N, int M, int heads, float scale, void* stream);
+/* backward: dq, and the matrices P, dS [B,heads,N,M] from which dV = P^T dO and dK = scale * dS^T Q follow (GEMMs) */
+int hpfg_attn_bwd(const float* q, const float* kv, const float* dout, float* dq, float* P, float* dS, int B, int N, int M, int heads, float scale,
+                  void* stream);
+/* DWConv (3x3 depthwise, pad 1, :139-146) + F.gelu (:156) on [B,H,W,C]; w9 = the [C,1,3,3] weight transposed to [9][C] */
+int hpfg_dwgelu_fwd(const float* x, const float* w9, const float* bias, float* y, int B, int H, int W, int C, void* stream);
+int hpfg_dwgelu_bwd(const float* x, const float* w9, const float* bias, const float* dy, float* du /* scratch [B,H,W,C] */, float* dx, float* dw9,
+                    float* dbias, float* partials /* [hpfg_dwgelu_bwd_blocks()][10][C] */, int B, int H, int W, int C, void* stream);
+int hpfg_dwgelu_bwd_blocks(int B, int H, int W);
 
 /* ---- parameter updates --------------------------------------------------------------------------------- */
 /* torch.optim.SGD(momentum, weight_decay) over a flat parameter buffer (utils/__init__.py:15-16); lr read from device */

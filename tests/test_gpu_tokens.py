@@ -1,0 +1,64 @@
+"""Token-layout kernels of the SegFormer branch (csrc/tokens.hip) against plain torch fp32 on the CPU: values and gradients."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hpfg_amd.ops_tokens import attention, dwconv_gelu, layer_norm
+from tests.helpers import maxerr
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("rows,C_", [((2, 49), 32), ((3, 100), 160), ((1, 7), 256), ((2, 5, 5), 64), ((1, 3), 1024)])
+def test_layer_norm(rows, C_):
+    g = torch.Generator().manual_seed(C_)
+    x = torch.randn(*rows, C_, generator=g) * 2 + 0.5
+    w, b = torch.randn(C_, generator=g), torch.randn(C_, generator=g)
+    dy = torch.randn(*rows, C_, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.layer_norm(xr, (C_,), wr, br).backward(dy)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = layer_norm(xd, wd, bd)
+    y.backward(dy.to(DEV))
+    assert maxerr(y.detach().cpu(), F.layer_norm(x, (C_,), w, b)) < 2e-5
+    assert maxerr(xd.grad.cpu(), xr.grad) < 5e-5
+    assert maxerr(wd.grad.cpu(), wr.grad) < 2e-4 and maxerr(bd.grad.cpu(), br.grad) < 2e-4
+
+
+@pytest.mark.parametrize("B,N,M,heads", [(2, 256, 4, 1), (2, 64, 4, 2), (1, 16, 4, 5), (2, 4, 4, 8), (1, 300, 49, 2), (1, 49, 49, 8), (1, 10, 64, 1)])
+def test_attention_core(B, N, M, heads):
+    g = torch.Generator().manual_seed(N + M)
+    C_ = heads * 32
+    q, kv, do = torch.randn(B, N, C_, generator=g), torch.randn(B, M, 2 * C_, generator=g), torch.randn(B, N, C_, generator=g)
+    scale = 32 ** -0.5
+
+    def ref(q_, kv_):
+        qh = q_.reshape(B, N, heads, 32).permute(0, 2, 1, 3)
+        k, v = kv_.reshape(B, M, 2, heads, 32).permute(2, 0, 3, 1, 4)
+        a = ((qh @ k.transpose(-2, -1)) * scale).softmax(-1)
+        return (a @ v).transpose(1, 2).reshape(B, N, C_)
+    qr, kr = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    ref(qr, kr).backward(do)
+    qd, kd = q.to(DEV).requires_grad_(True), kv.to(DEV).requires_grad_(True)
+    out = attention(qd, kd, heads, scale)
+    out.backward(do.to(DEV))
+    assert maxerr(out.detach().cpu(), ref(q, kv)) < 2e-5
+    assert maxerr(qd.grad.cpu(), qr.grad) < 5e-5 and maxerr(kd.grad.cpu(), kr.grad) < 2e-4
+
+
+@pytest.mark.parametrize("B,H,W,C_", [(2, 16, 16, 128), (2, 8, 8, 256), (1, 4, 4, 640), (2, 2, 2, 1024), (1, 7, 5, 128)])
+def test_dwconv_gelu(B, H, W, C_):
+    g = torch.Generator().manual_seed(C_ + H)
+    x = torch.randn(B, H, W, C_, generator=g)
+    w, b = torch.randn(C_, 1, 3, 3, generator=g) * 0.3, torch.randn(C_, generator=g) * 0.1
+    dy = torch.randn(B, H, W, C_, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.gelu(F.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=1, groups=C_)).permute(0, 2, 3, 1)
+    yr.backward(dy)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = dwconv_gelu(xd, wd, bd)
+    y.backward(dy.to(DEV))
+    assert maxerr(y.detach().cpu(), yr.detach()) < 2e-5
+    assert maxerr(xd.grad.cpu(), xr.grad) < 5e-5
+    assert maxerr(wd.grad.cpu(), wr.grad) < 5e-4 and maxerr(bd.grad.cpu(), br.grad) < 5e-4
