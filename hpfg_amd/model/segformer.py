@@ -1,0 +1,218 @@
+"""SegFormer-B0 for the CTCT cross-teaching branch -- FIRST VERSION.
+
+Same module tree, parameter names and constructor order as the reference's ``model/segformer.py`` (MiT :213-272, SegFormerHead
+:298-320, SegFormer :397-411), so ``state_dict()`` interchanges and a seed gives the same initial weights.  Where the work runs:
+
+* hand-written HIP (``csrc/tokens.hip`` through ``hpfg_amd.ops_tokens``): every LayerNorm, the attention core
+  softmax(q k^T / sqrt(d)) v (at most 64 keys after the spatial reduction, head dim 32), depthwise 3x3 + GELU of the Mix-FFN --
+  forward and backward;
+* library GEMMs (rocBLAS through ``F.linear`` / ``torch.matmul``): q / kv / proj / fc1 / fc2, the spatial-reduction conv (kernel ==
+  stride, so it is a GEMM over non-overlapping patches), the head's per-stage projections, the 1x1 fuse and prediction convs;
+* still plain PyTorch-ROCm ops in this version (to be replaced): im2col (``F.unfold``) in front of the patch-embedding GEMMs, bilinear
+  resizes, the head's BatchNorm (written out as mean / variance arithmetic) + ReLU + Dropout2d, residual adds and the token <-> image
+  reshapes.  No MIOpen call is left in the module: its BatchNorm / convolution backward was measured to be run-to-run
+  non-reproducible here (relative gradient differences up to 2e-3 between identical runs), which a parity-tested path cannot accept.
+
+Tokens are kept as [B, N, C] == NHWC throughout.  Stochastic depth and the head's Dropout2d draw from the torch device generator;
+``external_draws = (drop_path_draws, dropout_mask)`` replays given draws (parity tests against oracle/segformer_ref.py).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..ops_tokens import attention, dwconv_gelu, layer_norm
+
+MIT_SETTINGS = {"B0": [[32, 64, 160, 256], [2, 2, 2, 2]]}
+HEADS, SR = [1, 2, 5, 8], [8, 4, 2, 1]
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, head, sr_ratio):
+        super().__init__()
+        self.head, self.sr_ratio, self.scale = head, sr_ratio, (dim // head) ** -0.5
+        self.q = nn.Linear(dim, dim)
+        self.kv = nn.Linear(dim, dim * 2)
+        self.proj = nn.Linear(dim, dim)
+        if sr_ratio > 1:
+            self.sr = nn.Conv2d(dim, dim, sr_ratio, sr_ratio)
+            self.norm = nn.LayerNorm(dim)
+
+    def forward(self, x, H, W):
+        B, N, C = x.shape
+        q = F.linear(x, self.q.weight, self.q.bias)
+        if self.sr_ratio > 1:
+            s = self.sr_ratio
+            # kernel == stride: the conv is a GEMM over non-overlapping s x s patches, rows ordered (u, v, channel)
+            p = x.view(B, H // s, s, W // s, s, C).permute(0, 1, 3, 2, 4, 5).reshape(B, (H // s) * (W // s), s * s * C)
+            x = F.linear(p, self.sr.weight.permute(0, 2, 3, 1).reshape(C, s * s * C), self.sr.bias)
+            x = layer_norm(x, self.norm.weight, self.norm.bias)
+        kv = F.linear(x, self.kv.weight, self.kv.bias)
+        return F.linear(attention(q, kv, self.head, self.scale), self.proj.weight, self.proj.bias)
+
+
+class DWConv(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, groups=dim)
+
+
+class MLP(nn.Module):
+    def __init__(self, c1, c2):
+        super().__init__()
+        self.fc1 = nn.Linear(c1, c2)
+        self.dwconv = DWConv(c2)
+        self.fc2 = nn.Linear(c2, c1)
+
+    def forward(self, x, H, W):
+        B, N, _ = x.shape
+        h = F.linear(x, self.fc1.weight, self.fc1.bias)
+        h = dwconv_gelu(h.view(B, H, W, -1), self.dwconv.dwconv.weight, self.dwconv.dwconv.bias).view(B, N, -1)
+        return F.linear(h, self.fc2.weight, self.fc2.bias)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, c1=3, c2=32, patch_size=7, stride=4):
+        super().__init__()
+        self.proj = nn.Conv2d(c1, c2, patch_size, stride, patch_size // 2)       # parameter holder (reference names / initialiser)
+        self.norm = nn.LayerNorm(c2)
+        self.k, self.s = patch_size, stride
+
+    def forward(self, x):
+        """x [B,C,H,W] (any strides) -> tokens [B, H'*W', c2]: im2col + GEMM, then the HIP LayerNorm."""
+        B, _, H, W = x.shape
+        Ho, Wo = (H + 2 * (self.k // 2) - self.k) // self.s + 1, (W + 2 * (self.k // 2) - self.k) // self.s + 1
+        cols = F.unfold(x, self.k, padding=self.k // 2, stride=self.s).transpose(1, 2)          # [B, L, C*k*k], rows ordered (c, u, v)
+        t = F.linear(cols, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
+        return layer_norm(t, self.norm.weight, self.norm.bias), Ho, Wo
+
+
+class Block(nn.Module):
+    def __init__(self, dim, head, sr_ratio=1, dpr=0.0):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = Attention(dim, head, sr_ratio)
+        self.dpr = float(dpr)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = MLP(dim, int(dim * 4))
+
+    def _drop_path(self, y, draw):
+        if self.dpr == 0.0 or not self.training:
+            return y
+        kp = 1.0 - self.dpr
+        r = torch.rand((y.shape[0], 1, 1), dtype=y.dtype, device=y.device) if draw is None else draw.to(y.device)
+        return y.div(kp) * (kp + r).floor()
+
+    def forward(self, x, H, W, draws=(None, None)):
+        x = x + self._drop_path(self.attn(layer_norm(x, self.norm1.weight, self.norm1.bias), H, W), draws[0])
+        return x + self._drop_path(self.mlp(layer_norm(x, self.norm2.weight, self.norm2.bias), H, W), draws[1])
+
+
+class MiT(nn.Module):
+    def __init__(self, model_name: str = "B0", in_channels: int = 3):
+        super().__init__()
+        if model_name not in MIT_SETTINGS:
+            raise NotImplementedError(f"MiT-{model_name}: only B0 (the CTCT configuration) is built")
+        embed_dims, depths = MIT_SETTINGS[model_name]
+        self.embed_dims, self.depths = embed_dims, depths
+        self.patch_embed1 = PatchEmbed(in_channels, embed_dims[0], 7, 4)
+        self.patch_embed2 = PatchEmbed(embed_dims[0], embed_dims[1], 3, 2)
+        self.patch_embed3 = PatchEmbed(embed_dims[1], embed_dims[2], 3, 2)
+        self.patch_embed4 = PatchEmbed(embed_dims[2], embed_dims[3], 3, 2)
+        dpr = [x.item() for x in torch.linspace(0, 0.1, sum(depths))]
+        cur = 0
+        for i in range(4):
+            setattr(self, f"block{i + 1}", nn.ModuleList([Block(embed_dims[i], HEADS[i], SR[i], dpr[cur + j]) for j in range(depths[i])]))
+            setattr(self, f"norm{i + 1}", nn.LayerNorm(embed_dims[i]))
+            cur += depths[i]
+
+    def forward(self, x, draws=None):
+        """Returns the four stage outputs as tokens [(tokens [B,N,C], H, W)] (the reference returns them as NCHW images)."""
+        B = x.shape[0]
+        feats, bi = [], 0
+        for i in range(4):
+            x, H, W = getattr(self, f"patch_embed{i + 1}")(x)
+            for blk in getattr(self, f"block{i + 1}"):
+                d = (None, None) if draws is None else (draws[2 * bi], draws[2 * bi + 1])
+                x = blk(x, H, W, d)
+                bi += 1
+            n = getattr(self, f"norm{i + 1}")
+            t = layer_norm(x, n.weight, n.bias)
+            feats.append((t, H, W))
+            x = t.view(B, H, W, -1).permute(0, 3, 1, 2)          # NCHW view of the NHWC tokens for the next patch embedding
+        return feats
+
+
+class FFN(nn.Module):
+    def __init__(self, dim, embed_dim):
+        super().__init__()
+        self.proj = nn.Linear(dim, embed_dim)
+
+
+class ConvModule(nn.Module):
+    def __init__(self, c1, c2):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, 1, bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.activate = nn.ReLU(True)
+
+
+class SegFormerHead(nn.Module):
+    def __init__(self, dims, image_size=(224, 224), embed_dim: int = 256, num_classes: int = 19):
+        super().__init__()
+        self.image_size = list(image_size)
+        for i, dim in enumerate(dims):
+            self.add_module(f"linear_c{i + 1}", FFN(dim, embed_dim))
+        self.linear_fuse = ConvModule(embed_dim * 4, embed_dim)
+        self.linear_pred = nn.Conv2d(embed_dim, num_classes, 1)
+        self.dropout = nn.Dropout2d(0.1)
+
+    def forward(self, feats, dropout_mask=None):
+        B = feats[0][0].shape[0]
+        H, W = feats[0][1], feats[0][2]
+        outs = []
+        for i, (t, h, w) in enumerate(feats):
+            p = getattr(self, f"linear_c{i + 1}").proj
+            y = F.linear(t, p.weight, p.bias)                                      # [B, h*w, E] tokens
+            if i > 0:
+                y = F.interpolate(y.permute(0, 2, 1).reshape(B, -1, h, w), size=(H, W), mode="bilinear", align_corners=False)
+                y = y.flatten(2).transpose(1, 2)
+            outs.append(y)
+        cv, bn = self.linear_fuse.conv, self.linear_fuse.bn
+        z = F.linear(torch.cat(outs[::-1], dim=2), cv.weight.reshape(cv.weight.shape[0], -1))      # 1x1 conv without bias == GEMM over tokens
+        if self.training:                                                          # nn.BatchNorm2d, train mode, written out
+            mu = z.mean((0, 1))
+            var = (z - mu).square().mean((0, 1))
+            with torch.no_grad():
+                n = z.shape[0] * z.shape[1]
+                bn.running_mean.mul_(1 - bn.momentum).add_(mu.detach(), alpha=bn.momentum)
+                bn.running_var.mul_(1 - bn.momentum).add_(var.detach() * (n / max(n - 1, 1)), alpha=bn.momentum)
+                bn.num_batches_tracked += 1
+        else:
+            mu, var = bn.running_mean, bn.running_var
+        seg = torch.relu((z - mu) * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias)
+        if self.training:
+            if dropout_mask is None:                                               # nn.Dropout2d(0.1): whole channels per sample
+                dropout_mask = torch.empty(B, seg.shape[2], 1, 1, device=seg.device).bernoulli_(0.9)
+            seg = seg * dropout_mask.to(seg.device).reshape(B, 1, -1) / 0.9
+        pr = self.linear_pred
+        seg = F.linear(seg, pr.weight.reshape(pr.weight.shape[0], -1), pr.bias).permute(0, 2, 1).reshape(B, -1, H, W)
+        return F.interpolate(seg, size=self.image_size, mode="bilinear", align_corners=False)
+
+
+class SegFormer(nn.Module):
+    def __init__(self, image_size=(224, 224), in_channels=3, num_classes=4, model_name: str = "B0"):
+        super().__init__()
+        self.encoder = MiT(model_name=model_name, in_channels=in_channels)
+        self.decoder = SegFormerHead(self.encoder.embed_dims, image_size=image_size, embed_dim=256, num_classes=num_classes)
+        self.external_draws = None        # (drop_path_draws, dropout_mask): replay given random draws (tests)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("hpfg_amd.SegFormer runs on the GPU only: its LayerNorm / attention / DWConv kernels have no CPU fallback")
+        dp, mask = self.external_draws if self.external_draws is not None else (None, None)
+        return self.decoder(self.encoder(x.float(), dp), mask)
+
+    def val(self, x):
+        return self.forward(x)

@@ -1,0 +1,73 @@
+"""SegFormer-B0 (hpfg_amd/model/segformer.py: HIP LayerNorm / attention / DWConv-GELU + library GEMMs) against the CPU oracle, which is
+itself pinned to the reference module (tests/golden/segformer_b0.npz): same seed-initialised weights, same inputs, same random draws."""
+import numpy as np
+import pytest
+import torch
+
+from hpfg_amd.model import SegFormer, build_model
+from hpfg_amd.utils import AttrDict, Med_Sup_Loss
+from oracle import losses_ref, segformer_ref as S
+from tests.helpers import maxerr
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def test_state_dict_and_golden_fixture(golden_dir):
+    d = np.load(f"{golden_dir}/segformer_b0.npz")
+    torch.manual_seed(1337)
+    m = build_model(AttrDict(model="segformer", in_channels=1, num_classes=4, train_crop_size=[64, 64]))
+    st = S.init_state(1337, 1, 4)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(st.keys())
+    assert all(torch.equal(sd[k], st[k]) for k in st)              # same constructor order, same generator consumption
+    m = m.to(DEV)
+    x, y = torch.from_numpy(d["x"]).to(DEV), torch.from_numpy(d["y"]).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        assert maxerr(m(x).cpu(), torch.from_numpy(d["eval_logits"])) < 1e-3
+    m.train()
+    torch.manual_seed(99)
+    m.external_draws = S.draw_randomness(2)
+    out = m(x)
+    assert maxerr(out.detach().cpu(), torch.from_numpy(d["train_logits"])) < 1e-3
+    loss = Med_Sup_Loss(4)(out, y)
+    assert abs(float(loss) - float(d["loss"])) < 1e-4
+    loss.backward()
+    for k, p in m.named_parameters():
+        ref = d["g:" + k]
+        got = np.array([float(p.grad.sum()), float(p.grad.abs().sum()), float(p.grad.abs().max())])
+        assert np.abs(got - ref).max() < 2e-3 * max(1.0, float(np.abs(ref).max())), (k, got, ref)
+
+
+@pytest.mark.parametrize("size,B", [(224, 2), (96, 3)])
+def test_train_forward_backward_vs_oracle(size, B):
+    """Full-size tokens (3136 / 784 / 196 / 49 queries against 49 keys at 224x224): logits, loss and every gradient tensor."""
+    torch.manual_seed(5)
+    m = SegFormer(image_size=[size, size], in_channels=1, num_classes=4).to(DEV)
+    st = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(size)
+    x = torch.randn(B, 1, size, size, generator=g)
+    y = torch.randint(0, 4, (B, size, size), generator=g)
+    torch.manual_seed(7)
+    dp, mask = S.draw_randomness(B)
+    m.train()
+    m.external_draws = (dp, mask)
+    out = m(x.to(DEV))
+    loss = Med_Sup_Loss(4)(out, y.to(DEV))
+    loss.backward()
+    names = [k for k in st if st[k].is_floating_point() and "running" not in k]
+    for k in names:
+        st[k] = st[k].requires_grad_(True)
+    ro = S.segformer_forward(st, x, True, dp, mask)
+    rl = losses_ref.med_sup_loss(ro, y)
+    rg = dict(zip(names, torch.autograd.grad(rl, [st[k] for k in names])))
+    assert maxerr(out.detach().cpu(), ro.detach()) < 1e-3
+    assert abs(float(loss) - float(rl)) < 1e-4
+    # per-tensor relative L2 error; sums over ~50 000 tokens of sign-alternating terms (LayerNorm gains, biases) carry the most fp32
+    # summation-order noise, so every tensor is held to 5e-3 and the median tensor to 5e-4
+    errs = {k: float((p.grad.cpu().double() - rg[k].double()).norm() / max(1e-6, float(rg[k].double().norm()))) for k, p in m.named_parameters()}
+    bad = {k: v for k, v in errs.items() if not v < 5e-3}
+    assert not bad, bad
+    assert float(np.median(list(errs.values()))) < 5e-4, sorted(((v, k) for k, v in errs.items()), reverse=True)[:40]
+    assert maxerr(m.state_dict()["decoder.linear_fuse.bn.running_var"].cpu(), st["decoder.linear_fuse.bn.running_var"]) < 1e-4
