@@ -4,6 +4,8 @@
   MeanTeacherStep   2017_03_NIPS_Mean-Teacher_ACDC.py:82-113   (Mean_Teacher)
   CPSStep           2021_06_CVPR_CPS_ACDC.py:83-120            (CPS)
   HPFGStep          main.py:125-212              (HPFG, incl. update_ema_variables_backbone main.py:68-76)
+  ICTStep / UAMTStep / CTCTStep   the loop bodies of 2022_02_ISBI_ICT-MedSeg_ACDC.py, 2019_07_MICCAI_Uncertainty_Aware_ACDC.py and
+                    2021_12_MIDL_CTCT_ACDC.py (CTCT) on the same kernels
 
 Each step object owns the optimizer(s) / scheduler(s) built by the reference-compatible factories and exposes
 ``step(batch..., cur_itrs) -> dict of device scalars``.  Nothing in a step synchronises with the host: losses stay on the
@@ -124,7 +126,18 @@ class _StepBase:
     def _reduce_grads(self, *models):
         if self.dp is not None and (self.dp.world_size > 1 or self.dp.force_sync):
             for m in models:
-                self.dp.allreduce_sum(m.flat_grads)
+                if hasattr(m, "flat_grads"):
+                    self.dp.allreduce_sum(m.flat_grads)
+                else:                      # a model without the flat buffers (SegFormer): one flattened exchange, averaged here when the
+                    gs = [p.grad for p in m.parameters() if p.grad is not None]      # optimizer has no gradient scale of its own
+                    flat = torch.cat([g.reshape(-1) for g in gs])
+                    self.dp.allreduce_sum(flat)
+                    if not getattr(self.dp, "sync_bn", True):
+                        flat.div_(self.dp.world_size)
+                    o = 0
+                    for g in gs:
+                        g.copy_(flat[o:o + g.numel()].view_as(g))
+                        o += g.numel()
 
     def _set_grad_scale(self, *optimizers):
         """sync_bn=False: the per-rank losses are means over the local batch, so the summed gradient is averaged over ranks
@@ -448,8 +461,8 @@ class CPSStep(_StepBase):
         self.optimizer2.zero_grad()
         loss.backward()
         self._reduce_grads(self.model1, self.model2)
-        self.optimizer1.step(push_lr=False)
-        self.optimizer2.step(push_lr=False)
+        for o in (self.optimizer1, self.optimizer2):
+            o.step(push_lr=False) if hasattr(o, "push_lr") else o.step()         # FusedSGD reads its lr from the device scalars
         return {"loss": loss.detach(), "parts1": r1.detach(), "parts2": r2.detach(), "logits1": o1.detach(), "logits2": o2.detach()}
 
     def after(self):
@@ -607,6 +620,21 @@ class GraphedStep:
         return self.out
 
 
+class CTCTStep(CPSStep):
+    """Cross teaching between a CNN and a transformer (2021_12_MIDL_CTCT_ACDC.py:117-134): model1 (U-Net, HIP
+    engine, FusedSGD) and model2 (SegFormer, AdamW) see [labelled ; unlabelled]; each is supervised by 0.5*(CE + Dice) on the labelled
+    part and by w * Dice against the OTHER network's arg-max on the unlabelled part.  Same kernels as the CPS step; only the loss
+    weights differ (Dice-only pseudo-supervision, weight w instead of 0.5*w*(CE + Dice))."""
+
+    def host_scalars(self, cur_itrs, cons_w=None):
+        a = self.args
+        w = a.consistency * sigmoid_rampup(cur_itrs // 150, a.consistency_rampup) if cons_w is None else cons_w
+        h = self.sc.host
+        h[S_LR1], h[S_LR2] = self._lr(self.optimizer1), self._lr(self.optimizer2)
+        h[S_COEF_A:S_COEF_A + 5] = torch.tensor([0.5, 0.5, 0.0, w, 0.0])
+        return w
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # Driver loops with the reference's names / signatures (logging and checkpointing kept minimal; evaluation via hpfg_amd.val)
 # ------------------------------------------------------------------------------------------------------------------------
@@ -658,8 +686,8 @@ def Mean_Teacher(model, ema_model, label_loader, unlabel_loader, test_loader, ar
     return torch.stack(log)
 
 
-def CPS(model1, model2, label_loader, unlabel_loader, test_loader, args):
-    st = CPSStep(model1, model2, args, getattr(args, "dp", None))
+def CPS(model1, model2, label_loader, unlabel_loader, test_loader, args, step_cls=None):
+    st = (step_cls or CPSStep)(model1, model2, args, getattr(args, "dp", None))
     model1.train()
     model2.train()
     cur_itrs, log = 0, []
@@ -674,6 +702,11 @@ def CPS(model1, model2, label_loader, unlabel_loader, test_loader, args):
             if cur_itrs >= args.total_itrs:
                 return torch.stack(log)
     return torch.stack(log)
+
+
+def CTCT(model1, model2, label_loader, unlabel_loader, test_loader, args):
+    """Cross teaching between CNN and transformer with the driver's signature (2021_12_MIDL_CTCT_ACDC.py:82)."""
+    return CPS(model1, model2, label_loader, unlabel_loader, test_loader, args, step_cls=CTCTStep)
 
 
 def HPFG(model1, model2, ema_model, label_loader, unlabel_loader, test_loader, args):

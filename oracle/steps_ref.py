@@ -13,6 +13,7 @@ can drive oracle and HIP path with the same scalars.
 """
 from __future__ import annotations
 
+import math
 from typing import Dict, List, Optional
 
 import torch
@@ -176,6 +177,54 @@ def cps_step(st1, st2, bufs1, bufs2, xl, yl, xu, lr1, lr2, cons_w, momentum=0.9,
     sgd_update(st2, g2, bufs2, lr2, momentum, weight_decay)
     return {"loss": float(loss.detach()), "sup": float(sup.detach()), "semi": float(torch.as_tensor(semi).detach()), "logits1": o1.detach(), "logits2": o2.detach(),
             "grads1": g1, "grads2": g2}
+
+
+def adamw_update(st, grads, state, lr: float, weight_decay: float, betas=(0.9, 0.999), eps: float = 1e-8):
+    """torch.optim.AdamW (decoupled weight decay, bias-corrected moments) over a state dict, in place; `state` keeps step / m / v."""
+    state["step"] = state.get("step", 0) + 1
+    t = state["step"]
+    b1, b2 = betas
+    with torch.no_grad():
+        for k, g in grads.items():
+            p = st[k]
+            p.mul_(1.0 - lr * weight_decay)
+            m = state.setdefault("m:" + k, torch.zeros_like(p))
+            v = state.setdefault("v:" + k, torch.zeros_like(p))
+            m.mul_(b1).add_(g, alpha=1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(eps)
+            p.addcdiv_(m, denom, value=-lr / (1 - b1 ** t))
+
+
+def ctct_step(st1, st2, bufs1, adam2, xl, yl, xu, lr1, lr2, cons_w, momentum=0.9, wd1=5e-4, wd2=0.05, masks1=None, draws2=None):
+    """Cross teaching between the U-Net (st1, SGD) and SegFormer-B0 (st2, AdamW), 2021_12_MIDL_CTCT_ACDC.py:117-134.
+    masks1: U-Net dropout masks; draws2: (drop-path draws, Dropout2d mask) of the SegFormer forward."""
+    from . import segformer_ref
+    n1 = _train_state(st1)
+    n2 = [k for k in st2 if st2[k].is_floating_point() and "running" not in k]
+    for k in n2:
+        st2[k] = st2[k].detach().requires_grad_(True)
+    nl = xl.shape[0]
+    x = torch.cat([xl, xu], 0)
+    o1 = unet_ref.unet_forward(st1, x, True, masks1)
+    dp, mask = draws2 if draws2 is not None else (None, None)
+    o2 = segformer_ref.segformer_forward(st2, x, True, dp, mask)
+    s1, s2 = torch.softmax(o1, 1), torch.softmax(o2, 1)
+    loss1 = 0.5 * (losses_ref.cross_entropy(o1[:nl], yl) + losses_ref.dice_loss(s1[:nl], yl.unsqueeze(1)))
+    loss2 = 0.5 * (losses_ref.cross_entropy(o2[:nl], yl) + losses_ref.dice_loss(s2[:nl], yl.unsqueeze(1)))
+    p1, p2 = torch.argmax(s1[nl:].detach(), 1), torch.argmax(s2[nl:].detach(), 1)
+    ps1 = losses_ref.dice_loss(s1[nl:], p2.unsqueeze(1))
+    ps2 = losses_ref.dice_loss(s2[nl:], p1.unsqueeze(1))
+    loss = (loss1 + cons_w * ps1) + (loss2 + cons_w * ps2)
+    gs = torch.autograd.grad(loss, [st1[k] for k in n1] + [st2[k] for k in n2])
+    g1, g2 = dict(zip(n1, gs[:len(n1)])), dict(zip(n2, gs[len(n1):]))
+    _detach_state(st1)
+    for k in n2:
+        st2[k] = st2[k].detach()
+    sgd_update(st1, g1, bufs1, lr1, momentum, wd1)
+    adamw_update(st2, g2, adam2, lr2, wd2)
+    return {"loss": float(loss.detach()), "sup1": float(loss1.detach()), "sup2": float(loss2.detach()), "ps1": float(ps1.detach()), "ps2": float(ps2.detach()),
+            "logits1": o1.detach(), "logits2": o2.detach()}
 
 
 def hpfg_step(st1, st2, ema, bufs1, bufs2, xl, yl, xl1, yl1, xu, cutmix_mask, cur_itrs, lr1, lr2, consistency, rampup,

@@ -71,3 +71,38 @@ def test_train_forward_backward_vs_oracle(size, B):
     assert not bad, bad
     assert float(np.median(list(errs.values()))) < 5e-4, sorted(((v, k) for k, v in errs.items()), reverse=True)[:40]
     assert maxerr(m.state_dict()["decoder.linear_fuse.bn.running_var"].cpu(), st["decoder.linear_fuse.bn.running_var"]) < 1e-4
+
+
+def test_ctct_step_trace(golden_dir):
+    """CTCTStep (U-Net on the HIP engine + SegFormer, SGD + AdamW) against two iterations of the reference's own modules."""
+    from hpfg_amd import engine as E
+    from hpfg_amd.model import UNet
+    from hpfg_amd.train import CTCTStep
+    d = np.load(f"{golden_dir}/trace_ctct.npz")
+    torch.manual_seed(1)
+    m1 = UNet(1, 4)
+    m2 = SegFormer(image_size=[64, 64], in_channels=1, num_classes=4)          # second construction continues the generator, as in the driver
+    m1, m2 = m1.to(DEV), m2.to(DEV)
+    m1.train()
+    m2.train()
+    opt = dict(opt="sgd", lr=0.01, momentum=0.9, weight_decay=5e-4, sched="medical", total_itrs=30000, step_size=1500, warmup_epochs=1, warmup_lr=1e-4,
+               min_lr=1e-6)
+    a = AttrDict(dict(model1=AttrDict(opt), model2=AttrDict(dict(opt, opt="adamW", lr=0.0008, weight_decay=0.05)), consistency=0.1, consistency_rampup=200.0))
+    st = CTCTStep(m1, m2, a)
+    xl, yl, xu = (torch.from_numpy(d[k]).to(DEV) for k in ("xl", "yl", "xu"))
+    rows = []
+    for k in range(2):
+        masks = {}
+        for lvl in range(5):
+            c, h = E.WIDTHS[lvl], 64 >> lvl
+            bits = np.unpackbits(d[f"it{k}_u{lvl}"])[: 4 * c * h * h].reshape(4, c, h, h)
+            masks[E.enc_prefix(lvl) + ".0"] = torch.from_numpy(bits).permute(0, 2, 3, 1).contiguous().to(DEV)
+        m1.external_dropout_masks = masks
+        dp = [None if none else torch.from_numpy(x) for x, none in zip(d[f"it{k}_dp"], d[f"it{k}_dpnone"])]
+        m2.external_draws = (dp, torch.from_numpy(d[f"it{k}_mask"]))
+        r = st.step(xl, yl, xu, k + 1, cons_w=float(d["cons_w"]))
+        p1, p2 = r["parts1"].cpu(), r["parts2"].cpu()
+        rows.append([float(r["loss"]), 0.5 * float(p1[1]) + 0.5 * float(p1[2]), 0.5 * float(p2[1]) + 0.5 * float(p2[2]), float(p1[4]), float(p2[4])])
+    assert np.abs(np.array(rows) - d["losses"]).max() < 1e-3, (rows, d["losses"])
+    assert maxerr(r["logits1"].cpu(), torch.from_numpy(d["logits1_last"])) < 1e-3
+    assert maxerr(r["logits2"].cpu(), torch.from_numpy(d["logits2_last"])) < 1e-3

@@ -183,6 +183,28 @@ def test_segformer_oracle_matches_reference_fixture(golden_dir):
         assert np.abs(got - ref).max() < 1e-4 * max(1.0, float(np.abs(ref).max())), k
 
 
+def _ctct_draws(d, k):
+    dp = [None if none else torch.from_numpy(x) for x, none in zip(d[f"it{k}_dp"], d[f"it{k}_dpnone"])]
+    return dp, torch.from_numpy(d[f"it{k}_mask"])
+
+
+def test_ctct_trace(golden_dir):
+    """U-Net + SegFormer cross teaching (2021_12_MIDL_CTCT_ACDC.py:117-134): two iterations of the reference's own modules."""
+    from oracle import segformer_ref as S
+    d = np.load(f"{golden_dir}/trace_ctct.npz")
+    st1 = unet_ref.init_state(1, 1, 4)
+    st2 = S.init_state(None, 1, 4)
+    bufs1, adam2 = {}, {}
+    xl, yl, xu = torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xu"])
+    rows = []
+    for k in range(2):
+        r = steps_ref.ctct_step(st1, st2, bufs1, adam2, xl, yl, xu, laws_ref.medical_lr(k + 1, 0.01, 30000), laws_ref.medical_lr(k + 1, 0.0008, 30000),
+                                float(d["cons_w"]), 0.9, 5e-4, 0.05, _unpack_masks(d, f"it{k}_u", 4, 64), _ctct_draws(d, k))
+        rows.append([r["loss"], r["sup1"], r["sup2"], r["ps1"], r["ps2"]])
+    assert np.abs(np.array(rows) - d["losses"]).max() < 3e-5
+    assert float((r["logits2"] - torch.from_numpy(d["logits2_last"])).abs().max()) < 1e-4
+
+
 def test_cps_and_hpfg_traces(golden_dir):
     d = np.load(f"{golden_dir}/trace_cps.npz")
     torch.manual_seed(1337)

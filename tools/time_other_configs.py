@@ -1,6 +1,6 @@
 """Step times of the other BASELINE.json workloads on one GPU (not bench lines: parity-test configurations, timed for DESIGN.md).
 
-cfg0 supervised U-Net 8 x 224^2; cfg2 HPFG (two U-Net+ students + EMA teacher, 16 + 16 x 224^2); cfg3 CPS (two U-Nets, 32 + 32 x 96^2 RGB).
+cfg0 supervised U-Net 8 x 224^2; cfg2 HPFG (two U-Net+ students + EMA teacher, 16 + 16 x 224^2); cfg3 CPS (two U-Nets, 32 + 32 x 96^2 RGB); cfg4 CTCT (U-Net + SegFormer-B0, 8 + 24 x 224^2).
 Eager launches and, where the step captures, the hipGraph replay.
 """
 import os
@@ -78,3 +78,19 @@ m1.train(), m2.train()
 xl, yl = synth_batch(8, 32, 96, 96, 3, 2, 12)
 xu, _ = synth_batch(9, 32, 96, 96, 3, 2, 12)
 report("cfg3 CPS U-Net x2, 32 + 32 x 96^2 RGB", 64, CPSStep(m1, m2, a), tuple(t.to(DEV) for t in (xl, yl, xu)))
+del m1, m2
+torch.cuda.empty_cache()
+from hpfg_amd.train import CTCTStep  # noqa: E402
+a = cfg("ctct_unet_segformer_30k_224x224_ACDC.yaml")
+torch.manual_seed(a.seed)
+m1, m2 = build_model(a.model1).to(DEV), build_model(a.model2).to(DEV)
+m1.train(), m2.train()
+xl, yl = synth_batch(10, 8, 224, 224, 1, 4, 32)
+xu, _ = synth_batch(11, 24, 224, 224, 1, 4, 32)
+report("cfg4 CTCT U-Net + SegFormer-B0, 8 + 24 x 224^2", 32, CTCTStep(m1, m2, a), tuple(t.to(DEV) for t in (xl, yl, xu)))
+m2.eval()
+xe = torch.randn(32, 1, 224, 224, device=DEV)
+def fwd(k):
+    with torch.no_grad():
+        m2(xe)
+print(f"SegFormer-B0 alone, eval forward of 32 x 224^2: {timeit(fwd):.3f} ms", flush=True)
