@@ -66,7 +66,8 @@ def test_train_forward_backward_vs_oracle(size, B):
     assert abs(float(loss) - float(rl)) < 1e-4
     # per-tensor relative L2 error; sums over ~50 000 tokens of sign-alternating terms (LayerNorm gains, biases) carry the most fp32
     # summation-order noise, so every tensor is held to 5e-3 and the median tensor to 5e-4
-    errs = {k: float((p.grad.cpu().double() - rg[k].double()).norm() / max(1e-6, float(rg[k].double().norm()))) for k, p in m.named_parameters()}
+    # (the biases in front of the head's BatchNorm have an exactly zero gradient: both sides hold ~1e-8 of rounding noise, hence the floor)
+    errs = {k: float((p.grad.cpu().double() - rg[k].double()).norm() / max(1e-5, float(rg[k].double().norm()))) for k, p in m.named_parameters()}
     bad = {k: v for k, v in errs.items() if not v < 5e-3}
     assert not bad, bad
     assert float(np.median(list(errs.values()))) < 5e-4, sorted(((v, k) for k, v in errs.items()), reverse=True)[:40]
