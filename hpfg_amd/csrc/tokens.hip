@@ -410,8 +410,8 @@ extern "C" int hpfg_dwgelu_fwd(const float* x, const float* w9, const float* bia
 }
 
 extern "C" int hpfg_dwgelu_bwd_blocks(int B, int H, int W) {
-  long b = ((long)B * H * W + 127) / 128;
-  return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+  long b = ((long)B * H * W + 31) / 32;            // >= 8 workgroups per CU at the 56x56 stage: the pass is latency bound with fewer
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
 extern "C" int hpfg_dwgelu_bwd(const float* x, const float* w9, const float* bias, const float* dy, float* du, float* dx, float* dw9, float* dbias,
