@@ -359,6 +359,68 @@ __global__ __launch_bounds__(256) void dw_bwd_dx_kernel(const float* __restrict_
   }
 }
 
+// ---- bilinear resize, align_corners=False (F.interpolate in SegFormerHead.forward :314,319), NHWC, C % 4 == 0 ------------------------
+// source coordinate of output o: max(0, (o + 0.5) * in/out - 0.5); taps i0 = floor, i1 = min(i0 + 1, in - 1), weight of i1 = frac
+__device__ inline void rs_src(int o, float scale, int n_in, int& i0, int& i1, float& w1) {
+  float s = ((float)o + 0.5f) * scale - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i0 = i0 > n_in - 1 ? n_in - 1 : i0;
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  w1 = s - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int h, int w, int H, int W, int C,
+                                                         float sy, float sx) {
+  const int Q = C / 4;
+  const long total = (long)B * H * W * Q;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % Q) * 4;
+    const long p = i / Q;
+    const int X = (int)(p % W), Y = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+    int y0, y1, x0, x1;
+    float wy, wx;
+    rs_src(Y, sy, h, y0, y1, wy);
+    rs_src(X, sx, w, x0, x1, wx);
+    const float* base = x + (long)b * h * w * C + c;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(base + ((long)y0 * w + x0) * C), bb = *reinterpret_cast<const f32x4*>(base + ((long)y0 * w + x1) * C);
+    const f32x4 cc = *reinterpret_cast<const f32x4*>(base + ((long)y1 * w + x0) * C), d = *reinterpret_cast<const f32x4*>(base + ((long)y1 * w + x1) * C);
+    const f32x4 top = a + (bb - a) * wx, bot = cc + (d - cc) * wx;
+    *reinterpret_cast<f32x4*>(y + p * C + c) = top + (bot - top) * wy;
+  }
+}
+
+// backward as a gather (no atomics: reproducible): a source pixel sums, over the outputs whose two taps per axis include it, the
+// matching weights.  Candidates per axis: outputs [ (i - 1) * out/in , (i + 2) * out/in ).
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int h, int w, int H, int W, int C,
+                                                         float sy, float sx) {
+  const int Q = C / 4;
+  const long total = (long)B * h * w * Q;
+  const int ry = (H + h - 1) / h, rx = (W + w - 1) / w;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % Q) * 4;
+    const long p = i / Q;
+    const int xi = (int)(p % w), yi = (int)((p / w) % h), b = (int)(p / ((long)w * h));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int Y0 = max(0, (yi - 1) * ry), Y1 = min(H, (yi + 2) * ry), X0 = max(0, (xi - 1) * rx), X1 = min(W, (xi + 2) * rx);
+    for (int Y = Y0; Y < Y1; ++Y) {
+      int y0, y1;
+      float wy;
+      rs_src(Y, sy, h, y0, y1, wy);
+      const float fy = (y0 == yi ? 1.f - wy : 0.f) + (y1 == yi ? wy : 0.f);
+      if (fy == 0.f) continue;
+      for (int X = X0; X < X1; ++X) {
+        int x0, x1;
+        float wx;
+        rs_src(X, sx, w, x0, x1, wx);
+        const float fx = (x0 == xi ? 1.f - wx : 0.f) + (x1 == xi ? wx : 0.f);
+        if (fx != 0.f) acc += *reinterpret_cast<const f32x4*>(dy + (((long)b * H + Y) * W + X) * C + c) * (fy * fx);
+      }
+    }
+    *reinterpret_cast<f32x4*>(dx + p * C + c) = acc;
+  }
+}
+
 inline int grid_cap(long total, int cap) {
   long b = (total + 255) / 256;
   if (b < 1) b = 1;
@@ -423,4 +485,18 @@ extern "C" int hpfg_dwgelu_bwd(const float* x, const float* w9, const float* bia
   hipLaunchKernelGGL(col_reduce_kernel, dim3(9 * C), dim3(64), 0, (hipStream_t)stream, partials, nblk, 10 * C, dw9);
   hipLaunchKernelGGL(col_reduce_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials + 9 * C, nblk, 10 * C, dbias);
   return hpfg_launch_status("dwgelu_bwd_kernel");
+}
+
+extern "C" int hpfg_resize_bilinear_fwd(const float* x, float* y, int B, int h, int w, int H, int W, int C, void* stream) {
+  HPFG_ARG_CHECK(x && y && B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C % 4 == 0 && C >= 4, "resize_bilinear_fwd: bad args");
+  hipLaunchKernelGGL(resize_fwd_kernel, dim3(grid_cap((long)B * H * W * (C / 4), 8192)), dim3(256), 0, (hipStream_t)stream, x, y, B, h, w, H, W, C,
+                     (float)h / (float)H, (float)w / (float)W);
+  return hpfg_launch_status("resize_fwd_kernel");
+}
+
+extern "C" int hpfg_resize_bilinear_bwd(const float* dy, float* dx, int B, int h, int w, int H, int W, int C, void* stream) {
+  HPFG_ARG_CHECK(dy && dx && B > 0 && h > 0 && w > 0 && H >= h && W >= w && C % 4 == 0 && C >= 4, "resize_bilinear_bwd: bad args (upsampling only)");
+  hipLaunchKernelGGL(resize_bwd_kernel, dim3(grid_cap((long)B * h * w * (C / 4), 8192)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, h, w, H, W, C,
+                     (float)h / (float)H, (float)w / (float)W);
+  return hpfg_launch_status("resize_bwd_kernel");
 }

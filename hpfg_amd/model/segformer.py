@@ -8,9 +8,9 @@ Same module tree, parameter names and constructor order as the reference's ``mod
   forward and backward;
 * library GEMMs (rocBLAS through ``F.linear`` / ``torch.matmul``): q / kv / proj / fc1 / fc2, the spatial-reduction conv (kernel ==
   stride, so it is a GEMM over non-overlapping patches), the head's per-stage projections, the 1x1 fuse and prediction convs;
-* still plain PyTorch-ROCm ops in this version (to be replaced): im2col (``F.unfold``) in front of the patch-embedding GEMMs, bilinear
-  resizes, the head's BatchNorm (written out as mean / variance arithmetic) + ReLU + Dropout2d, residual adds and the token <-> image
-  reshapes.  No MIOpen call is left in the module: its BatchNorm / convolution backward was measured to be run-to-run
+* still plain PyTorch-ROCm ops in this version (to be replaced): im2col (``F.unfold``) in front of the patch-embedding GEMMs,
+  the head's BatchNorm (written out as mean / variance arithmetic) + ReLU + Dropout2d, residual adds and the token <-> image
+  reshapes (the bilinear resizes of the head are HIP too, `resize_bilinear`).  No MIOpen call is left in the module: its BatchNorm / convolution backward was measured to be run-to-run
   non-reproducible here (relative gradient differences up to 2e-3 between identical runs), which a parity-tested path cannot accept.
 
 Tokens are kept as [B, N, C] == NHWC throughout.  Stochastic depth and the head's Dropout2d draw from the torch device generator;
@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops_tokens import attention, dwconv_gelu, layer_norm
+from ..ops_tokens import attention, dwconv_gelu, layer_norm, resize_bilinear
 
 MIT_SETTINGS = {"B0": [[32, 64, 160, 256], [2, 2, 2, 2]]}
 HEADS, SR = [1, 2, 5, 8], [8, 4, 2, 1]
@@ -176,8 +176,7 @@ class SegFormerHead(nn.Module):
             p = getattr(self, f"linear_c{i + 1}").proj
             y = F.linear(t, p.weight, p.bias)                                      # [B, h*w, E] tokens
             if i > 0:
-                y = F.interpolate(y.permute(0, 2, 1).reshape(B, -1, h, w), size=(H, W), mode="bilinear", align_corners=False)
-                y = y.flatten(2).transpose(1, 2)
+                y = resize_bilinear(y.view(B, h, w, -1), H, W).view(B, H * W, -1)          # HIP, NHWC
             outs.append(y)
         cv, bn = self.linear_fuse.conv, self.linear_fuse.bn
         z = F.linear(torch.cat(outs[::-1], dim=2), cv.weight.reshape(cv.weight.shape[0], -1))      # 1x1 conv without bias == GEMM over tokens
@@ -197,8 +196,10 @@ class SegFormerHead(nn.Module):
                 dropout_mask = torch.empty(B, seg.shape[2], 1, 1, device=seg.device).bernoulli_(0.9)
             seg = seg * dropout_mask.to(seg.device).reshape(B, 1, -1) / 0.9
         pr = self.linear_pred
-        seg = F.linear(seg, pr.weight.reshape(pr.weight.shape[0], -1), pr.bias).permute(0, 2, 1).reshape(B, -1, H, W)
-        return F.interpolate(seg, size=self.image_size, mode="bilinear", align_corners=False)
+        seg = F.linear(seg, pr.weight.reshape(pr.weight.shape[0], -1), pr.bias)
+        if seg.shape[-1] % 4 == 0:                                                 # HIP resize on NHWC; the result is viewed as NCHW
+            return resize_bilinear(seg.view(B, H, W, -1), self.image_size[0], self.image_size[1]).permute(0, 3, 1, 2)
+        return F.interpolate(seg.permute(0, 2, 1).reshape(B, -1, H, W), size=self.image_size, mode="bilinear", align_corners=False)
 
 
 class SegFormer(nn.Module):

@@ -123,3 +123,28 @@ class _DWGelu(torch.autograd.Function):
 def dwconv_gelu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """gelu(depthwise_conv3x3(x) + bias) on x [B,H,W,C] (NHWC); weight [C,1,3,3] as nn.Conv2d(C, C, 3, 1, 1, groups=C) holds it."""
     return _DWGelu.apply(x, weight, bias)
+
+
+class _Resize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, W):
+        _need_gpu(x, "resize_bilinear")
+        xc = x.contiguous().float()
+        B, h, w, C_ = xc.shape
+        y = torch.empty(B, H, W, C_, dtype=torch.float32, device=x.device)
+        L.check(L.load().hpfg_resize_bilinear_fwd(L.ptr(xc), L.ptr(y), B, h, w, H, W, C_, _st(x)), "resize_fwd")
+        ctx.shape = (B, h, w, H, W, C_)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, h, w, H, W, C_ = ctx.shape
+        dyc = dy.contiguous()
+        dx = torch.empty(B, h, w, C_, dtype=torch.float32, device=dy.device)
+        L.check(L.load().hpfg_resize_bilinear_bwd(L.ptr(dyc), L.ptr(dx), B, h, w, H, W, C_, _st(dy)), "resize_bwd")
+        return dx, None, None
+
+
+def resize_bilinear(x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """F.interpolate(..., size=(H, W), mode="bilinear", align_corners=False) on NHWC x [B,h,w,C] (C % 4 == 0), upsampling."""
+    return _Resize.apply(x, H, W)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 112
+#define HPFG_VERSION 113
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -254,6 +254,10 @@ int hpfg_dwgelu_fwd(const float* x, const float* w9, const float* bias, float* y
 int hpfg_dwgelu_bwd(const float* x, const float* w9, const float* bias, const float* dy, float* du /* scratch [B,H,W,C] */, float* dx, float* dw9,
                     float* dbias, float* partials /* [hpfg_dwgelu_bwd_blocks()][10][C] */, int B, int H, int W, int C, void* stream);
 int hpfg_dwgelu_bwd_blocks(int B, int H, int W);
+/* F.interpolate(mode="bilinear", align_corners=False) of SegFormerHead.forward (:314,319) on NHWC [B,h,w,C] -> [B,H,W,C]; backward is a
+ * gather over the outputs that tap a source pixel (no atomics), upsampling only */
+int hpfg_resize_bilinear_fwd(const float* x, float* y, int B, int h, int w, int H, int W, int C, void* stream);
+int hpfg_resize_bilinear_bwd(const float* dy, float* dx, int B, int h, int w, int H, int W, int C, void* stream);
 
 /* ---- parameter updates --------------------------------------------------------------------------------- */
 /* torch.optim.SGD(momentum, weight_decay) over a flat parameter buffer (utils/__init__.py:15-16); lr read from device */

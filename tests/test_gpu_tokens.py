@@ -3,7 +3,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from hpfg_amd.ops_tokens import attention, dwconv_gelu, layer_norm
+from hpfg_amd.ops_tokens import attention, dwconv_gelu, layer_norm, resize_bilinear
 from tests.helpers import maxerr
 
 pytestmark = pytest.mark.gpu
@@ -62,3 +62,19 @@ def test_dwconv_gelu(B, H, W, C_):
     assert maxerr(y.detach().cpu(), yr.detach()) < 2e-5
     assert maxerr(xd.grad.cpu(), xr.grad) < 5e-5
     assert maxerr(wd.grad.cpu(), wr.grad) < 5e-4 and maxerr(bd.grad.cpu(), br.grad) < 5e-4
+
+
+@pytest.mark.parametrize("B,h,w,H,W,C_", [(2, 8, 8, 16, 16, 256), (2, 4, 4, 16, 16, 256), (1, 2, 2, 16, 16, 256), (2, 14, 14, 56, 56, 4), (1, 7, 7, 56, 56, 8),
+                                          (1, 5, 3, 20, 12, 4)])
+def test_resize_bilinear(B, h, w, H, W, C_):
+    g = torch.Generator().manual_seed(h * 100 + H)
+    x = torch.randn(B, h, w, C_, generator=g)
+    dy = torch.randn(B, H, W, C_, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr.permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    yr.backward(dy)
+    xd = x.to(DEV).requires_grad_(True)
+    y = resize_bilinear(xd, H, W)
+    y.backward(dy.to(DEV))
+    assert maxerr(y.detach().cpu(), yr.detach()) < 1e-5
+    assert maxerr(xd.grad.cpu(), xr.grad) < 2e-5
