@@ -421,6 +421,122 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
   }
 }
 
+// ---- BatchNorm (train) + ReLU + channel dropout over tokens [R, C] (ConvModule + Dropout2d of the head, segformer.py:288-296,307,318) ----
+// thread t <-> channel quad t % Q and row lane t / Q; part[blockIdx][2][C] partial sums, reduced in a fixed order by col_reduce_kernel
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ x, long R, int C, float* __restrict__ part, int rows_per_wg) {
+  __shared__ float red[256 * 8];
+  const int Q = C >> 2, q = threadIdx.x % Q, pl = threadIdx.x / Q, PL = 256 / Q, c = q * 4;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+  const long r0 = (long)blockIdx.x * rows_per_wg;
+  if (pl < PL)
+    for (long r = r0 + pl; r < r0 + rows_per_wg && r < R; r += PL) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + c);
+      a += v;
+      b += v * v;
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[threadIdx.x * 8 + j] = a[j];
+    red[threadIdx.x * 8 + 4 + j] = b[j];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * C; o += 256) {
+    const int which = o / C, cc = o % C, qq = cc >> 2, j = cc & 3;
+    float acc = 0.f;
+    for (int l = 0; l < PL; ++l) acc += red[(l * Q + qq) * 8 + which * 4 + j];
+    part[((long)blockIdx.x * 2 + which) * C + cc] = acc;
+  }
+}
+
+// y = relu((x - mean) * rstd * gamma + beta) * mask[row / rows_per_image][c] * inv_keep
+__global__ __launch_bounds__(256) void bnrelu_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mask, float inv_keep, long rows_per_image, float* __restrict__ y,
+                                                           long R, int C) {
+  const int Q = C >> 2;
+  const long total = R * Q;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % Q) * 4;
+    const long r = i / Q;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 m = {inv_keep, inv_keep, inv_keep, inv_keep};
+    if (mask) m = *reinterpret_cast<const f32x4*>(mask + (r / rows_per_image) * C + c) * inv_keep;
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaxf((v[j] - mu[j]) * rs[j] * g[j] + be[j], 0.f) * (mask ? m[j] : 1.f);
+    *reinterpret_cast<f32x4*>(y + r * C + c) = o;
+  }
+}
+
+// backward sums: g = dy * mask * inv_keep * [bn(x) > 0];  part[blk][0] = sum g, part[blk][1] = sum g * xhat
+__global__ __launch_bounds__(256) void bnrelu_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ mask, float inv_keep,
+                                                               long rows_per_image, long R, int C, float* __restrict__ part, int rows_per_wg) {
+  __shared__ float red[256 * 8];
+  const int Q = C >> 2, q = threadIdx.x % Q, pl = threadIdx.x / Q, PL = 256 / Q, c = q * 4;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+  const long r0 = (long)blockIdx.x * rows_per_wg;
+  if (pl < PL)
+    for (long r = r0 + pl; r < r0 + rows_per_wg && r < R; r += PL) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + c), d = *reinterpret_cast<const f32x4*>(dy + r * C + c);
+      f32x4 m = {1.f, 1.f, 1.f, 1.f};
+      if (mask) m = *reinterpret_cast<const f32x4*>(mask + (r / rows_per_image) * C + c) * inv_keep;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (v[j] - mu[j]) * rs[j];
+        const float g = xh * ga[j] + be[j] > 0.f ? d[j] * m[j] : 0.f;
+        a[j] += g;
+        b[j] += g * xh;
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[threadIdx.x * 8 + j] = a[j];
+    red[threadIdx.x * 8 + 4 + j] = b[j];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * C; o += 256) {
+    const int which = o / C, cc = o % C, qq = cc >> 2, j = cc & 3;
+    float acc = 0.f;
+    for (int l = 0; l < PL; ++l) acc += red[(l * Q + qq) * 8 + which * 4 + j];
+    part[((long)blockIdx.x * 2 + which) * C + cc] = acc;
+  }
+}
+
+// dx = gamma * rstd * (g - sum_g / R - xhat * sum_gx / R)
+__global__ __launch_bounds__(256) void bnrelu_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ mask, float inv_keep,
+                                                               long rows_per_image, const float* __restrict__ sums /* [2][C] */, float* __restrict__ dx,
+                                                               long R, int C) {
+  const int Q = C >> 2;
+  const long total = R * Q;
+  const float invR = 1.f / (float)R;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % Q) * 4;
+    const long r = i / Q;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + c), d = *reinterpret_cast<const f32x4*>(dy + r * C + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + c), s2 = *reinterpret_cast<const f32x4*>(sums + C + c);
+    f32x4 m = {1.f, 1.f, 1.f, 1.f};
+    if (mask) m = *reinterpret_cast<const f32x4*>(mask + (r / rows_per_image) * C + c) * inv_keep;
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (v[j] - mu[j]) * rs[j];
+      const float g = xh * ga[j] + be[j] > 0.f ? d[j] * m[j] : 0.f;
+      o[j] = ga[j] * rs[j] * (g - s1[j] * invR - xh * s2[j] * invR);
+    }
+    *reinterpret_cast<f32x4*>(dx + r * C + c) = o;
+  }
+}
+
 inline int grid_cap(long total, int cap) {
   long b = (total + 255) / 256;
   if (b < 1) b = 1;
@@ -499,4 +615,41 @@ extern "C" int hpfg_resize_bilinear_bwd(const float* dy, float* dx, int B, int h
   hipLaunchKernelGGL(resize_bwd_kernel, dim3(grid_cap((long)B * h * w * (C / 4), 8192)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, h, w, H, W, C,
                      (float)h / (float)H, (float)w / (float)W);
   return hpfg_launch_status("resize_bwd_kernel");
+}
+
+extern "C" int hpfg_tok_stat_blocks(long R) {
+  long b = (R + 63) / 64;
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+static int tok_c_ok(int C) { return C % 4 == 0 && C >= 4 && C <= 1024 && 256 % (C / 4) == 0; }
+
+/* sums[0][C] = sum_r x, sums[1][C] = sum_r x^2 */
+extern "C" int hpfg_tok_col_stats(const float* x, long R, int C, float* partials, float* sums, void* stream) {
+  HPFG_ARG_CHECK(x && partials && sums && R > 0 && tok_c_ok(C), "tok_col_stats: bad args (C/4 must divide 256)");
+  const int nblk = hpfg_tok_stat_blocks(R);
+  hipLaunchKernelGGL(col_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, R, C, partials, (int)((R + nblk - 1) / nblk));
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(2 * C), dim3(64), 0, (hipStream_t)stream, partials, nblk, 2 * C, sums);
+  return hpfg_launch_status("col_stats_kernel");
+}
+
+extern "C" int hpfg_bnrelu_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* mask,
+                                 float inv_keep, long rows_per_image, float* y, long R, int C, void* stream) {
+  HPFG_ARG_CHECK(x && mean && rstd && gamma && beta && y && R > 0 && C % 4 == 0 && rows_per_image > 0, "bnrelu_apply: bad args");
+  hipLaunchKernelGGL(bnrelu_apply_kernel, dim3(grid_cap(R * (C / 4), 8192)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, mask,
+                     inv_keep, rows_per_image, y, R, C);
+  return hpfg_launch_status("bnrelu_apply_kernel");
+}
+
+extern "C" int hpfg_bnrelu_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                               const float* mask, float inv_keep, long rows_per_image, float* dx, float* partials, float* sums, long R, int C,
+                               void* stream) {
+  HPFG_ARG_CHECK(x && dy && mean && rstd && gamma && beta && dx && partials && sums && R > 0 && tok_c_ok(C) && rows_per_image > 0, "bnrelu_bwd: bad args");
+  const int nblk = hpfg_tok_stat_blocks(R);
+  hipLaunchKernelGGL(bnrelu_bwd_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, dy, mean, rstd, gamma, beta, mask, inv_keep,
+                     rows_per_image, R, C, partials, (int)((R + nblk - 1) / nblk));
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(2 * C), dim3(64), 0, (hipStream_t)stream, partials, nblk, 2 * C, sums);
+  hipLaunchKernelGGL(bnrelu_bwd_apply_kernel, dim3(grid_cap(R * (C / 4), 8192)), dim3(256), 0, (hipStream_t)stream, x, dy, mean, rstd, gamma, beta, mask,
+                     inv_keep, rows_per_image, sums, dx, R, C);
+  return hpfg_launch_status("bnrelu_bwd_kernel");
 }

@@ -3,15 +3,16 @@
 Same module tree, parameter names and constructor order as the reference's ``model/segformer.py`` (MiT :213-272, SegFormerHead
 :298-320, SegFormer :397-411), so ``state_dict()`` interchanges and a seed gives the same initial weights.  Where the work runs:
 
-* hand-written HIP (``csrc/tokens.hip`` through ``hpfg_amd.ops_tokens``): every LayerNorm, the attention core
-  softmax(q k^T / sqrt(d)) v (at most 64 keys after the spatial reduction, head dim 32), depthwise 3x3 + GELU of the Mix-FFN --
-  forward and backward;
+* hand-written HIP (``csrc/tokens.hip`` through ``hpfg_amd.ops_tokens``), forward and backward: every LayerNorm, the attention core
+  softmax(q k^T / sqrt(d)) v (at most 64 keys after the spatial reduction, head dim 32), depthwise 3x3 + GELU of the Mix-FFN, the
+  head's bilinear resizes and its BatchNorm(train) + ReLU + Dropout2d;
 * library GEMMs (rocBLAS through ``F.linear`` / ``torch.matmul``): q / kv / proj / fc1 / fc2, the spatial-reduction conv (kernel ==
-  stride, so it is a GEMM over non-overlapping patches), the head's per-stage projections, the 1x1 fuse and prediction convs;
-* still plain PyTorch-ROCm ops in this version (to be replaced): im2col (``F.unfold``) in front of the patch-embedding GEMMs,
-  the head's BatchNorm (written out as mean / variance arithmetic) + ReLU + Dropout2d, residual adds and the token <-> image
-  reshapes (the bilinear resizes of the head are HIP too, `resize_bilinear`).  No MIOpen call is left in the module: its BatchNorm / convolution backward was measured to be run-to-run
-  non-reproducible here (relative gradient differences up to 2e-3 between identical runs), which a parity-tested path cannot accept.
+  stride, so it is a GEMM over non-overlapping patches), the patch embeddings (after im2col), the head's per-stage projections, the
+  1x1 fuse and prediction convs, dK / dV of the attention backward;
+* still plain PyTorch-ROCm ops in this version (to be replaced): im2col (``F.unfold``), the channel concat of the head, residual adds,
+  the drop-path scaling and the token <-> image reshapes.
+No MIOpen call is left in the module: its BatchNorm / convolution backward was measured to be run-to-run non-reproducible here
+(relative gradient differences up to 2e-3 between identical runs), which a parity-tested path cannot accept.
 
 Tokens are kept as [B, N, C] == NHWC throughout.  Stochastic depth and the head's Dropout2d draw from the torch device generator;
 ``external_draws = (drop_path_draws, dropout_mask)`` replays given draws (parity tests against oracle/segformer_ref.py).
@@ -22,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops_tokens import attention, dwconv_gelu, layer_norm, resize_bilinear
+from ..ops_tokens import attention, bn_relu_dropout, dwconv_gelu, layer_norm, resize_bilinear
 
 MIT_SETTINGS = {"B0": [[32, 64, 160, 256], [2, 2, 2, 2]]}
 HEADS, SR = [1, 2, 5, 8], [8, 4, 2, 1]
@@ -180,21 +181,17 @@ class SegFormerHead(nn.Module):
             outs.append(y)
         cv, bn = self.linear_fuse.conv, self.linear_fuse.bn
         z = F.linear(torch.cat(outs[::-1], dim=2), cv.weight.reshape(cv.weight.shape[0], -1))      # 1x1 conv without bias == GEMM over tokens
-        if self.training:                                                          # nn.BatchNorm2d, train mode, written out
-            mu = z.mean((0, 1))
-            var = (z - mu).square().mean((0, 1))
+        if self.training:          # nn.BatchNorm2d (train) + ReLU + nn.Dropout2d(0.1) (whole channels per sample): HIP kernels over the tokens
+            if dropout_mask is None:
+                dropout_mask = torch.empty(B, z.shape[2], 1, 1, device=z.device).bernoulli_(0.9)
+            seg, mu, var = bn_relu_dropout(z, bn.weight, bn.bias, dropout_mask.to(z.device), 0.9, bn.eps)
             with torch.no_grad():
                 n = z.shape[0] * z.shape[1]
-                bn.running_mean.mul_(1 - bn.momentum).add_(mu.detach(), alpha=bn.momentum)
-                bn.running_var.mul_(1 - bn.momentum).add_(var.detach() * (n / max(n - 1, 1)), alpha=bn.momentum)
+                bn.running_mean.mul_(1 - bn.momentum).add_(mu, alpha=bn.momentum)
+                bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
                 bn.num_batches_tracked += 1
-        else:
-            mu, var = bn.running_mean, bn.running_var
-        seg = torch.relu((z - mu) * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias)
-        if self.training:
-            if dropout_mask is None:                                               # nn.Dropout2d(0.1): whole channels per sample
-                dropout_mask = torch.empty(B, seg.shape[2], 1, 1, device=seg.device).bernoulli_(0.9)
-            seg = seg * dropout_mask.to(seg.device).reshape(B, 1, -1) / 0.9
+        else:                      # eval: a per-channel affine map of the running statistics (elementwise torch ops)
+            seg = torch.relu((z - bn.running_mean) * torch.rsqrt(bn.running_var + bn.eps) * bn.weight + bn.bias)
         pr = self.linear_pred
         seg = F.linear(seg, pr.weight.reshape(pr.weight.shape[0], -1), pr.bias)
         if seg.shape[-1] % 4 == 0:                                                 # HIP resize on NHWC; the result is viewed as NCHW

@@ -148,3 +148,47 @@ class _Resize(torch.autograd.Function):
 def resize_bilinear(x: torch.Tensor, H: int, W: int) -> torch.Tensor:
     """F.interpolate(..., size=(H, W), mode="bilinear", align_corners=False) on NHWC x [B,h,w,C] (C % 4 == 0), upsampling."""
     return _Resize.apply(x, H, W)
+
+
+class _BNReLUDrop(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mask, keep, eps):
+        _need_gpu(x, "bn_relu_dropout")
+        lib = L.load()
+        B, N, C_ = x.shape
+        xc = x.contiguous().float()
+        R = B * N
+        part = torch.empty(lib.hpfg_tok_stat_blocks(R) * 2 * C_, dtype=torch.float32, device=x.device)
+        sums = torch.empty(2, C_, dtype=torch.float32, device=x.device)
+        L.check(lib.hpfg_tok_col_stats(L.ptr(xc), R, C_, L.ptr(part), L.ptr(sums), _st(x)), "tok_col_stats")
+        mean = sums[0] / R
+        var = (sums[1] / R - mean * mean).clamp_min_(0.0)
+        rstd = torch.rsqrt(var + eps)
+        y = torch.empty_like(xc)
+        m = None if mask is None else mask.reshape(B, C_).float().contiguous()
+        L.check(lib.hpfg_bnrelu_apply(L.ptr(xc), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta), L.ptr(m), 1.0 / keep, N, L.ptr(y), R, C_, _st(x)),
+                "bnrelu_apply")
+        ctx.save_for_backward(xc, gamma, beta, mean, rstd, m if m is not None else xc.new_empty(0))
+        ctx.keep, ctx.N = keep, N
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        lib = L.load()
+        x, gamma, beta, mean, rstd, m = ctx.saved_tensors
+        B, N, C_ = x.shape
+        R = B * N
+        dyc = dy.contiguous()
+        dx = torch.empty_like(x)
+        part = torch.empty(lib.hpfg_tok_stat_blocks(R) * 2 * C_, dtype=torch.float32, device=x.device)
+        sums = torch.empty(2, C_, dtype=torch.float32, device=x.device)
+        L.check(lib.hpfg_bnrelu_bwd(L.ptr(x), L.ptr(dyc), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta), L.ptr(m if m.numel() else None),
+                                    1.0 / ctx.keep, N, L.ptr(dx), L.ptr(part), L.ptr(sums), R, C_, _st(x)), "bnrelu_bwd")
+        return dx, sums[1].clone(), sums[0].clone(), None, None, None
+
+
+def bn_relu_dropout(x, gamma, beta, mask=None, keep: float = 0.9, eps: float = 1e-5):
+    """Train-mode BatchNorm over all tokens of x [B,N,C] + ReLU + per-(image, channel) dropout mask [B,C] (0/1, scaled by 1/keep).
+    Returns (y, batch mean, biased batch variance); the caller updates the running statistics."""
+    return _BNReLUDrop.apply(x, gamma, beta, mask, keep, eps)

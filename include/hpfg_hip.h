@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 113
+#define HPFG_VERSION 114
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -258,6 +258,15 @@ int hpfg_dwgelu_bwd_blocks(int B, int H, int W);
  * gather over the outputs that tap a source pixel (no atomics), upsampling only */
 int hpfg_resize_bilinear_fwd(const float* x, float* y, int B, int h, int w, int H, int W, int C, void* stream);
 int hpfg_resize_bilinear_bwd(const float* dy, float* dx, int B, int h, int w, int H, int W, int C, void* stream);
+/* ConvModule's BatchNorm2d (train) + ReLU and the head's Dropout2d (segformer.py:288-296,307,318) over tokens [R,C]:
+ * column sums (sum x, sum x^2) -> the caller forms mean / rstd (and the running statistics) -> apply; mask [R/rows_per_image][C] of
+ * 0/1 keeps (or NULL), scaled by inv_keep.  Backward: sums [2][C] = (sum g, sum g*xhat) = (dbeta, dgamma), then dx. */
+int hpfg_tok_col_stats(const float* x, long R, int C, float* partials /* [hpfg_tok_stat_blocks(R)][2][C] */, float* sums /* [2][C] */, void* stream);
+int hpfg_tok_stat_blocks(long R);
+int hpfg_bnrelu_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* mask, float inv_keep,
+                      long rows_per_image, float* y, long R, int C, void* stream);
+int hpfg_bnrelu_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* mask,
+                    float inv_keep, long rows_per_image, float* dx, float* partials, float* sums, long R, int C, void* stream);
 
 /* ---- parameter updates --------------------------------------------------------------------------------- */
 /* torch.optim.SGD(momentum, weight_decay) over a flat parameter buffer (utils/__init__.py:15-16); lr read from device */

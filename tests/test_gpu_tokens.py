@@ -3,7 +3,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from hpfg_amd.ops_tokens import attention, dwconv_gelu, layer_norm, resize_bilinear
+from hpfg_amd.ops_tokens import attention, bn_relu_dropout, dwconv_gelu, layer_norm, resize_bilinear
 from tests.helpers import maxerr
 
 pytestmark = pytest.mark.gpu
@@ -78,3 +78,26 @@ def test_resize_bilinear(B, h, w, H, W, C_):
     y.backward(dy.to(DEV))
     assert maxerr(y.detach().cpu(), yr.detach()) < 1e-5
     assert maxerr(xd.grad.cpu(), xr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("B,N,C_,use_mask", [(2, 256, 256, True), (3, 49, 256, False), (2, 1000, 64, True)])
+def test_bn_relu_dropout(B, N, C_, use_mask):
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(B, N, C_, generator=g) * 1.5 + 0.3
+    w, b = torch.randn(C_, generator=g), torch.randn(C_, generator=g) * 0.3
+    dy = torch.randn(B, N, C_, generator=g)
+    mask = torch.empty(B, C_, 1, 1).bernoulli_(0.9, generator=g) if use_mask else None
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    mu = xr.mean((0, 1))
+    var = (xr - mu).square().mean((0, 1))
+    yr = torch.relu((xr - mu) * torch.rsqrt(var + 1e-5) * wr + br)
+    if use_mask:
+        yr = yr * mask.reshape(B, 1, C_) / 0.9
+    yr.backward(dy)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y, m_, v_ = bn_relu_dropout(xd, wd, bd, None if mask is None else mask.to(DEV), 0.9)
+    y.backward(dy.to(DEV))
+    assert maxerr(y.detach().cpu(), yr.detach()) < 2e-5
+    assert maxerr(m_.cpu(), mu.detach()) < 1e-5 and maxerr(v_.cpu(), var.detach()) < 1e-4
+    assert maxerr(xd.grad.cpu(), xr.grad) < 5e-5
+    assert maxerr(wd.grad.cpu(), wr.grad) < 1e-3 and maxerr(bd.grad.cpu(), br.grad) < 1e-3
