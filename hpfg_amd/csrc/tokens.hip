@@ -537,6 +537,51 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_apply_kernel(const float* __re
   }
 }
 
+// ---- weight gradient of a Linear over MANY tokens: dW[n][k] = sum_r dY[r][n] * X[r][k], R >> N, K ---------------------------------------
+// (the library GEMM picks a single-pass kernel for this tall-skinny shape: ~300 us for R = 100 352, N x K = 32 x 128.)  Split the rows
+// over blockIdx.y, 64 x 64 output tile per blockIdx.x, 4 x 4 outputs per thread from LDS-staged 64-row panels; the per-split partial
+// matrices are summed in a fixed order by col_reduce_kernel.
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, long R,
+                                                           int N, int K, int rows_per_split) {
+  __shared__ float sa[64][64 + 4], sb[64][64 + 4];
+  const int tiles_k = (K + 63) / 64;
+  const int n0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
+  const int tn = (threadIdx.x / 16) * 4, tk = (threadIdx.x % 16) * 4;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  const long r0 = (long)blockIdx.y * rows_per_split, r1 = r0 + rows_per_split < R ? r0 + rows_per_split : R;
+  for (long rb = r0; rb < r1; rb += 64) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 16; e += 256) {          // 64 rows x 16 float4 per panel
+      const int rr = e / 16, c4 = (e % 16) * 4;
+      const long r = rb + rr;
+      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = va;
+      if (r < r1) {
+        if (n0 + c4 < N) va = *reinterpret_cast<const f32x4*>(dy + r * N + n0 + c4);
+        if (k0 + c4 < K) vb = *reinterpret_cast<const f32x4*>(x + r * K + k0 + c4);
+      }
+      *reinterpret_cast<f32x4*>(&sa[rr][c4]) = va;
+      *reinterpret_cast<f32x4*>(&sb[rr][c4]) = vb;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int rr = 0; rr < 64; ++rr) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&sa[rr][tn]), b = *reinterpret_cast<const f32x4*>(&sb[rr][tk]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+    }
+  }
+  float* o = part + (long)blockIdx.y * N * K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (n0 + tn + i < N && k0 + tk < K) *reinterpret_cast<f32x4*>(o + (long)(n0 + tn + i) * K + k0 + tk) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+}
+
 inline int grid_cap(long total, int cap) {
   long b = (total + 255) / 256;
   if (b < 1) b = 1;
@@ -652,4 +697,25 @@ extern "C" int hpfg_bnrelu_bwd(const float* x, const float* dy, const float* mea
   hipLaunchKernelGGL(bnrelu_bwd_apply_kernel, dim3(grid_cap(R * (C / 4), 8192)), dim3(256), 0, (hipStream_t)stream, x, dy, mean, rstd, gamma, beta, mask,
                      inv_keep, rows_per_image, sums, dx, R, C);
   return hpfg_launch_status("bnrelu_bwd_kernel");
+}
+
+extern "C" int hpfg_linear_wgrad_splits(long R, int N, int K) {
+  const long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
+  long s = 2048 / tiles;                       // ~8 workgroups per CU in total
+  const long by_rows = (R + 255) / 256;        // at least 256 rows per split
+  if (s > by_rows) s = by_rows;
+  return (int)(s < 1 ? 1 : (s > 1024 ? 1024 : s));
+}
+
+/* dW[N][K] = dY^T X over R rows; partials [hpfg_linear_wgrad_splits()][N][K] */
+extern "C" int hpfg_linear_wgrad(const float* dy, const float* x, float* dw, float* partials, long R, int N, int K, void* stream) {
+  HPFG_ARG_CHECK(dy && x && dw && partials && R > 0 && N % 4 == 0 && K % 4 == 0 && N >= 4 && K >= 4, "linear_wgrad: bad args (N, K multiples of 4)");
+  const int S = hpfg_linear_wgrad_splits(R, N, K);
+  int per = (int)((R + S - 1) / S);
+  per = (per + 63) / 64 * 64;
+  dim3 grid(((N + 63) / 64) * ((K + 63) / 64), S);
+  hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, x, partials, R, N, K, per);
+  const long NK = (long)N * K;
+  hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)NK), dim3(64), 0, (hipStream_t)stream, partials, S, (int)NK, dw);
+  return hpfg_launch_status("linear_wgrad_kernel");
 }

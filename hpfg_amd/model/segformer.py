@@ -8,7 +8,8 @@ Same module tree, parameter names and constructor order as the reference's ``mod
   head's bilinear resizes and its BatchNorm(train) + ReLU + Dropout2d;
 * library GEMMs (rocBLAS through ``F.linear`` / ``torch.matmul``): q / kv / proj / fc1 / fc2, the spatial-reduction conv (kernel ==
   stride, so it is a GEMM over non-overlapping patches), the patch embeddings (after im2col), the head's per-stage projections, the
-  1x1 fuse and prediction convs, dK / dV of the attention backward;
+  1x1 fuse and prediction convs, dK / dV of the attention backward -- except the weight gradients of the
+  Linear layers that see >= 8192 tokens (tall-skinny dY^T X), which run on a row-split HIP kernel with a fixed-order reduction;
 * still plain PyTorch-ROCm ops in this version (to be replaced): im2col (``F.unfold``), the channel concat of the head, residual adds,
   the drop-path scaling and the token <-> image reshapes.
 No MIOpen call is left in the module: its BatchNorm / convolution backward was measured to be run-to-run non-reproducible here
@@ -23,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops_tokens import attention, bn_relu_dropout, dwconv_gelu, layer_norm, resize_bilinear
+from ..ops_tokens import attention, bn_relu_dropout, dwconv_gelu, layer_norm, linear, resize_bilinear
 
 MIT_SETTINGS = {"B0": [[32, 64, 160, 256], [2, 2, 2, 2]]}
 HEADS, SR = [1, 2, 5, 8], [8, 4, 2, 1]
@@ -42,15 +43,15 @@ class Attention(nn.Module):
 
     def forward(self, x, H, W):
         B, N, C = x.shape
-        q = F.linear(x, self.q.weight, self.q.bias)
+        q = linear(x, self.q.weight, self.q.bias)
         if self.sr_ratio > 1:
             s = self.sr_ratio
             # kernel == stride: the conv is a GEMM over non-overlapping s x s patches, rows ordered (u, v, channel)
             p = x.view(B, H // s, s, W // s, s, C).permute(0, 1, 3, 2, 4, 5).reshape(B, (H // s) * (W // s), s * s * C)
-            x = F.linear(p, self.sr.weight.permute(0, 2, 3, 1).reshape(C, s * s * C), self.sr.bias)
+            x = linear(p, self.sr.weight.permute(0, 2, 3, 1).reshape(C, s * s * C), self.sr.bias)
             x = layer_norm(x, self.norm.weight, self.norm.bias)
-        kv = F.linear(x, self.kv.weight, self.kv.bias)
-        return F.linear(attention(q, kv, self.head, self.scale), self.proj.weight, self.proj.bias)
+        kv = linear(x, self.kv.weight, self.kv.bias)
+        return linear(attention(q, kv, self.head, self.scale), self.proj.weight, self.proj.bias)
 
 
 class DWConv(nn.Module):
@@ -68,9 +69,9 @@ class MLP(nn.Module):
 
     def forward(self, x, H, W):
         B, N, _ = x.shape
-        h = F.linear(x, self.fc1.weight, self.fc1.bias)
+        h = linear(x, self.fc1.weight, self.fc1.bias)
         h = dwconv_gelu(h.view(B, H, W, -1), self.dwconv.dwconv.weight, self.dwconv.dwconv.bias).view(B, N, -1)
-        return F.linear(h, self.fc2.weight, self.fc2.bias)
+        return linear(h, self.fc2.weight, self.fc2.bias)
 
 
 class PatchEmbed(nn.Module):
@@ -85,7 +86,7 @@ class PatchEmbed(nn.Module):
         B, _, H, W = x.shape
         Ho, Wo = (H + 2 * (self.k // 2) - self.k) // self.s + 1, (W + 2 * (self.k // 2) - self.k) // self.s + 1
         cols = F.unfold(x, self.k, padding=self.k // 2, stride=self.s).transpose(1, 2)          # [B, L, C*k*k], rows ordered (c, u, v)
-        t = F.linear(cols, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
+        t = linear(cols, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
         return layer_norm(t, self.norm.weight, self.norm.bias), Ho, Wo
 
 
@@ -175,12 +176,12 @@ class SegFormerHead(nn.Module):
         outs = []
         for i, (t, h, w) in enumerate(feats):
             p = getattr(self, f"linear_c{i + 1}").proj
-            y = F.linear(t, p.weight, p.bias)                                      # [B, h*w, E] tokens
+            y = linear(t, p.weight, p.bias)                                      # [B, h*w, E] tokens
             if i > 0:
                 y = resize_bilinear(y.view(B, h, w, -1), H, W).view(B, H * W, -1)          # HIP, NHWC
             outs.append(y)
         cv, bn = self.linear_fuse.conv, self.linear_fuse.bn
-        z = F.linear(torch.cat(outs[::-1], dim=2), cv.weight.reshape(cv.weight.shape[0], -1))      # 1x1 conv without bias == GEMM over tokens
+        z = linear(torch.cat(outs[::-1], dim=2), cv.weight.reshape(cv.weight.shape[0], -1))      # 1x1 conv without bias == GEMM over tokens
         if self.training:          # nn.BatchNorm2d (train) + ReLU + nn.Dropout2d(0.1) (whole channels per sample): HIP kernels over the tokens
             if dropout_mask is None:
                 dropout_mask = torch.empty(B, z.shape[2], 1, 1, device=z.device).bernoulli_(0.9)
@@ -193,7 +194,7 @@ class SegFormerHead(nn.Module):
         else:                      # eval: a per-channel affine map of the running statistics (elementwise torch ops)
             seg = torch.relu((z - bn.running_mean) * torch.rsqrt(bn.running_var + bn.eps) * bn.weight + bn.bias)
         pr = self.linear_pred
-        seg = F.linear(seg, pr.weight.reshape(pr.weight.shape[0], -1), pr.bias)
+        seg = linear(seg, pr.weight.reshape(pr.weight.shape[0], -1), pr.bias)
         if seg.shape[-1] % 4 == 0:                                                 # HIP resize on NHWC; the result is viewed as NCHW
             return resize_bilinear(seg.view(B, H, W, -1), self.image_size[0], self.image_size[1]).permute(0, 3, 1, 2)
         return F.interpolate(seg.permute(0, 2, 1).reshape(B, -1, H, W), size=self.image_size, mode="bilinear", align_corners=False)

@@ -3,6 +3,7 @@ softmax(q k^T) v, and depthwise-3x3 + GELU.  Device tensors only; the library ra
 from __future__ import annotations
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib as L
 
@@ -192,3 +193,47 @@ def bn_relu_dropout(x, gamma, beta, mask=None, keep: float = 0.9, eps: float = 1
     """Train-mode BatchNorm over all tokens of x [B,N,C] + ReLU + per-(image, channel) dropout mask [B,C] (0/1, scaled by 1/keep).
     Returns (y, batch mean, biased batch variance); the caller updates the running statistics."""
     return _BNReLUDrop.apply(x, gamma, beta, mask, keep, eps)
+
+
+TALL_ROWS = 8192          # from this many tokens on, the weight gradient of a Linear runs on the row-split HIP kernel
+
+
+class _LinearTall(torch.autograd.Function):
+    """y = x W^T + b over tokens x [.., K]: forward and dX are library GEMMs, dW (tall-skinny: rows >> N, K) and db are HIP."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        x, w = ctx.saved_tensors
+        N, K = w.shape
+        dyc = dy.reshape(-1, N).contiguous()
+        xc = x.reshape(-1, K).contiguous()
+        R = xc.shape[0]
+        dx = torch.matmul(dyc, w).view_as(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        part = torch.empty(lib.hpfg_linear_wgrad_splits(R, N, K) * N * K, dtype=torch.float32, device=w.device)
+        L.check(lib.hpfg_linear_wgrad(L.ptr(dyc), L.ptr(xc), L.ptr(dw), L.ptr(part), R, N, K, _st(w)), "linear_wgrad")
+        db = None
+        if ctx.has_bias:
+            if N % 4 == 0 and N <= 1024 and 256 % (N // 4) == 0:
+                p2 = torch.empty(lib.hpfg_tok_stat_blocks(R) * 2 * N, dtype=torch.float32, device=w.device)
+                sums = torch.empty(2, N, dtype=torch.float32, device=w.device)
+                L.check(lib.hpfg_tok_col_stats(L.ptr(dyc), R, N, L.ptr(p2), L.ptr(sums), _st(w)), "tok_col_stats")
+                db = sums[0].clone()
+            else:
+                db = dyc.sum(0)
+        return dx, dw, db
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
+    """F.linear, with the weight / bias gradients on the HIP row-split kernels when there are many tokens."""
+    rows = x.numel() // x.shape[-1]
+    if x.is_cuda and rows >= TALL_ROWS and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0 and x.dtype == torch.float32:
+        return _LinearTall.apply(x, weight, bias)
+    return F.linear(x, weight, bias)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 114
+#define HPFG_VERSION 115
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -261,6 +261,11 @@ int hpfg_resize_bilinear_bwd(const float* dy, float* dx, int B, int h, int w, in
 /* ConvModule's BatchNorm2d (train) + ReLU and the head's Dropout2d (segformer.py:288-296,307,318) over tokens [R,C]:
  * column sums (sum x, sum x^2) -> the caller forms mean / rstd (and the running statistics) -> apply; mask [R/rows_per_image][C] of
  * 0/1 keeps (or NULL), scaled by inv_keep.  Backward: sums [2][C] = (sum g, sum g*xhat) = (dbeta, dgamma), then dx. */
+/* weight gradient of nn.Linear over many tokens, dW[N][K] = dY[R][N]^T X[R][K] with R >> N, K (the q / kv / proj / fc1 / fc2 layers of the
+ * high-resolution stages): row-split partial products + fixed-order reduction */
+int hpfg_linear_wgrad(const float* dy, const float* x, float* dw, float* partials /* [hpfg_linear_wgrad_splits()][N][K] */, long R, int N, int K,
+                      void* stream);
+int hpfg_linear_wgrad_splits(long R, int N, int K);
 int hpfg_tok_col_stats(const float* x, long R, int C, float* partials /* [hpfg_tok_stat_blocks(R)][2][C] */, float* sums /* [2][C] */, void* stream);
 int hpfg_tok_stat_blocks(long R);
 int hpfg_bnrelu_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* mask, float inv_keep,

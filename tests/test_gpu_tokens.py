@@ -3,7 +3,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from hpfg_amd.ops_tokens import attention, bn_relu_dropout, dwconv_gelu, layer_norm, resize_bilinear
+from hpfg_amd.ops_tokens import attention, bn_relu_dropout, dwconv_gelu, layer_norm, linear, resize_bilinear
 from tests.helpers import maxerr
 
 pytestmark = pytest.mark.gpu
@@ -101,3 +101,20 @@ def test_bn_relu_dropout(B, N, C_, use_mask):
     assert maxerr(m_.cpu(), mu.detach()) < 1e-5 and maxerr(v_.cpu(), var.detach()) < 1e-4
     assert maxerr(xd.grad.cpu(), xr.grad) < 5e-5
     assert maxerr(wd.grad.cpu(), wr.grad) < 1e-3 and maxerr(bd.grad.cpu(), br.grad) < 1e-3
+
+
+@pytest.mark.parametrize("R,N,K", [(9000, 32, 32), (20000, 64, 32), (8200, 32, 128), (10000, 256, 64), (8192, 4, 256), (9001, 160, 36)])
+def test_linear_tall_weight_gradient(R, N, K):
+    g = torch.Generator().manual_seed(N + K)
+    x, w, b = torch.randn(2, R // 2, K, generator=g), torch.randn(N, K, generator=g) * 0.2, torch.randn(N, generator=g)
+    x = x[:, : R // 2]
+    dy = torch.randn(2, R // 2, N, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.linear(xr, wr, br).backward(dy)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = linear(xd, wd, bd)
+    y.backward(dy.to(DEV))
+    scale = float(wr.grad.abs().max())
+    assert maxerr(y.detach().cpu(), F.linear(x, w, b)) < 1e-4
+    assert maxerr(xd.grad.cpu(), xr.grad) < 1e-4
+    assert maxerr(wd.grad.cpu(), wr.grad) < 2e-5 * max(1.0, scale) * 10 and maxerr(bd.grad.cpu(), br.grad) < 1e-3
