@@ -131,6 +131,28 @@ __global__ __launch_bounds__(64) void col_reduce_kernel(const float* __restrict_
   if (threadIdx.x == 0) out[c] = (float)a;
 }
 
+// out[o] = sum_s part[s * n + o] for MANY outputs o (weight-gradient partial matrices): lane <-> output (coalesced), the four waves of a
+// workgroup take every fourth row with four loads in flight each, fixed combination order
+__global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ part, int S, long n, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long o = (long)blockIdx.x * 64 + lane;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (o < n) {
+    int s = wave;
+    for (; s + 12 < S; s += 16) {
+      a0 += part[(long)s * n + o];
+      a1 += part[(long)(s + 4) * n + o];
+      a2 += part[(long)(s + 8) * n + o];
+      a3 += part[(long)(s + 12) * n + o];
+    }
+    for (; s < S; s += 4) a0 += part[(long)s * n + o];
+  }
+  red[wave][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (wave == 0 && o < n) out[o] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
 // ---- attention core: thread per query, K / V of one (batch, head) in LDS; M <= 64 keys, head dim 32 ---------------------------------
 constexpr int AD = 32, AM = 64;
 // q [B,N,h,32] (row stride C = h*32), kv [B,M,2,h,32] (the kv Linear's output), out [B,N,h,32]
@@ -716,6 +738,6 @@ extern "C" int hpfg_linear_wgrad(const float* dy, const float* x, float* dw, flo
   dim3 grid(((N + 63) / 64) * ((K + 63) / 64), S);
   hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, x, partials, R, N, K, per);
   const long NK = (long)N * K;
-  hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)NK), dim3(64), 0, (hipStream_t)stream, partials, S, (int)NK, dw);
+  hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((NK + 63) / 64)), dim3(256), 0, (hipStream_t)stream, partials, S, NK, dw);
   return hpfg_launch_status("linear_wgrad_kernel");
 }
