@@ -604,6 +604,61 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     if (n0 + tn + i < N && k0 + tk < K) *reinterpret_cast<f32x4*>(o + (long)(n0 + tn + i) * K + k0 + tk) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
 }
 
+// ---- im2col / col2im of the overlap patch embeddings (PatchEmbed.proj, segformer.py:172: kernel k, stride s, padding k/2), NHWC ----------
+// cols[b][oy][ox][(u, v, c)] = x[b][oy*s + u - p][ox*s + v - p][c] (0 outside); VEC = 4 channels per thread when C % 4 == 0
+template <int VEC>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ cols, int B, int H, int W, int C, int k, int s,
+                                                     int p, int Ho, int Wo) {
+  const int Cq = C / VEC;
+  const long total = (long)B * Ho * Wo * k * k * Cq;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % Cq) * VEC;
+    long r = i / Cq;
+    const int v = (int)(r % k);
+    r /= k;
+    const int u = (int)(r % k);
+    r /= k;
+    const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho), b = (int)(r / ((long)Wo * Ho));
+    const int y = oy * s + u - p, xx = ox * s + v - p;
+    const bool in = y >= 0 && y < H && xx >= 0 && xx < W;
+    const long src = (((long)b * H + (in ? y : 0)) * W + (in ? xx : 0)) * C + c;
+    if (VEC == 4) {
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (in) val = *reinterpret_cast<const f32x4*>(x + src);
+      *reinterpret_cast<f32x4*>(cols + i * 4) = val;
+    } else {
+      cols[i] = in ? x[src] : 0.f;
+    }
+  }
+}
+
+// dx[b][y][x][c] = sum over the (oy, ox, u, v) whose patch element is this pixel (gather: no atomics)
+template <int VEC>
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcols, float* __restrict__ dx, int B, int H, int W, int C, int k, int s,
+                                                     int p, int Ho, int Wo) {
+  const int Cq = C / VEC;
+  const long total = (long)B * H * W * Cq;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % Cq) * VEC;
+    const long px = i / Cq;
+    const int xx = (int)(px % W), y = (int)((px / W) % H), b = (int)(px / ((long)W * H));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < k; ++u) {
+      const int ty = y + p - u;
+      if (ty < 0 || ty % s != 0 || ty / s >= Ho) continue;
+      for (int v = 0; v < k; ++v) {
+        const int tx = xx + p - v;
+        if (tx < 0 || tx % s != 0 || tx / s >= Wo) continue;
+        const long src = (((((long)b * Ho + ty / s) * Wo + tx / s) * k + u) * k + v) * C + c;
+        if (VEC == 4) acc += *reinterpret_cast<const f32x4*>(dcols + src);
+        else acc[0] += dcols[src];
+      }
+    }
+    if (VEC == 4) *reinterpret_cast<f32x4*>(dx + px * C + c) = acc;
+    else dx[px * C + c] = acc[0];
+  }
+}
+
 inline int grid_cap(long total, int cap) {
   long b = (total + 255) / 256;
   if (b < 1) b = 1;
@@ -740,4 +795,22 @@ extern "C" int hpfg_linear_wgrad(const float* dy, const float* x, float* dw, flo
   const long NK = (long)N * K;
   hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((NK + 63) / 64)), dim3(256), 0, (hipStream_t)stream, partials, S, NK, dw);
   return hpfg_launch_status("linear_wgrad_kernel");
+}
+
+extern "C" int hpfg_im2col_nhwc(const float* x, float* cols, int B, int H, int W, int C, int k, int s, void* stream) {
+  HPFG_ARG_CHECK(x && cols && B > 0 && H > 0 && W > 0 && C > 0 && k > 0 && s > 0, "im2col_nhwc: bad args");
+  const int p = k / 2, Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+  const long total = (long)B * Ho * Wo * k * k * (C % 4 == 0 ? C / 4 : C);
+  if (C % 4 == 0) hipLaunchKernelGGL(im2col_kernel<4>, dim3(grid_cap(total, 16384)), dim3(256), 0, (hipStream_t)stream, x, cols, B, H, W, C, k, s, p, Ho, Wo);
+  else hipLaunchKernelGGL(im2col_kernel<1>, dim3(grid_cap(total, 16384)), dim3(256), 0, (hipStream_t)stream, x, cols, B, H, W, C, k, s, p, Ho, Wo);
+  return hpfg_launch_status("im2col_kernel");
+}
+
+extern "C" int hpfg_col2im_nhwc(const float* dcols, float* dx, int B, int H, int W, int C, int k, int s, void* stream) {
+  HPFG_ARG_CHECK(dcols && dx && B > 0 && H > 0 && W > 0 && C > 0 && k > 0 && s > 0, "col2im_nhwc: bad args");
+  const int p = k / 2, Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+  const long total = (long)B * H * W * (C % 4 == 0 ? C / 4 : C);
+  if (C % 4 == 0) hipLaunchKernelGGL(col2im_kernel<4>, dim3(grid_cap(total, 16384)), dim3(256), 0, (hipStream_t)stream, dcols, dx, B, H, W, C, k, s, p, Ho, Wo);
+  else hipLaunchKernelGGL(col2im_kernel<1>, dim3(grid_cap(total, 16384)), dim3(256), 0, (hipStream_t)stream, dcols, dx, B, H, W, C, k, s, p, Ho, Wo);
+  return hpfg_launch_status("col2im_kernel");
 }

@@ -5,15 +5,16 @@ Same module tree, parameter names and constructor order as the reference's ``mod
 
 * hand-written HIP (``csrc/tokens.hip`` through ``hpfg_amd.ops_tokens``), forward and backward: every LayerNorm, the attention core
   softmax(q k^T / sqrt(d)) v (at most 64 keys after the spatial reduction, head dim 32), depthwise 3x3 + GELU of the Mix-FFN, the
-  head's bilinear resizes and its BatchNorm(train) + ReLU + Dropout2d;
+  head's bilinear resizes and its BatchNorm(train) + ReLU + Dropout2d, im2col / col2im of the overlap patch embeddings;
 * library GEMMs (rocBLAS through ``F.linear`` / ``torch.matmul``): q / kv / proj / fc1 / fc2, the spatial-reduction conv (kernel ==
   stride, so it is a GEMM over non-overlapping patches), the patch embeddings (after im2col), the head's per-stage projections, the
   1x1 fuse and prediction convs, dK / dV of the attention backward -- except the weight gradients of the
   Linear layers that see >= 8192 tokens (tall-skinny dY^T X), which run on a row-split HIP kernel with a fixed-order reduction;
-* still plain PyTorch-ROCm ops in this version (to be replaced): im2col (``F.unfold``), the channel concat of the head, residual adds,
+* still plain PyTorch-ROCm ops in this version (to be replaced): the channel concat of the head, residual adds,
   the drop-path scaling and the token <-> image reshapes.
-No MIOpen call is left in the module: its BatchNorm / convolution backward was measured to be run-to-run non-reproducible here
-(relative gradient differences up to 2e-3 between identical runs), which a parity-tested path cannot accept.
+No MIOpen call is left in the module: with MIOpen convolutions / BatchNorm the forward was not bit-reproducible between identical runs
+(logits differing by ~4e-7), and one ReLU gate of the head flipping on such noise moves every gradient upstream by ~1e-3; without it the
+forward is bit-identical run to run.
 
 Tokens are kept as [B, N, C] == NHWC throughout.  Stochastic depth and the head's Dropout2d draw from the torch device generator;
 ``external_draws = (drop_path_draws, dropout_mask)`` replays given draws (parity tests against oracle/segformer_ref.py).
@@ -24,7 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops_tokens import attention, bn_relu_dropout, dwconv_gelu, layer_norm, linear, resize_bilinear
+from ..ops_tokens import attention, bn_relu_dropout, dwconv_gelu, im2col, layer_norm, linear, resize_bilinear
 
 MIT_SETTINGS = {"B0": [[32, 64, 160, 256], [2, 2, 2, 2]]}
 HEADS, SR = [1, 2, 5, 8], [8, 4, 2, 1]
@@ -82,11 +83,11 @@ class PatchEmbed(nn.Module):
         self.k, self.s = patch_size, stride
 
     def forward(self, x):
-        """x [B,C,H,W] (any strides) -> tokens [B, H'*W', c2]: im2col + GEMM, then the HIP LayerNorm."""
-        B, _, H, W = x.shape
+        """x NHWC [B,H,W,C] -> tokens [B, H'*W', c2]: HIP im2col, library GEMM, HIP LayerNorm."""
+        B, H, W, _ = x.shape
         Ho, Wo = (H + 2 * (self.k // 2) - self.k) // self.s + 1, (W + 2 * (self.k // 2) - self.k) // self.s + 1
-        cols = F.unfold(x, self.k, padding=self.k // 2, stride=self.s).transpose(1, 2)          # [B, L, C*k*k], rows ordered (c, u, v)
-        t = linear(cols, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
+        wt = self.proj.weight.permute(0, 2, 3, 1).reshape(self.proj.weight.shape[0], -1)          # rows ordered (u, v, c) like the patches
+        t = linear(im2col(x, self.k, self.s), wt, self.proj.bias)
         return layer_norm(t, self.norm.weight, self.norm.bias), Ho, Wo
 
 
@@ -132,6 +133,7 @@ class MiT(nn.Module):
     def forward(self, x, draws=None):
         """Returns the four stage outputs as tokens [(tokens [B,N,C], H, W)] (the reference returns them as NCHW images)."""
         B = x.shape[0]
+        x = x.permute(0, 2, 3, 1)                                # NCHW input -> NHWC (a view; contiguous already when C == 1)
         feats, bi = [], 0
         for i in range(4):
             x, H, W = getattr(self, f"patch_embed{i + 1}")(x)
@@ -142,7 +144,7 @@ class MiT(nn.Module):
             n = getattr(self, f"norm{i + 1}")
             t = layer_norm(x, n.weight, n.bias)
             feats.append((t, H, W))
-            x = t.view(B, H, W, -1).permute(0, 3, 1, 2)          # NCHW view of the NHWC tokens for the next patch embedding
+            x = t.view(B, H, W, -1)                               # the tokens ARE the NHWC image of the next patch embedding
         return feats
 
 

@@ -237,3 +237,30 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
     if x.is_cuda and rows >= TALL_ROWS and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0 and x.dtype == torch.float32:
         return _LinearTall.apply(x, weight, bias)
     return F.linear(x, weight, bias)
+
+
+class _Im2col(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, s):
+        _need_gpu(x, "im2col")
+        xc = x.contiguous().float()
+        B, H, W, C_ = xc.shape
+        p = k // 2
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        cols = torch.empty(B, Ho * Wo, k * k * C_, dtype=torch.float32, device=x.device)
+        L.check(L.load().hpfg_im2col_nhwc(L.ptr(xc), L.ptr(cols), B, H, W, C_, k, s, _st(x)), "im2col")
+        ctx.geo = (B, H, W, C_, k, s)
+        return cols
+
+    @staticmethod
+    def backward(ctx, dcols):
+        B, H, W, C_, k, s = ctx.geo
+        dc = dcols.contiguous()
+        dx = torch.empty(B, H, W, C_, dtype=torch.float32, device=dc.device)
+        L.check(L.load().hpfg_col2im_nhwc(L.ptr(dc), L.ptr(dx), B, H, W, C_, k, s, _st(dc)), "col2im")
+        return dx, None, None
+
+
+def im2col(x: torch.Tensor, k: int, s: int) -> torch.Tensor:
+    """Patches of a conv with kernel k, stride s, padding k // 2 over NHWC x [B,H,W,C] -> [B, Ho*Wo, k*k*C], patch order (u, v, c)."""
+    return _Im2col.apply(x, k, s)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 115
+#define HPFG_VERSION 116
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -261,6 +261,10 @@ int hpfg_resize_bilinear_bwd(const float* dy, float* dx, int B, int h, int w, in
 /* ConvModule's BatchNorm2d (train) + ReLU and the head's Dropout2d (segformer.py:288-296,307,318) over tokens [R,C]:
  * column sums (sum x, sum x^2) -> the caller forms mean / rstd (and the running statistics) -> apply; mask [R/rows_per_image][C] of
  * 0/1 keeps (or NULL), scaled by inv_keep.  Backward: sums [2][C] = (sum g, sum g*xhat) = (dbeta, dgamma), then dx. */
+/* im2col / col2im of PatchEmbed.proj (segformer.py:172: kernel k, stride s, padding k/2) on NHWC x [B,H,W,C]:
+ * cols [B, Ho*Wo, k*k*C] with the patch ordered (u, v, c); col2im is the gather-form transpose (no atomics) */
+int hpfg_im2col_nhwc(const float* x, float* cols, int B, int H, int W, int C, int k, int s, void* stream);
+int hpfg_col2im_nhwc(const float* dcols, float* dx, int B, int H, int W, int C, int k, int s, void* stream);
 /* weight gradient of nn.Linear over many tokens, dW[N][K] = dY[R][N]^T X[R][K] with R >> N, K (the q / kv / proj / fc1 / fc2 layers of the
  * high-resolution stages): row-split partial products + fixed-order reduction */
 int hpfg_linear_wgrad(const float* dy, const float* x, float* dw, float* partials /* [hpfg_linear_wgrad_splits()][N][K] */, long R, int N, int K,

@@ -3,7 +3,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from hpfg_amd.ops_tokens import attention, bn_relu_dropout, dwconv_gelu, layer_norm, linear, resize_bilinear
+from hpfg_amd.ops_tokens import attention, bn_relu_dropout, dwconv_gelu, im2col, layer_norm, linear, resize_bilinear
 from tests.helpers import maxerr
 
 pytestmark = pytest.mark.gpu
@@ -118,3 +118,20 @@ def test_linear_tall_weight_gradient(R, N, K):
     assert maxerr(y.detach().cpu(), F.linear(x, w, b)) < 1e-4
     assert maxerr(xd.grad.cpu(), xr.grad) < 1e-4
     assert maxerr(wd.grad.cpu(), wr.grad) < 2e-5 * max(1.0, scale) * 10 and maxerr(bd.grad.cpu(), br.grad) < 1e-3
+
+
+@pytest.mark.parametrize("B,H,W,C_,k,s", [(2, 64, 64, 1, 7, 4), (2, 16, 16, 32, 3, 2), (1, 9, 7, 64, 3, 2), (1, 224, 224, 1, 7, 4), (2, 8, 8, 160, 3, 2)])
+def test_im2col_matches_conv(B, H, W, C_, k, s):
+    """im2col + GEMM == nn.Conv2d(k, s, padding k//2), values and input gradient."""
+    g = torch.Generator().manual_seed(H + C_)
+    x = torch.randn(B, H, W, C_, generator=g)
+    w, b = torch.randn(8, C_, k, k, generator=g) * 0.2, torch.randn(8, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr.permute(0, 3, 1, 2), w, b, stride=s, padding=k // 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xd = x.to(DEV).requires_grad_(True)
+    y = F.linear(im2col(xd, k, s), w.permute(0, 2, 3, 1).reshape(8, -1).to(DEV), b.to(DEV))          # [B, L, 8]
+    y.backward(dy.flatten(2).transpose(1, 2).to(DEV))
+    assert maxerr(y.detach().cpu(), yr.detach().flatten(2).transpose(1, 2)) < 1e-4
+    assert maxerr(xd.grad.cpu(), xr.grad) < 1e-4
