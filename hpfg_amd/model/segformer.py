@@ -217,3 +217,7 @@ class SegFormer(nn.Module):
 
     def val(self, x):
         return self.forward(x)
+
+    def bump_graph_seed(self):
+        """GraphedStep hook (the U-Net engines advance their dropout seed word here): nothing to do -- drop-path and Dropout2d draw from
+        the torch device generator, whose state a captured graph advances by itself at every replay."""

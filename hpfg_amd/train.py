@@ -148,7 +148,8 @@ class _StepBase:
 
     @staticmethod
     def _lr(opt):
-        return float(opt.param_groups[0]["lr"])
+        lr = opt.param_groups[0]["lr"]
+        return 0.0 if torch.is_tensor(lr) else float(lr)      # a tensor lr (capturable AdamW) stays on the device; only FusedSGD reads this
 
 
 class SupervisedStep(_StepBase):

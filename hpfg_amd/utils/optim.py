@@ -64,7 +64,13 @@ def build_optimizer(args, model):
             return FusedSGD(model, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
         return torch.optim.SGD(model.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
     if args.opt == "adamW":
-        return torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+        params = list(model.parameters())
+        if params and params[0].is_cuda:
+            # capturable: step counters and the learning rate live on the device, so the update can be replayed inside a hipGraph
+            # (torch's schedulers fill a tensor lr in place)
+            lr = torch.tensor(float(args.lr), dtype=torch.float32, device=params[0].device)
+            return torch.optim.AdamW(params, lr=lr, weight_decay=args.weight_decay, capturable=True)
+        return torch.optim.AdamW(params, lr=args.lr, weight_decay=args.weight_decay)
     if args.opt == "adam":
         return torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
     raise ValueError("get_optimizer error")

@@ -113,3 +113,26 @@ def test_ctct_step_trace(golden_dir):
     # element: wherever a gradient is at rounding level its sign -- hence a full +-8e-4 step -- differs between two fp32 evaluations.
     # The losses above still agree to 1e-3; the logits are bounded by a few such steps.
     assert maxerr(r["logits2"].cpu(), torch.from_numpy(d["logits2_last"])) < 2e-2
+
+
+def test_ctct_step_captures_into_a_graph():
+    """The whole cross-teaching step (both networks, both optimizers: FusedSGD and capturable AdamW) replays from one hipGraph."""
+    from hpfg_amd.datasets.synthetic import synth_batch
+    from hpfg_amd.model import UNet
+    from hpfg_amd.train import CTCTStep, GraphedStep
+    torch.manual_seed(3)
+    m1, m2 = UNet(1, 4).to(DEV), SegFormer(image_size=[64, 64], in_channels=1, num_classes=4).to(DEV)
+    m1.train()
+    m2.train()
+    opt = dict(opt="sgd", lr=0.01, momentum=0.9, weight_decay=5e-4, sched="medical", total_itrs=30000, step_size=1500, warmup_epochs=1, warmup_lr=1e-4,
+               min_lr=1e-6)
+    a = AttrDict(dict(model1=AttrDict(opt), model2=AttrDict(dict(opt, opt="adamW", lr=0.0008, weight_decay=0.05)), consistency=0.1, consistency_rampup=200.0))
+    xl, yl = synth_batch(1, 4, 64, 64, 1, 4, 8)
+    xu, _ = synth_batch(2, 4, 64, 64, 1, 4, 8)
+    xl, yl, xu = xl.to(DEV), yl.to(DEV), xu.to(DEV)
+    gs = GraphedStep(CTCTStep(m1, m2, a), [xl, yl, xu], warmup=2, alias_inputs=True)
+    w0 = m2.decoder.linear_pred.weight.detach().clone()
+    losses = [float(gs.step([xl, yl, xu], 3 + k)["loss"]) for k in range(12)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert float((m2.decoder.linear_pred.weight.detach() - w0).abs().max()) > 1e-4          # AdamW ran inside the graph
+    assert abs(float(a.model2.lr) - 0.0008) < 1e-12 and float(gs.s.optimizer2.param_groups[0]["lr"]) < 0.0008      # the tensor lr follows the schedule

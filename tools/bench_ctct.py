@@ -31,3 +31,18 @@ for i in range(n):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / n * 1e3
 print(f"CTCT 8+24 x 224^2: {ms:.3f} ms/step = {32 / ms * 1e3:.0f} img/s")
+if os.environ.get("GRAPH", "1") == "1":
+    from hpfg_amd.train import GraphedStep  # noqa: E402
+    try:
+        gs = GraphedStep(st, [xl, yl, xu], warmup=2, alias_inputs=True)
+        for i in range(5):
+            gs.step([xl, yl, xu], 100 + i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            gs.step([xl, yl, xu], 200 + i)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        print(f"CTCT 8+24 x 224^2, hipGraph: {ms:.3f} ms/step = {32 / ms * 1e3:.0f} img/s")
+    except Exception as e:
+        print("hipGraph capture of the CTCT step failed:", type(e).__name__, str(e)[:300])
