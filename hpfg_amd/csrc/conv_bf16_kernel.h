@@ -120,6 +120,17 @@ __device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (
       tsc = ld4(tb, HPFG_BN_SCALE * p.bwd_of.bn_stride);
       tsh = ld4(tb, HPFG_BN_SHIFT * p.bwd_of.bn_stride);
     }
+    // bwd: request the z values of all MI pixel tiles of this channel group before the first one is used (one exposed round trip per
+    // channel group instead of one per tile when the scheduler would otherwise pair each load with its use)
+    f32x4 zq[C::MI];
+    if (bwd) {
+#pragma unroll
+      for (int m = 0; m < C::MI; ++m) {
+        const int pxl = (wm * C::MI + m) * 16 + (lane & 15);
+        const int gy = min(ty0 + pxl / C::TW, H - 1), gx = min(tx0 + pxl % C::TW, W - 1);
+        zq[m] = *reinterpret_cast<const f32x4*>(p.bwd_of.z + (((long)n * H + gy) * W + gx) * p.bwd_of.pstride + min(co, p.Cout - 4));
+      }
+    }
 #pragma unroll
     for (int m = 0; m < C::MI; ++m) {
       const int pxl = (wm * C::MI + m) * 16 + (lane & 15);
@@ -139,7 +150,7 @@ __device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (
         }
         if (bwd) {
           const long pix = ((long)n * H + gy) * W + gx;
-          const f32x4 z = *reinterpret_cast<const f32x4*>(p.bwd_of.z + pix * p.bwd_of.pstride + co);
+          const f32x4 z = zq[m];
           uint32_t km = 0xFu;
           if (p.bwd_of.drop_p > 0.f) km = keep4(p.bwd_of, bcx, (uint32_t)(pix * p.bwd_of.C + co));
 #pragma unroll
