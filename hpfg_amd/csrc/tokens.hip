@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void dwgelu_fwd_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void dwgelu_bwd_du_kernel(const float* __restrict__ x, const float* __restrict__ w9, const float* __restrict__ bias,
                                                             const float* __restrict__ dy, float* __restrict__ du, float* __restrict__ part, int B, int H,
                                                             int W, int C) {
-  __shared__ float red[256 * 4];
+  __shared__ float red[256 * 40];
   const int Q = C / 4;                       // 256 % Q == 0 or Q % 256 == 0 is NOT required: a thread's channel quad changes per item,
   const long total = (long)B * H * W * Q;    // so the partial sums are accumulated per (item % Q) through LDS below
   // each workgroup owns a contiguous range of pixels and loops over channel quads inside: thread t <-> quad (t % Qw), pixel lane t / Qw
@@ -346,16 +346,19 @@ __global__ __launch_bounds__(256) void dwgelu_bwd_du_kernel(const float* __restr
           if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) acc[t] += g * *reinterpret_cast<const f32x4*>(x + (((long)b * H + y2) * W + x2) * C + c);
         }
       }
-    for (int t = 0; t < 10; ++t) {
-      __syncthreads();
+    // all ten sums of every channel quad in one LDS round: red[thread][t][j]
+    __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 4; ++j) red[threadIdx.x * 4 + j] = acc[t][j];
-      __syncthreads();
-      for (int o = threadIdx.x; o < Qw * 4 && qb * 4 + o < C; o += 256) {
-        const int qq = o >> 2, j = o & 3;
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[(threadIdx.x * 10 + t) * 4 + j] = acc[t][j];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 10 * Qw * 4; o += 256) {
+      const int t = o / (Qw * 4), cc = o % (Qw * 4), qq = cc >> 2, j = cc & 3;
+      if (qb * 4 + cc < C) {
         float s = 0.f;
-        for (int l = 0; l < PL; ++l) s += red[(l * Qw + qq) * 4 + j];
-        part[((long)blockIdx.x * 10 + t) * C + qb * 4 + o] = s;
+        for (int l = 0; l < PL; ++l) s += red[((l * Qw + qq) * 10 + t) * 4 + j];
+        part[((long)blockIdx.x * 10 + t) * C + qb * 4 + cc] = s;
       }
     }
   }
