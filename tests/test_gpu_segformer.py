@@ -136,3 +136,25 @@ def test_ctct_step_captures_into_a_graph():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     assert float((m2.decoder.linear_pred.weight.detach() - w0).abs().max()) > 1e-4          # AdamW ran inside the graph
     assert abs(float(a.model2.lr) - 0.0008) < 1e-12 and float(gs.s.optimizer2.param_groups[0]["lr"]) < 0.0008      # the tensor lr follows the schedule
+
+
+def test_eval_path_runs_the_segformer():
+    """hpfg_amd.val.test_single_volume (the reference's evaluation signature) on a SegFormer: slices resized to the network size, eval-mode
+    forward, arg-max and Dice counts on the device -- against the oracle forward on the same weights."""
+    from hpfg_amd.val import test_single_volume
+    torch.manual_seed(11)
+    m = SegFormer(image_size=[64, 64], in_channels=1, num_classes=4).to(DEV)
+    st = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    vol = torch.rand(1, 5, 80, 72, generator=g)
+    lab = torch.randint(0, 4, (1, 5, 80, 72), generator=g)
+    got = np.array(test_single_volume(vol, lab, m, classes=4, patch_size=[64, 64]))
+    assert m.training            # the evaluation restores the mode it found
+    from scipy.ndimage import zoom                      # the reference's resize (val.py:274,280), slice by slice
+    xs = np.stack([zoom(sl, (64 / 80, 64 / 72), order=0) for sl in vol[0].numpy()])
+    with torch.no_grad():
+        logits = S.segformer_forward(st, torch.from_numpy(xs).float().unsqueeze(1), False)
+    pred = np.stack([zoom(p, (80 / 64, 72 / 64), order=0) for p in logits.argmax(1).numpy().astype(np.uint8)])
+    want = [losses_ref.binary_dice(pred == c, lab[0].numpy() == c) for c in range(1, 4)]
+    assert np.abs(got[:, 0] - np.array(want)).max() < 2e-3, (got[:, 0], want)
+    assert got.shape == (3, 2) and np.isfinite(got).all()
