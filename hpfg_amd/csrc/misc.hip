@@ -420,6 +420,29 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   }
 }
 
+// torch.optim.AdamW (decoupled weight decay, bias-corrected moments) over flat buffers; *step_dev holds the number of steps already taken
+// (a one-thread kernel advances it afterwards, so a captured graph counts by itself)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    long n, const float* __restrict__ lr_dev, const float* __restrict__ step_dev, float b1, float b2,
+                                                    float eps, float wd, float gscale) {
+  const float lr = *lr_dev, t = *step_dev + 1.f;
+  const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+  const float step_size = lr / bc1, decay = 1.f - lr * wd;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i] * gscale;
+    const float w = p[i] * decay;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = w - step_size * mi / (sqrtf(vi) / bc2s + eps);
+  }
+}
+
+__global__ void step_inc_kernel(float* step_dev) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *step_dev += 1.f;
+}
+
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const float* __restrict__ s, long n, const float* __restrict__ alpha_dev) {
   const float a = *alpha_dev;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) t[i] = t[i] * a + s[i] * (1.f - a);
@@ -578,6 +601,15 @@ extern "C" int hpfg_sgd_step(float* p, const float* g, float* mom, long n, const
   HPFG_ARG_CHECK(p && g && mom && lr_dev && n > 0, "sgd_step: bad args");
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, mom, n, lr_dev, momentum, weight_decay, grad_scale);
   return hpfg_launch_status("sgd_kernel");
+}
+
+extern "C" int hpfg_adamw_step(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float* step_dev, float beta1, float beta2,
+                               float eps, float weight_decay, float grad_scale, void* stream) {
+  HPFG_ARG_CHECK(p && g && m && v && lr_dev && step_dev && n > 0, "adamw_step: bad args");
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_dev, step_dev, beta1, beta2, eps,
+                     weight_decay, grad_scale);
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev);
+  return hpfg_launch_status("adamw_kernel");
 }
 
 extern "C" int hpfg_ema_update(float* t, const float* s, long n, const float* alpha_dev, void* stream) {

@@ -58,6 +58,66 @@ class FusedSGD(torch.optim.Optimizer):
             self._mom.copy_(mom)
 
 
+def flatten_parameters(model):
+    """Re-point every parameter of `model` at a slice of ONE flat fp32 buffer (and its .grad at a slice of one flat gradient buffer), so
+    that an optimizer step is a single kernel.  The hpfg_amd U-Nets are built that way; this does it for any module (SegFormer).
+    Must run after the module is on its device.  Sets model.flat_params / model.flat_grads."""
+    if hasattr(model, "flat_params"):
+        return
+    ps = [p for p in model.parameters()]
+    dev = ps[0].device
+    n = sum(p.numel() for p in ps)
+    flat = torch.empty(n, dtype=torch.float32, device=dev)
+    grad = torch.zeros(n, dtype=torch.float32, device=dev)
+    o = 0
+    with torch.no_grad():
+        for p in ps:
+            k = p.numel()
+            flat[o:o + k].copy_(p.detach().reshape(-1))
+            p.data = flat[o:o + k].view(p.shape)
+            p.grad = grad[o:o + k].view(p.shape)
+            o += k
+    model.flat_params, model.flat_grads = flat, grad
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW(lr, weight_decay) -- betas (0.9, 0.999), eps 1e-8 as the reference leaves them (utils/__init__.py:17-19) -- as ONE
+    HIP kernel over the model's flat parameter / gradient / moment buffers; learning rate and step count live on the device, so the
+    update replays inside a hipGraph.  A ``torch.optim.Optimizer`` (param_groups, zero_grad), so the LR schedulers drive it unchanged."""
+
+    def __init__(self, model, lr=1e-3, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8):
+        flatten_parameters(model)
+        self.model = model
+        super().__init__([p for p in model.parameters() if p.requires_grad], dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps))
+        flat = model.flat_params
+        self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
+        self._step_dev = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self._lr_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+        self._lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.model.flat_grads.zero_()          # one memset; the p.grad views stay attached (autograd accumulates into them)
+        for p, g in ((p, p.grad) for p in self.model.parameters()):
+            if g is None:                       # a detached view can be dropped by user code: re-attach
+                raise RuntimeError("FusedAdamW: a parameter lost its gradient view; call flatten_parameters(model) again")
+
+    def push_lr(self):
+        self._lr_host[0] = float(self.param_groups[0]["lr"])
+        self._lr_dev.copy_(self._lr_host, non_blocking=True)
+
+    @torch.no_grad()
+    def step(self, closure=None, push_lr: bool = True):
+        g = self.param_groups[0]
+        flat, grad = self.model.flat_params, self.model.flat_grads
+        if push_lr:
+            self.push_lr()
+        st = torch.cuda.current_stream(flat.device).cuda_stream
+        L.check(L.load().hpfg_adamw_step(L.ptr(flat), L.ptr(grad), L.ptr(self._m), L.ptr(self._v), flat.numel(), L.ptr(self._lr_dev), L.ptr(self._step_dev),
+                                         float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), float(self.grad_scale), st),
+                "adamw_step")
+
+
 def build_optimizer(args, model):
     if args.opt == "sgd":
         if hasattr(model, "flat_params") and model.flat_params.is_cuda:
@@ -66,10 +126,7 @@ def build_optimizer(args, model):
     if args.opt == "adamW":
         params = list(model.parameters())
         if params and params[0].is_cuda:
-            # capturable: step counters and the learning rate live on the device, so the update can be replayed inside a hipGraph
-            # (torch's schedulers fill a tensor lr in place)
-            lr = torch.tensor(float(args.lr), dtype=torch.float32, device=params[0].device)
-            return torch.optim.AdamW(params, lr=lr, weight_decay=args.weight_decay, capturable=True)
+            return FusedAdamW(model, lr=args.lr, weight_decay=args.weight_decay)
         return torch.optim.AdamW(params, lr=args.lr, weight_decay=args.weight_decay)
     if args.opt == "adam":
         return torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)

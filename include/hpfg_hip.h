@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 116
+#define HPFG_VERSION 117
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -281,6 +281,10 @@ int hpfg_bnrelu_bwd(const float* x, const float* dy, const float* mean, const fl
 /* torch.optim.SGD(momentum, weight_decay) over a flat parameter buffer (utils/__init__.py:15-16); lr read from device */
 int hpfg_sgd_step(float* p, const float* g, float* mom, long n, const float* lr_dev, float momentum, float weight_decay,
                   float grad_scale, void* stream);
+/* torch.optim.AdamW (utils/__init__.py:17-19: lr, weight_decay; betas (0.9, 0.999), eps 1e-8) over flat buffers; lr and the step count
+ * (float, number of steps already taken; advanced by the call) are read from device memory, so the update replays inside a hipGraph */
+int hpfg_adamw_step(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float* step_dev, float beta1, float beta2, float eps,
+                    float weight_decay, float grad_scale, void* stream);
 /* EMA teacher: t = alpha*t + (1-alpha)*s over flat buffers (utils/utils.py:82-86); alpha read from device */
 int hpfg_ema_update(float* t, const float* s, long n, const float* alpha_dev, void* stream);
 
