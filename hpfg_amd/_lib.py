@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ = range(7)
 LOSS_NSUM = 32
-VERSION = 117
+VERSION = 118
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -118,6 +118,8 @@ PROTOTYPES = {
     "hpfg_dwgelu_bwd_blocks": (_i, [_i, _i, _i]),
     "hpfg_resize_bilinear_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "hpfg_resize_bilinear_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "hpfg_residual_scale": (_i, [_p, _p, _p, _p, _i, _l, _p]),
+    "hpfg_scale_rows": (_i, [_p, _p, _p, _i, _l, _p]),
     "hpfg_im2col_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "hpfg_col2im_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "hpfg_linear_wgrad": (_i, [_p, _p, _p, _p, _l, _i, _i, _p]),

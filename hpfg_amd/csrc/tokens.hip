@@ -662,6 +662,23 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
   }
 }
 
+// ---- residual branch with stochastic depth: out = x + y * s[b] (Block.forward :197-198 with DropPath :23-30; s = 1 or 0 or 1/keep) ----------
+__global__ __launch_bounds__(256) void residual_scale_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ s,
+                                                             float* __restrict__ out, long per_sample4, long total4) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const float sc = s ? s[i / per_sample4] : 1.f;
+    const f32x4 a = reinterpret_cast<const f32x4*>(x)[i], b = reinterpret_cast<const f32x4*>(y)[i];
+    reinterpret_cast<f32x4*>(out)[i] = a + b * sc;
+  }
+}
+
+// dy_branch = dout * s[b]
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ d, const float* __restrict__ s, float* __restrict__ out,
+                                                         long per_sample4, long total4) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total4; i += (long)gridDim.x * 256)
+    reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(d)[i] * s[i / per_sample4];
+}
+
 inline int grid_cap(long total, int cap) {
   long b = (total + 255) / 256;
   if (b < 1) b = 1;
@@ -688,8 +705,9 @@ extern "C" int hpfg_ln_bwd(const float* x, const float* dy, const float* gamma, 
   const int nblk = hpfg_ln_bwd_blocks(rows);
   const int per = (int)((rows + nblk - 1) / nblk);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, dy, gamma, mean, rstd, dx, partials, rows, C, per);
-  hipLaunchKernelGGL(col_reduce_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials, nblk, 2 * C, dgamma);
-  hipLaunchKernelGGL(col_reduce_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials + C, nblk, 2 * C, dbeta);
+  // dgamma and dbeta are adjacent halves of ONE [2][C] output: a single reduction launch
+  HPFG_ARG_CHECK(dbeta == dgamma + C, "ln_bwd: dgamma and dbeta must be the two halves of one [2][C] buffer");
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(2 * C), dim3(64), 0, (hipStream_t)stream, partials, nblk, 2 * C, dgamma);
   return hpfg_launch_status("ln_bwd_kernel");
 }
 
@@ -723,8 +741,8 @@ extern "C" int hpfg_dwgelu_bwd(const float* x, const float* w9, const float* bia
   const int nblk = hpfg_dwgelu_bwd_blocks(B, H, W);
   hipLaunchKernelGGL(dwgelu_bwd_du_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, w9, bias, dy, du, partials, B, H, W, C);
   hipLaunchKernelGGL(dw_bwd_dx_kernel, dim3(grid_cap((long)B * H * W * (C / 4), 8192)), dim3(256), 0, (hipStream_t)stream, du, w9, dx, B, H, W, C);
-  hipLaunchKernelGGL(col_reduce_kernel, dim3(9 * C), dim3(64), 0, (hipStream_t)stream, partials, nblk, 10 * C, dw9);
-  hipLaunchKernelGGL(col_reduce_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials + 9 * C, nblk, 10 * C, dbias);
+  HPFG_ARG_CHECK(dbias == dw9 + 9 * C, "dwgelu_bwd: dw9 and dbias must be one [10][C] buffer");
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(10 * C), dim3(64), 0, (hipStream_t)stream, partials, nblk, 10 * C, dw9);
   return hpfg_launch_status("dwgelu_bwd_kernel");
 }
 
@@ -816,4 +834,18 @@ extern "C" int hpfg_col2im_nhwc(const float* dcols, float* dx, int B, int H, int
   if (C % 4 == 0) hipLaunchKernelGGL(col2im_kernel<4>, dim3(grid_cap(total, 16384)), dim3(256), 0, (hipStream_t)stream, dcols, dx, B, H, W, C, k, s, p, Ho, Wo);
   else hipLaunchKernelGGL(col2im_kernel<1>, dim3(grid_cap(total, 16384)), dim3(256), 0, (hipStream_t)stream, dcols, dx, B, H, W, C, k, s, p, Ho, Wo);
   return hpfg_launch_status("col2im_kernel");
+}
+
+extern "C" int hpfg_residual_scale(const float* x, const float* y, const float* scale, float* out, int B, long per_sample, void* stream) {
+  HPFG_ARG_CHECK(x && y && out && B > 0 && per_sample > 0 && per_sample % 4 == 0, "residual_scale: bad args");
+  const long total4 = (long)B * per_sample / 4;
+  hipLaunchKernelGGL(residual_scale_kernel, dim3(grid_cap(total4, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, scale, out, per_sample / 4, total4);
+  return hpfg_launch_status("residual_scale_kernel");
+}
+
+extern "C" int hpfg_scale_rows(const float* d, const float* scale, float* out, int B, long per_sample, void* stream) {
+  HPFG_ARG_CHECK(d && scale && out && B > 0 && per_sample > 0 && per_sample % 4 == 0, "scale_rows: bad args");
+  const long total4 = (long)B * per_sample / 4;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_cap(total4, 8192)), dim3(256), 0, (hipStream_t)stream, d, scale, out, per_sample / 4, total4);
+  return hpfg_launch_status("scale_rows_kernel");
 }

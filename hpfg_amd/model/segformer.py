@@ -10,8 +10,8 @@ Same module tree, parameter names and constructor order as the reference's ``mod
   stride, so it is a GEMM over non-overlapping patches), the patch embeddings (after im2col), the head's per-stage projections, the
   1x1 fuse and prediction convs, dK / dV of the attention backward -- except the weight gradients of the
   Linear layers that see >= 8192 tokens (tall-skinny dY^T X), which run on a row-split HIP kernel with a fixed-order reduction;
-* still plain PyTorch-ROCm ops in this version (to be replaced): the channel concat of the head, residual adds,
-  the drop-path scaling and the token <-> image reshapes.
+* still plain PyTorch-ROCm ops in this version (to be replaced): the channel concat of the head and the token <-> image reshapes
+  (residual adds with their drop-path factor are one HIP kernel, `residual_scale`).
 No MIOpen call is left in the module: with MIOpen convolutions / BatchNorm the forward was not bit-reproducible between identical runs
 (logits differing by ~4e-7), and one ReLU gate of the head flipping on such noise moves every gradient upstream by ~1e-3; without it the
 forward is bit-identical run to run.
@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops_tokens import attention, bn_relu_dropout, dwconv_gelu, im2col, layer_norm, linear, resize_bilinear
+from ..ops_tokens import attention, bn_relu_dropout, dwconv_gelu, im2col, layer_norm, linear, residual_scale, resize_bilinear
 
 MIT_SETTINGS = {"B0": [[32, 64, 160, 256], [2, 2, 2, 2]]}
 HEADS, SR = [1, 2, 5, 8], [8, 4, 2, 1]
@@ -100,16 +100,20 @@ class Block(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = MLP(dim, int(dim * 4))
 
-    def _drop_path(self, y, draw):
+    def _keep_scale(self, batch, draw, device):
+        """Per-sample factor of a residual branch (DropPath, segformer.py:23-30): floor(keep + U) / keep, or None when nothing is dropped."""
         if self.dpr == 0.0 or not self.training:
-            return y
+            return None
         kp = 1.0 - self.dpr
-        r = torch.rand((y.shape[0], 1, 1), dtype=y.dtype, device=y.device) if draw is None else draw.to(y.device)
-        return y.div(kp) * (kp + r).floor()
+        r = torch.rand((batch, 1, 1), dtype=torch.float32, device=device) if draw is None else draw.to(device)
+        return (kp + r).floor() / kp
 
     def forward(self, x, H, W, draws=(None, None)):
-        x = x + self._drop_path(self.attn(layer_norm(x, self.norm1.weight, self.norm1.bias), H, W), draws[0])
-        return x + self._drop_path(self.mlp(layer_norm(x, self.norm2.weight, self.norm2.bias), H, W), draws[1])
+        B = x.shape[0]
+        a = self.attn(layer_norm(x, self.norm1.weight, self.norm1.bias), H, W)
+        x = residual_scale(x, a, self._keep_scale(B, draws[0], x.device))
+        m = self.mlp(layer_norm(x, self.norm2.weight, self.norm2.bias), H, W)
+        return residual_scale(x, m, self._keep_scale(B, draws[1], x.device))
 
 
 class MiT(nn.Module):

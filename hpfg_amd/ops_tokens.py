@@ -40,7 +40,8 @@ class _LayerNorm(torch.autograd.Function):
         rows = x.numel() // C_
         dyc = dy.contiguous()
         dx = torch.empty_like(x)
-        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        dgb = torch.empty(2, C_, dtype=torch.float32, device=x.device)          # [dgamma ; dbeta]: one reduction launch fills both
+        dg, db = dgb[0], dgb[1]
         part = torch.empty(lib.hpfg_ln_bwd_blocks(rows) * 2 * C_, dtype=torch.float32, device=x.device)
         L.check(lib.hpfg_ln_bwd(L.ptr(x), L.ptr(dyc), L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(part), rows, C_,
                                 _st(x)), "ln_bwd")
@@ -114,7 +115,8 @@ class _DWGelu(torch.autograd.Function):
         B, H, W, C_ = x.shape
         dyc = dy.contiguous()
         du, dx = torch.empty_like(x), torch.empty_like(x)
-        dw9, db = torch.empty_like(w9), torch.empty_like(bias)
+        dwb = torch.empty(10, C_, dtype=torch.float32, device=x.device)         # [dw9 (9 rows) ; dbias]: one reduction launch fills both
+        dw9, db = dwb[:9], dwb[9]
         part = torch.empty(lib.hpfg_dwgelu_bwd_blocks(B, H, W) * 10 * C_, dtype=torch.float32, device=x.device)
         L.check(lib.hpfg_dwgelu_bwd(L.ptr(x), L.ptr(w9), L.ptr(bias), L.ptr(dyc), L.ptr(du), L.ptr(dx), L.ptr(dw9), L.ptr(db), L.ptr(part), B, H, W, C_,
                                     _st(x)), "dwgelu_bwd")
@@ -264,3 +266,32 @@ class _Im2col(torch.autograd.Function):
 def im2col(x: torch.Tensor, k: int, s: int) -> torch.Tensor:
     """Patches of a conv with kernel k, stride s, padding k // 2 over NHWC x [B,H,W,C] -> [B, Ho*Wo, k*k*C], patch order (u, v, c)."""
     return _Im2col.apply(x, k, s)
+
+
+class _ResidualScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, scale):
+        _need_gpu(x, "residual_scale")
+        xc, yc = x.contiguous().float(), y.contiguous().float()
+        B = xc.shape[0]
+        per = xc.numel() // B
+        out = torch.empty_like(xc)
+        sc = None if scale is None else scale.reshape(B).float().contiguous()
+        L.check(L.load().hpfg_residual_scale(L.ptr(xc), L.ptr(yc), L.ptr(sc), L.ptr(out), B, per, _st(x)), "residual_scale")
+        ctx.sc, ctx.geo = sc, (B, per)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.sc is None:
+            return dout, dout, None
+        B, per = ctx.geo
+        d = dout.contiguous()
+        dy = torch.empty_like(d)
+        L.check(L.load().hpfg_scale_rows(L.ptr(d), L.ptr(ctx.sc), L.ptr(dy), B, per, _st(d)), "scale_rows")
+        return dout, dy, None
+
+
+def residual_scale(x: torch.Tensor, y: torch.Tensor, scale=None) -> torch.Tensor:
+    """x + y * scale[b] per sample b (scale None = 1): a residual branch with stochastic depth in one kernel."""
+    return _ResidualScale.apply(x, y, scale)

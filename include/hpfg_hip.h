@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 117
+#define HPFG_VERSION 118
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -240,7 +240,7 @@ int hpfg_cutmix_blend(const float* a, const float* b, const float* mask, float* 
 /* ---- token-layout ops of the SegFormer branch (model/segformer.py).  [B,N,C] tokens == NHWC pixels. --- */
 /* nn.LayerNorm(C) (eps 1e-5) over the last dimension (segformer.py:107,174,192,195,232-244); mean / rstd [rows] are kept for backward */
 int hpfg_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long rows, int C, void* stream);
-int hpfg_ln_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
+int hpfg_ln_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta /* == dgamma + C */,
                 float* partials /* [hpfg_ln_bwd_blocks(rows)][2][C] */, long rows, int C, void* stream);
 int hpfg_ln_bwd_blocks(long rows);
 /* Attention.forward :122-126 without its Linear layers: out[b,i,h,:] = softmax_j(scale * q[b,i,h,:].k[b,j,h,:]) v[b,j,h,:];
@@ -252,7 +252,7 @@ int hpfg_attn_bwd(const float* q, const float* kv, const float* dout, float* dq,
 /* DWConv (3x3 depthwise, pad 1, :139-146) + F.gelu (:156) on [B,H,W,C]; w9 = the [C,1,3,3] weight transposed to [9][C] */
 int hpfg_dwgelu_fwd(const float* x, const float* w9, const float* bias, float* y, int B, int H, int W, int C, void* stream);
 int hpfg_dwgelu_bwd(const float* x, const float* w9, const float* bias, const float* dy, float* du /* scratch [B,H,W,C] */, float* dx, float* dw9,
-                    float* dbias, float* partials /* [hpfg_dwgelu_bwd_blocks()][10][C] */, int B, int H, int W, int C, void* stream);
+                    float* dbias /* == dw9 + 9*C */, float* partials /* [hpfg_dwgelu_bwd_blocks()][10][C] */, int B, int H, int W, int C, void* stream);
 int hpfg_dwgelu_bwd_blocks(int B, int H, int W);
 /* F.interpolate(mode="bilinear", align_corners=False) of SegFormerHead.forward (:314,319) on NHWC [B,h,w,C] -> [B,H,W,C]; backward is a
  * gather over the outputs that tap a source pixel (no atomics), upsampling only */
@@ -261,6 +261,10 @@ int hpfg_resize_bilinear_bwd(const float* dy, float* dx, int B, int h, int w, in
 /* ConvModule's BatchNorm2d (train) + ReLU and the head's Dropout2d (segformer.py:288-296,307,318) over tokens [R,C]:
  * column sums (sum x, sum x^2) -> the caller forms mean / rstd (and the running statistics) -> apply; mask [R/rows_per_image][C] of
  * 0/1 keeps (or NULL), scaled by inv_keep.  Backward: sums [2][C] = (sum g, sum g*xhat) = (dbeta, dgamma), then dx. */
+/* residual branch with stochastic depth (Block.forward :197-198, DropPath :23-30): out[b] = x[b] + y[b] * scale[b] (scale NULL = 1); the
+ * branch gradient is dout[b] * scale[b] */
+int hpfg_residual_scale(const float* x, const float* y, const float* scale, float* out, int B, long per_sample, void* stream);
+int hpfg_scale_rows(const float* d, const float* scale, float* out, int B, long per_sample, void* stream);
 /* im2col / col2im of PatchEmbed.proj (segformer.py:172: kernel k, stride s, padding k/2) on NHWC x [B,H,W,C]:
  * cols [B, Ho*Wo, k*k*C] with the patch ordered (u, v, c); col2im is the gather-form transpose (no atomics) */
 int hpfg_im2col_nhwc(const float* x, float* cols, int B, int H, int W, int C, int k, int s, void* stream);

@@ -3,7 +3,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from hpfg_amd.ops_tokens import attention, bn_relu_dropout, dwconv_gelu, im2col, layer_norm, linear, resize_bilinear
+from hpfg_amd.ops_tokens import attention, bn_relu_dropout, dwconv_gelu, im2col, layer_norm, linear, residual_scale, resize_bilinear
 from tests.helpers import maxerr
 
 pytestmark = pytest.mark.gpu
@@ -135,3 +135,17 @@ def test_im2col_matches_conv(B, H, W, C_, k, s):
     y.backward(dy.flatten(2).transpose(1, 2).to(DEV))
     assert maxerr(y.detach().cpu(), yr.detach().flatten(2).transpose(1, 2)) < 1e-4
     assert maxerr(xd.grad.cpu(), xr.grad) < 1e-4
+
+
+def test_residual_scale():
+    g = torch.Generator().manual_seed(1)
+    x, y, s = torch.randn(3, 50, 32, generator=g), torch.randn(3, 50, 32, generator=g), torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.9]).view(3, 1, 1)
+    d = torch.randn(3, 50, 32, generator=g)
+    for sc in (s, None):
+        xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        (xr + (yr * sc if sc is not None else yr)).backward(d)
+        xd, yd = x.to(DEV).requires_grad_(True), y.to(DEV).requires_grad_(True)
+        out = residual_scale(xd, yd, None if sc is None else sc.to(DEV))
+        out.backward(d.to(DEV))
+        assert maxerr(out.detach().cpu(), x + (y * sc if sc is not None else y)) < 1e-6
+        assert maxerr(xd.grad.cpu(), xr.grad) < 1e-6 and maxerr(yd.grad.cpu(), yr.grad) < 1e-6
