@@ -126,7 +126,7 @@ class _StepBase:
     def _reduce_grads(self, *models):
         if self.dp is not None and (self.dp.world_size > 1 or self.dp.force_sync):
             for m in models:
-                if hasattr(m, "flat_grads"):
+                if hasattr(m, "flat_grads") and not hasattr(m, "_hpfg_generic_flat"):
                     self.dp.allreduce_sum(m.flat_grads)
                 else:                      # a model without the flat buffers (SegFormer): one flattened exchange, averaged here when the
                     gs = [p.grad for p in m.parameters() if p.grad is not None]      # optimizer has no gradient scale of its own

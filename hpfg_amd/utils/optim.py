@@ -59,7 +59,7 @@ class FusedSGD(torch.optim.Optimizer):
 
 
 def flatten_parameters(model):
-    """Re-point every parameter of `model` at a slice of ONE flat fp32 buffer (and its .grad at a slice of one flat gradient buffer), so
+    """Re-point every parameter of `model` at a slice of ONE flat fp32 buffer (gradients are packed into a second flat buffer per step), so
     that an optimizer step is a single kernel.  The hpfg_amd U-Nets are built that way; this does it for any module (SegFormer).
     Must run after the module is on its device.  Sets model.flat_params / model.flat_grads."""
     if hasattr(model, "flat_params"):
@@ -75,9 +75,9 @@ def flatten_parameters(model):
             k = p.numel()
             flat[o:o + k].copy_(p.detach().reshape(-1))
             p.data = flat[o:o + k].view(p.shape)
-            p.grad = grad[o:o + k].view(p.shape)
             o += k
     model.flat_params, model.flat_grads = flat, grad
+    model._hpfg_generic_flat = True      # gradients reach flat_grads only through FusedAdamW.gather_flat_grads()
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -96,11 +96,17 @@ class FusedAdamW(torch.optim.Optimizer):
         self._lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.grad_scale = 1.0
 
-    def zero_grad(self, set_to_none: bool = False):
-        self.model.flat_grads.zero_()          # one memset; the p.grad views stay attached (autograd accumulates into them)
-        for p, g in ((p, p.grad) for p in self.model.parameters()):
-            if g is None:                       # a detached view can be dropped by user code: re-attach
-                raise RuntimeError("FusedAdamW: a parameter lost its gradient view; call flatten_parameters(model) again")
+    def zero_grad(self, set_to_none: bool = True):
+        # grads are dropped, not zeroed: autograd then ASSIGNS each parameter's gradient (accumulating into kept views would cost one
+        # add kernel per parameter tensor, 189 launches); gather_flat_grads() packs them into the flat buffer in one concat
+        for p in self.model.parameters():
+            p.grad = None
+
+    @torch.no_grad()
+    def gather_flat_grads(self):
+        ps = [p for p in self.model.parameters()]
+        torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps], out=self.model.flat_grads)
+        return self.model.flat_grads
 
     def push_lr(self):
         self._lr_host[0] = float(self.param_groups[0]["lr"])
@@ -109,7 +115,7 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, push_lr: bool = True):
         g = self.param_groups[0]
-        flat, grad = self.model.flat_params, self.model.flat_grads
+        flat, grad = self.model.flat_params, self.gather_flat_grads()
         if push_lr:
             self.push_lr()
         st = torch.cuda.current_stream(flat.device).cuda_stream
