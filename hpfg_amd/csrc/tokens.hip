@@ -122,6 +122,106 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
   }
 }
 
+// C <= 256: G = 8 / 16 / 32 / 64 lanes per row (one float4 each), 64 / G rows per wave -- with C = 32 the one-row-per-wave kernels above
+// keep 8 of 64 lanes busy
+template <int G>
+__global__ __launch_bounds__(256) void ln_fwd_small_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                           float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, long rows, int C) {
+  constexpr int RW = 64 / G;
+  const int lane = threadIdx.x & 63, q = lane % G, c = q * 4;
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW + lane / G;
+  const bool on = row < rows && c < C;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (on) v = *reinterpret_cast<const f32x4*>(x + row * C + c);
+  float s = v[0] + v[1] + v[2] + v[3];
+#pragma unroll
+  for (int o = G / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  const float mu = s / (float)C;
+  float d2 = 0.f;
+  if (on)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d2 += (v[j] - mu) * (v[j] - mu);
+#pragma unroll
+  for (int o = G / 2; o >= 1; o >>= 1) d2 += __shfl_xor(d2, o);
+  const float rs = rsqrtf(d2 / (float)C + LN_EPS);
+  if (on) {
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c), bb = *reinterpret_cast<const f32x4*>(b + c);
+    f32x4 o4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o4[j] = (v[j] - mu) * rs * gg[j] + bb[j];
+    *reinterpret_cast<f32x4*>(y + row * C + c) = o4;
+    if (q == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void ln_bwd_small_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ g,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
+                                                           float* __restrict__ part, long rows, int C, int rows_per_wg) {
+  constexpr int RW = 64 / G;
+  __shared__ float red[4][2][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane % G, c = q * 4;
+  const bool chan = c < C;
+  f32x4 gg = {0.f, 0.f, 0.f, 0.f};
+  if (chan) gg = *reinterpret_cast<const f32x4*>(g + c);
+  f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = ag;
+  const long r0 = (long)blockIdx.x * rows_per_wg;
+  for (long rb = r0 + wave * RW; rb < r0 + rows_per_wg && rb < rows; rb += 4 * RW) {
+    const long row = rb + lane / G;
+    const bool on = chan && row < rows && row < r0 + rows_per_wg;
+    f32x4 xh = {0.f, 0.f, 0.f, 0.f}, dg = xh;
+    float s1 = 0.f, s2 = 0.f, rs = 0.f;
+    if (on) {
+      const float mu = mean[row];
+      rs = rstd[row];
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * C + c), dv = *reinterpret_cast<const f32x4*>(dy + row * C + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[j] = (xv[j] - mu) * rs;
+        dg[j] = dv[j] * gg[j];
+        s1 += dg[j];
+        s2 += dg[j] * xh[j];
+        ag[j] += dv[j] * xh[j];
+        ab[j] += dv[j];
+      }
+    }
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) {
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    if (on) {
+      const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+      f32x4 o4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o4[j] = rs * (dg[j] - m1 - xh[j] * m2);
+      *reinterpret_cast<f32x4*>(dx + row * C + c) = o4;
+    }
+  }
+  // lanes with the same channel quad (q, q + G, ...) combine, then the four waves
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int o = 32; o >= G; o >>= 1) {
+      ag[j] += __shfl_xor(ag[j], o);
+      ab[j] += __shfl_xor(ab[j], o);
+    }
+  if (lane < G && chan)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[wave][0][c + j] = ag[j];
+      red[wave][1][c + j] = ab[j];
+    }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * C; o += 256) {
+    const int which = o / C, cc = o % C;
+    part[((long)blockIdx.x * 2 + which) * C + cc] = (red[0][which][cc] + red[1][which][cc]) + (red[2][which][cc] + red[3][which][cc]);
+  }
+}
+
 __global__ __launch_bounds__(64) void col_reduce_kernel(const float* __restrict__ part, int nblk, int stride, float* __restrict__ out) {
   const int c = blockIdx.x;
   double a = 0.0;
@@ -689,6 +789,18 @@ inline int grid_cap(long total, int cap) {
 
 extern "C" int hpfg_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long rows, int C, void* stream) {
   HPFG_ARG_CHECK(x && gamma && beta && y && mean && rstd && rows > 0 && C % 4 == 0 && C >= 4 && C <= 1024, "ln_fwd: bad args (C %% 4 == 0, C <= 1024)");
+  const int Q = C / 4;
+  if (Q <= 64) {
+#define LN_FWD_SMALL(G)                                                                                                                              \
+  hipLaunchKernelGGL(ln_fwd_small_kernel<G>, dim3((unsigned)((rows + 4 * (64 / G) - 1) / (4 * (64 / G)))), dim3(256), 0, (hipStream_t)stream, x, gamma, \
+                     beta, y, mean, rstd, rows, C)
+    if (Q <= 8) LN_FWD_SMALL(8);
+    else if (Q <= 16) LN_FWD_SMALL(16);
+    else if (Q <= 32) LN_FWD_SMALL(32);
+    else LN_FWD_SMALL(64);
+#undef LN_FWD_SMALL
+    return hpfg_launch_status("ln_fwd_small_kernel");
+  }
   hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, rows, C);
   return hpfg_launch_status("ln_fwd_kernel");
 }
@@ -704,7 +816,23 @@ extern "C" int hpfg_ln_bwd(const float* x, const float* dy, const float* gamma, 
                  "ln_bwd: bad args");
   const int nblk = hpfg_ln_bwd_blocks(rows);
   const int per = (int)((rows + nblk - 1) / nblk);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, dy, gamma, mean, rstd, dx, partials, rows, C, per);
+  const int Q = C / 4;
+  if (Q <= 64) {
+    const int G = Q <= 8 ? 8 : (Q <= 16 ? 16 : (Q <= 32 ? 32 : 64));
+    const int step = 4 * (64 / G);                        // rows one workgroup sweep covers
+    const int per_s = (per + step - 1) / step * step;     // whole sweeps per workgroup
+    const int nb = (int)((rows + per_s - 1) / per_s);     // <= nblk; the unused partial rows are zeroed by the extra workgroups below
+    (void)nb;
+#define LN_BWD_SMALL(GG) \
+  hipLaunchKernelGGL(ln_bwd_small_kernel<GG>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, dy, gamma, mean, rstd, dx, partials, rows, C, per_s)
+    if (G == 8) LN_BWD_SMALL(8);
+    else if (G == 16) LN_BWD_SMALL(16);
+    else if (G == 32) LN_BWD_SMALL(32);
+    else LN_BWD_SMALL(64);
+#undef LN_BWD_SMALL
+  } else {
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, dy, gamma, mean, rstd, dx, partials, rows, C, per);
+  }
   // dgamma and dbeta are adjacent halves of ONE [2][C] output: a single reduction launch
   HPFG_ARG_CHECK(dbeta == dgamma + C, "ln_bwd: dgamma and dbeta must be the two halves of one [2][C] buffer");
   hipLaunchKernelGGL(col_reduce_kernel, dim3(2 * C), dim3(64), 0, (hipStream_t)stream, partials, nblk, 2 * C, dgamma);
