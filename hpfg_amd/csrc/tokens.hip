@@ -666,45 +666,56 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_apply_kernel(const float* __re
 // (the library GEMM picks a single-pass kernel for this tall-skinny shape: ~300 us for R = 100 352, N x K = 32 x 128.)  Split the rows
 // over blockIdx.y, 64 x 64 output tile per blockIdx.x, 4 x 4 outputs per thread from LDS-staged 64-row panels; the per-split partial
 // matrices are summed in a fixed order by col_reduce_kernel.
+template <int TN, int TK>
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, long R,
                                                            int N, int K, int rows_per_split) {
-  __shared__ float sa[64][64 + 4], sb[64][64 + 4];
-  const int tiles_k = (K + 63) / 64;
-  const int n0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
-  const int tn = (threadIdx.x / 16) * 4, tk = (threadIdx.x % 16) * 4;
-  float acc[4][4];
+  constexpr int MN = TN / 16, MK = TK / 16;          // outputs per thread: MN x MK (16 x 16 threads)
+  __shared__ float sa[64][TN + 4], sb[64][TK + 4];
+  const int tiles_k = (K + TK - 1) / TK;
+  const int n0 = (blockIdx.x / tiles_k) * TN, k0 = (blockIdx.x % tiles_k) * TK;
+  const int tn = (threadIdx.x / 16) * MN, tk = (threadIdx.x % 16) * MK;
+  float acc[MN][MK];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MN; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int j = 0; j < MK; ++j) acc[i][j] = 0.f;
   const long r0 = (long)blockIdx.y * rows_per_split, r1 = r0 + rows_per_split < R ? r0 + rows_per_split : R;
   for (long rb = r0; rb < r1; rb += 64) {
     __syncthreads();
-    for (int e = threadIdx.x; e < 64 * 16; e += 256) {          // 64 rows x 16 float4 per panel
-      const int rr = e / 16, c4 = (e % 16) * 4;
+    for (int e = threadIdx.x; e < 64 * (TN / 4); e += 256) {
+      const int rr = e / (TN / 4), c4 = (e % (TN / 4)) * 4;
       const long r = rb + rr;
-      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = va;
-      if (r < r1) {
-        if (n0 + c4 < N) va = *reinterpret_cast<const f32x4*>(dy + r * N + n0 + c4);
-        if (k0 + c4 < K) vb = *reinterpret_cast<const f32x4*>(x + r * K + k0 + c4);
-      }
+      f32x4 va = {0.f, 0.f, 0.f, 0.f};
+      if (r < r1 && n0 + c4 < N) va = *reinterpret_cast<const f32x4*>(dy + r * N + n0 + c4);
       *reinterpret_cast<f32x4*>(&sa[rr][c4]) = va;
+    }
+    for (int e = threadIdx.x; e < 64 * (TK / 4); e += 256) {
+      const int rr = e / (TK / 4), c4 = (e % (TK / 4)) * 4;
+      const long r = rb + rr;
+      f32x4 vb = {0.f, 0.f, 0.f, 0.f};
+      if (r < r1 && k0 + c4 < K) vb = *reinterpret_cast<const f32x4*>(x + r * K + k0 + c4);
       *reinterpret_cast<f32x4*>(&sb[rr][c4]) = vb;
     }
     __syncthreads();
 #pragma unroll 8
     for (int rr = 0; rr < 64; ++rr) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(&sa[rr][tn]), b = *reinterpret_cast<const f32x4*>(&sb[rr][tk]);
+      float a[MN], b[MK];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MN; ++i) a[i] = sa[rr][tn + i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+      for (int j = 0; j < MK; ++j) b[j] = sb[rr][tk + j];
+#pragma unroll
+      for (int i = 0; i < MN; ++i)
+#pragma unroll
+        for (int j = 0; j < MK; ++j) acc[i][j] += a[i] * b[j];
     }
   }
   float* o = part + (long)blockIdx.y * N * K;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (n0 + tn + i < N && k0 + tk < K) *reinterpret_cast<f32x4*>(o + (long)(n0 + tn + i) * K + k0 + tk) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+  for (int i = 0; i < MN; ++i)
+#pragma unroll
+    for (int j = 0; j < MK; ++j)
+      if (n0 + tn + i < N && k0 + tk + j < K) o[(long)(n0 + tn + i) * K + k0 + tk + j] = acc[i][j];
 }
 
 // ---- im2col / col2im of the overlap patch embeddings (PatchEmbed.proj, segformer.py:172: kernel k, stride s, padding k/2), NHWC ----------
@@ -925,8 +936,15 @@ extern "C" int hpfg_bnrelu_bwd(const float* x, const float* dy, const float* mea
   return hpfg_launch_status("bnrelu_bwd_kernel");
 }
 
+static void lw_tile(int N, int K, int& TN, int& TK) {
+  TN = N <= 32 ? 32 : 64;
+  TK = K <= 32 ? 32 : 64;
+}
+
 extern "C" int hpfg_linear_wgrad_splits(long R, int N, int K) {
-  const long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
+  int TN, TK;
+  lw_tile(N, K, TN, TK);
+  const long tiles = (long)((N + TN - 1) / TN) * ((K + TK - 1) / TK);
   long s = 2048 / tiles;                       // ~8 workgroups per CU in total
   const long by_rows = (R + 255) / 256;        // at least 256 rows per split
   if (s > by_rows) s = by_rows;
@@ -939,8 +957,13 @@ extern "C" int hpfg_linear_wgrad(const float* dy, const float* x, float* dw, flo
   const int S = hpfg_linear_wgrad_splits(R, N, K);
   int per = (int)((R + S - 1) / S);
   per = (per + 63) / 64 * 64;
-  dim3 grid(((N + 63) / 64) * ((K + 63) / 64), S);
-  hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, x, partials, R, N, K, per);
+  int TN, TK;
+  lw_tile(N, K, TN, TK);
+  dim3 grid(((N + TN - 1) / TN) * ((K + TK - 1) / TK), S);
+  if (TN == 32 && TK == 32) hipLaunchKernelGGL((linear_wgrad_kernel<32, 32>), grid, dim3(256), 0, (hipStream_t)stream, dy, x, partials, R, N, K, per);
+  else if (TN == 32) hipLaunchKernelGGL((linear_wgrad_kernel<32, 64>), grid, dim3(256), 0, (hipStream_t)stream, dy, x, partials, R, N, K, per);
+  else if (TK == 32) hipLaunchKernelGGL((linear_wgrad_kernel<64, 32>), grid, dim3(256), 0, (hipStream_t)stream, dy, x, partials, R, N, K, per);
+  else hipLaunchKernelGGL((linear_wgrad_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, dy, x, partials, R, N, K, per);
   const long NK = (long)N * K;
   hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((NK + 63) / 64)), dim3(256), 0, (hipStream_t)stream, partials, S, NK, dw);
   return hpfg_launch_status("linear_wgrad_kernel");
