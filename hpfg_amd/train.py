@@ -128,12 +128,10 @@ class _StepBase:
             for m in models:
                 if hasattr(m, "flat_grads") and not hasattr(m, "_hpfg_generic_flat"):
                     self.dp.allreduce_sum(m.flat_grads)
-                else:                      # a model without the flat buffers (SegFormer): one flattened exchange, averaged here when the
-                    gs = [p.grad for p in m.parameters() if p.grad is not None]      # optimizer has no gradient scale of its own
-                    flat = torch.cat([g.reshape(-1) for g in gs])
+                else:                      # a model whose gradients live in per-parameter tensors (SegFormer): one flattened exchange of the
+                    gs = [p.grad for p in m.parameters() if p.grad is not None]      # SUM; the 1/world of the per-rank-BatchNorm mode is the
+                    flat = torch.cat([g.reshape(-1) for g in gs])                    # optimizer's grad_scale (FusedSGD / FusedAdamW), as for the U-Nets
                     self.dp.allreduce_sum(flat)
-                    if not getattr(self.dp, "sync_bn", True):
-                        flat.div_(self.dp.world_size)
                     o = 0
                     for g in gs:
                         g.copy_(flat[o:o + g.numel()].view_as(g))

@@ -102,3 +102,38 @@ def test_sync_path_captures_into_a_graph(dp):
     """RCCL collectives inside the captured step (what bench.py does for N > 1 when HPFG_DP_GRAPH=1)."""
     lg, _ = _run(dp, graphed=True, steps=2)
     assert all(x == x and abs(x) < 10 for x in lg)
+
+
+def test_ctct_step_on_the_data_parallel_path(dp):
+    """The cross-teaching step with a model that has no HIP engine of its own (SegFormer: gradients exchanged as one flattened buffer,
+    FusedAdamW) on a 1-rank group: same losses and weights as without the group, in both BatchNorm modes."""
+    from hpfg_amd.model import SegFormer
+    from hpfg_amd.train import CTCTStep
+    from oracle import segformer_ref as S
+
+    def run(ctx):
+        torch.manual_seed(9)
+        m1, m2 = UNet(1, 4).to(DEV), SegFormer(image_size=[64, 64], in_channels=1, num_classes=4).to(DEV)
+        m1.train()
+        m2.train()
+        opt = dict(opt="sgd", lr=0.01, momentum=0.9, weight_decay=5e-4, sched="medical", total_itrs=30000, step_size=1500, warmup_epochs=1, warmup_lr=1e-4,
+                   min_lr=1e-6)
+        a = AttrDict(dict(model1=AttrDict(opt), model2=AttrDict(dict(opt, opt="adamW", lr=0.0008, weight_decay=0.05)), consistency=0.1,
+                          consistency_rampup=200.0))
+        st = CTCTStep(m1, m2, a, ctx)
+        xl, yl = synth_batch(1, 2, 64, 64, 1, 4, 8)
+        xu, _ = synth_batch(2, 2, 64, 64, 1, 4, 8)
+        losses = []
+        for k in range(1, 4):
+            torch.manual_seed(100 + k)
+            m2.external_draws = S.draw_randomness(4)
+            losses.append(float(st.step(xl.to(DEV), yl.to(DEV), xu.to(DEV), k, cons_w=0.05)["loss"]))
+        return losses, m2.flat_params.clone(), m1.flat_params.clone()
+
+    l0, s0, u0 = run(None)
+    for sync_bn in (True, False):
+        dp.sync_bn = sync_bn
+        l1, s1, u1 = run(dp)
+        assert max(abs(a - b) for a, b in zip(l0, l1)) < 1e-5, (sync_bn, l0, l1)
+        assert maxerr(s0, s1) < 1e-5 and maxerr(u0, u1) < 1e-5, sync_bn
+    dp.sync_bn = True
