@@ -122,6 +122,7 @@ class UNetEngine:
         self.math = L.MATH_F32      # L.MATH_BF16X3 selects the split-bf16 matrix-core kernels for conv forward / dgrad
         self.ext_masks: Dict[str, torch.Tensor] = {}   # conv name -> uint8 NHWC keep-mask (parity tests replaying torch's masks)
         self.allreduce = None    # callable(tensor) -> in-place sum across ranks (data parallel), set by hpfg_amd.parallel
+        self.probe = None        # bench.py: (conv name, [(event, event), ...]) -- HIP events around that layer's forward launch (eager steps only)
 
     # ---------------------------------------------------------------------------------------------------------
     def _stream(self):
@@ -260,7 +261,14 @@ class UNetEngine:
                 ca.stat_partials = L.ptr(self.partials) if want_stats else None
                 ca.out_pstride, ca.Cout, ca.CoutPad = s.cout, s.cout, s.cout_pad
                 ca.N, ca.H, ca.W, ca.taps = self.N, s.h, s.w, s.taps
+                probe = self.probe is not None and self.probe[0] == s.name
+                if probe:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(torch.cuda.current_stream(self.dev))
                 L.check(self.lib.hpfg_conv_fwd(C.byref(ca), st), f"conv_fwd[{s.name}]")
+                if probe:
+                    e1.record(torch.cuda.current_stream(self.dev))
+                    self.probe[1].append((e0, e1))
                 if want_stats:
                     nblk = self.lib.hpfg_conv_stat_rows(C.byref(ca))
             if s.bn:
@@ -338,6 +346,9 @@ class UNetEngine:
             d.taps, d.Cin, d.CinPad, d.Cout, d.CoutPad = 1, 1, 1, s.cout, s.cout
         self._slab_host = descs
         self._slab_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.dev)
+        # descriptor order = encoder convs | decoder convs | bias pseudo layers (all decoder): two contiguous ranges, so the decoder's
+        # weight gradients can be finished (and handed to the data-parallel all-reduce) while the encoder half still back-propagates
+        self._n_enc_desc = sum(1 for s in self.order if s.name.startswith("encoder."))
         self._bwd_alloc = True
 
     def _bn_backward(self, s: ConvSpec, pooled_grad: Optional[torch.Tensor] = None):
@@ -423,8 +434,17 @@ class UNetEngine:
             self._fused_rows[stats_for] = rows
         L.check(self.lib.hpfg_conv_fwd(C.byref(ca), self._stream()), f"dgrad[{s.name}]")
 
-    def backward(self, dlogits: torch.Tensor, dfeat4: Optional[torch.Tensor] = None):
+    def _slab_reduce(self, lo: int, hi: int):
+        """Sum the weight-gradient slabs of descriptors [lo, hi) into the gradient buffer (one launch)."""
+        sz = C.sizeof(L.SlabDesc)
+        host = (L.SlabDesc * (hi - lo)).from_buffer(self._slab_host, lo * sz)
+        L.check(self.lib.hpfg_slab_reduce_multi(self._slab_dev.data_ptr() + lo * sz, host, hi - lo, self._stream()), "slab_reduce_multi")
+
+    def backward(self, dlogits: torch.Tensor, dfeat4: Optional[torch.Tensor] = None, bucket_cb=None):
         """dlogits: [N,H,W,ncls] contiguous.  dfeat4: optional gradient w.r.t. the activated bottleneck [N,h,w,256].
+        bucket_cb: optional callable(i); called with 0 once every DECODER parameter gradient is final (queued on the current stream:
+        decoder slabs reduced by a launch of their own) and with 1 after the encoder's -- data parallel: the decoder bucket is
+        all-reduced on a side stream while the encoder half of backward still computes (hpfg_amd.parallel.GradBuckets).
         Writes every parameter gradient of encoder/decoder into self.grads (overwrite).  Biases of convs that feed a
         train-mode BatchNorm have an exactly zero gradient (the batch mean removes them); their slots are never written and
         rely on the zero-initialised gradient buffer."""
@@ -458,6 +478,12 @@ class UNetEngine:
             self._wgrad_dgrad(su, gu, self.dA[prev], prev if (k > 1 or dfeat4 is None) else None)
         if dfeat4 is not None:
             self.dA[enc_prefix(4) + ".4"].add_(dfeat4)
+        if bucket_cb is not None:
+            if self._side_used:
+                torch.cuda.current_stream(self.dev).wait_stream(self._side)
+                self._side_used = False
+            self._slab_reduce(self._n_enc_desc, len(self._slab_host))
+            bucket_cb(0)
         # ---- encoder blocks, deepest first
         for lvl in range(4, -1, -1):
             p = enc_prefix(lvl)
@@ -473,5 +499,9 @@ class UNetEngine:
         if self._side_used:
             torch.cuda.current_stream(self.dev).wait_stream(self._side)
             self._side_used = False
-        L.check(self.lib.hpfg_slab_reduce_multi(self._slab_dev.data_ptr(), self._slab_host, len(self._slab_host), st), "slab_reduce_multi")
+        if bucket_cb is not None:
+            self._slab_reduce(0, self._n_enc_desc)
+            bucket_cb(1)
+        else:
+            self._slab_reduce(0, len(self._slab_host))
         self.bwd_ready = False

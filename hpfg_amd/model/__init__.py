@@ -1,3 +1,3 @@
 from .builder import build_model
 from .segformer import SegFormer
-from .unet import UNet, UNet_Plus
+from .unet import UNet, UNet_Plus, reset_dropout_streams

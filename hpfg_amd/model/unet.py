@@ -25,6 +25,27 @@ from .. import heads
 
 WIDTHS = E.WIDTHS
 
+_INSTANCES = [0]
+
+
+def reset_dropout_streams(count: int = 0) -> None:
+    """Restart the numbering of the per-instance dropout streams: two runs that construct their networks in the same order after
+    the same ``torch.manual_seed`` then draw identical masks (run-to-run reproducibility inside one process)."""
+    _INSTANCES[0] = int(count)
+
+
+def _fresh_dropout_seed() -> int:
+    """A dropout stream of its own for every network instance (student / teacher / model1 / model2 draw independent masks, as the
+    reference's separate nn.Dropout calls do: 2017_03_NIPS_Mean-Teacher_ACDC.py:95-101 feeds both nets the same x, the masks are
+    the perturbation).  Derived from a process-wide instance counter, NOT from torch's generator: constructing a model must
+    consume the RNG exactly like the reference's constructor so that seeded initial weights stay bit-equal."""
+    _INSTANCES[0] += 1
+    h = (0x1234567 + _INSTANCES[0] * 0x9E3779B1 + (torch.initial_seed() & 0xFFFFFFFF) * 0x85EBCA6B) & 0xFFFFFFFF      # reads, never advances, torch's generator
+    h ^= h >> 15
+    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h ^= h >> 13
+    return h & 0x7FFFFFFF
+
 
 def _block(cin: int, cout: int) -> nn.Module:
     """Parameter container with the key layout of the reference's ConvBlock (unet.py:15-25): conv_conv.{0,1,4,5}."""
@@ -79,7 +100,13 @@ class _UNetFn(torch.autograd.Function):
         df = None
         if ctx.want_feat and dfeat is not None:
             df = dfeat.permute(0, 2, 3, 1).contiguous()
-        eng.backward(dl, df)
+        dp = net.dp
+        cb = None
+        if dp is not None and dp.active and getattr(dp, "overlap", False) and getattr(eng, "direct", False):
+            # data parallel: hand each finished slice of the flat gradient buffer to the all-reduce while backward continues
+            cb = lambda i: dp.launch_bucket(net.grad_bucket(i))
+            net._buckets_launched = True
+        eng.backward(dl, df, cb)
         net._accumulate_grads(eng)
         return None, None, None, None, None
 
@@ -108,7 +135,7 @@ class UNet(nn.Module):
         self._engines: Dict[Tuple, List[E.UNetEngine]] = {}
         self._anchor: Optional[torch.Tensor] = None
         self._seed_counter = 0
-        self.dropout_seed = 0x1234567
+        self.dropout_seed = _fresh_dropout_seed()
         self.dp = None   # hpfg_amd.parallel.DataParallelContext or None
         self.math = os.environ.get("HPFG_MATH", "bf16x3")   # "bf16x3": split-bf16 MFMA, fp32 accumulate (default); "f32": exact fp32 MFMA
         self.external_dropout_masks = None   # optional {conv name: uint8 NHWC keep-mask}: replay masks drawn elsewhere (tests)
@@ -149,6 +176,7 @@ class UNet(nn.Module):
         self._engines = {}
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
         self._backbone_numel = sum(p.numel() for n, p in ps if n.startswith("encoder.") or n.startswith("decoder."))
+        self._encoder_numel = sum(p.numel() for n, p in ps if n.startswith("encoder."))
 
     def _is_flat(self) -> bool:
         ps = list(self.parameters())
@@ -177,6 +205,7 @@ class UNet(nn.Module):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         new.dp = self.dp
+        new.dropout_seed = _fresh_dropout_seed()      # a copy (EMA teacher) draws its own masks
         new._flat = new._flat_grad = new._flat_buf = new._flat_long = None
         new._engines, new._anchor = {}, None
         new._flatten()
@@ -196,6 +225,11 @@ class UNet(nn.Module):
     def flat_grads(self) -> torch.Tensor:
         self._ensure_flat()
         return self._flat_grad
+
+    def grad_bucket(self, i: int) -> torch.Tensor:
+        """Data-parallel gradient buckets in the order backward finishes them: 0 = decoder (+ projection necks, whose gradients
+        torch autograd has written before the U-Net backward starts), 1 = encoder.  Contiguous slices of the flat buffer."""
+        return self._flat_grad[self._encoder_numel:] if i == 0 else self._flat_grad[:self._encoder_numel]
 
     def backbone_numel(self) -> int:
         """Number of leading flat elements that belong to encoder+decoder (main.py:68-76 updates only those)."""
@@ -259,7 +293,8 @@ class UNet(nn.Module):
             eng.gtmp = gtmp
             eng.direct = direct
             pool.append(eng)
-        eng.base_seed = self.dropout_seed
+        rank = self.dp.rank if self.dp is not None else 0
+        eng.base_seed = (self.dropout_seed + 0x632BE5AB * rank) & 0x7FFFFFFF      # every data-parallel rank draws its own masks too
         eng.math = L.MATH_BF16X3 if self.math == "bf16x3" else L.MATH_F32
         ext = self.external_dropout_masks
         if isinstance(ext, (list, tuple)):      # tests: one mask set per forward, consumed in order (several forwards per step)

@@ -5,8 +5,12 @@ The reference is single-process / single-device (main.py:44 says so); sharding i
   1. BatchNorm statistics: every BN layer's [sum z, sum z^2] (forward) and [sum g, sum g*xhat] (backward), 2*C fp64 values,
      all-reduced between the partial-sum kernel and the finalize kernel (engine.py) -- train-mode teacher included;
   2. loss sums: the CE/Dice/MSE partial sums (32 floats) all-reduced before the scalar finalize (utils/loss.py);
-  3. gradients: ONE all-reduce (SUM, the loss is already normalised by the global counts) of the flat fp32 gradient buffer
-     per trainable model (7.26 MB U-Net / 14.65 MB U-Net+), issued right after backward.
+  3. gradients: SUM all-reduce (the loss is already normalised by the global counts) of the flat fp32 gradient buffer of every
+     trainable model (7.26 MB U-Net / 14.65 MB U-Net+) in TWO buckets overlapped with backward: the decoder's slice (+ the
+     projection necks) is all-reduced on a side HIP stream as soon as the decoder half of engine.backward has finished it, while
+     the encoder half still computes; the encoder's slice follows at the end (`launch_bucket` / `join_buckets`).  xGMI is
+     point-to-point (7 links x ~153 GB/s): two ~3.6 MB messages keep every link busy without paying the ring latency more than
+     twice per model and step.
 EMA, SGD and the LR/ramp-up scalars stay per rank (parameters are bit-identical after the reduced step).
 
 `sync_bn=False` selects the usual DistributedDataParallel semantics instead: BatchNorm statistics and the loss are per rank
@@ -31,6 +35,39 @@ class DataParallelContext:
         self.device = device
         self.force_sync = False     # tests: issue the collectives (and the sync code path of the engines) even with one rank
         self.sync_bn = True         # False: per-rank BatchNorm statistics and loss, gradients averaged (DDP semantics)
+        self.overlap = True         # gradient buckets all-reduced on a side stream from inside backward (False: one blocking exchange after it)
+        self.bucket_hook = None     # GraphedStep sets it while capturing: a bucket boundary then ends one hipGraph and starts the next
+        self._side = None
+        self._pending = False
+
+    @property
+    def active(self) -> bool:
+        return self.world_size > 1 or self.force_sync
+
+    def launch_bucket(self, t: torch.Tensor):
+        """All-reduce (SUM) the gradient slice `t`, whose producers are queued on the current stream, without blocking that stream:
+        the collective runs on a side stream that waits for the producers; `join_buckets()` makes the consumers wait for it."""
+        if not self.active:
+            return
+        if self.bucket_hook is not None:
+            self.bucket_hook(t)
+            return
+        if not t.is_cuda:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        main = torch.cuda.current_stream(t.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=t.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        t.record_stream(self._side)
+        self._pending = True
+
+    def join_buckets(self):
+        if self._pending:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+            self._pending = False
 
     def allreduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         if self.world_size > 1 or self.force_sync:

@@ -35,14 +35,33 @@ S_LR1, S_LR2, S_ALPHA, S_THRESH, S_COEF_A, S_COEF_B = 0, 1, 2, 3, 8, 16
 
 
 class StepScalars:
-    """Host-computed per-iteration scalars -> device, one async copy per step (pinned source, graph-capturable)."""
+    """Host-computed per-iteration scalars -> device, one async copy per step.
+
+    ``host`` is a plain staging block the step laws fill in; ``push()`` snapshots it into the next slot of a ring of pinned
+    blocks and copies THAT slot to the device.  A slot is reused only after the event recorded behind its copy has completed, so
+    a host that runs several steps ahead of the GPU (hipGraph replays take ~50 us of host time against ms of GPU time) can never
+    overwrite scalars a queued copy has not read yet.  The copy is issued eagerly in front of a graph replay (never captured: a
+    captured memcpy node would re-read one fixed host address at execution time)."""
+
+    SLOTS = 8
 
     def __init__(self, dev):
-        self.host = torch.zeros(32, dtype=torch.float32).pin_memory()
+        self.host = torch.zeros(32, dtype=torch.float32)
+        self.ring = torch.zeros(self.SLOTS, 32, dtype=torch.float32).pin_memory()
+        self.events = [None] * self.SLOTS
+        self.slot = 0
         self.dev = torch.zeros(32, dtype=torch.float32, device=dev)
 
     def push(self):
-        self.dev.copy_(self.host, non_blocking=True)
+        k = self.slot
+        self.slot = (k + 1) % self.SLOTS
+        if self.events[k] is not None:
+            self.events[k].synchronize()          # the copy that last read this slot has executed
+        self.ring[k].copy_(self.host)
+        self.dev.copy_(self.ring[k], non_blocking=True)
+        ev = self.events[k] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev.device))
+        self.events[k] = ev
 
     def view(self, off, n=1):
         return self.dev[off:off + n]
@@ -126,7 +145,10 @@ class _StepBase:
     def _reduce_grads(self, *models):
         if self.dp is not None and (self.dp.world_size > 1 or self.dp.force_sync):
             for m in models:
-                if hasattr(m, "flat_grads") and not hasattr(m, "_hpfg_generic_flat"):
+                if getattr(m, "_buckets_launched", False):      # the engine's backward already handed both buckets to the side stream
+                    m._buckets_launched = False
+                    self.dp.join_buckets()
+                elif hasattr(m, "flat_grads") and not hasattr(m, "_hpfg_generic_flat"):
                     self.dp.allreduce_sum(m.flat_grads)
                 else:                      # a model whose gradients live in per-parameter tensors (SegFormer): one flattened exchange of the
                     gs = [p.grad for p in m.parameters() if p.grad is not None]      # SUM; the 1/world of the per-rank-BatchNorm mode is the
@@ -556,8 +578,8 @@ class HPFGStep(_StepBase):
 
 class GraphedStep:
     """Captures ``step_obj.device_step`` on static input buffers into one hipGraph (torch.cuda.CUDAGraph) and replays it.
-    Host scalars keep flowing through the pinned block (the captured copy node re-reads it at every replay); dropout masks
-    change per replay through the engines' device seed word."""
+    Host scalars are copied to the device eagerly in front of every replay (StepScalars ring); dropout masks change per replay
+    through the engines' device seed word."""
 
     def __init__(self, step_obj, example_inputs, warmup: int = 3, alias_inputs: bool = False):
         """alias_inputs: the graph reads ``example_inputs`` themselves (the caller refills those tensors in place, or they never
@@ -583,17 +605,53 @@ class GraphedStep:
         self.split = bool(dp is not None and not getattr(dp, "sync_bn", True) and (dp.world_size > 1 or dp.force_sync)
                           and hasattr(step_obj, "device_fwd_bwd"))
         if self.split:
-            # per-rank BatchNorm (DDP semantics): the only collective of the step is the gradient all-reduce.  Capture the work before
-            # and after it as two graphs and issue the RCCL call eagerly in between -- no collective node inside a hipGraph.
+            # per-rank BatchNorm (DDP semantics): the only collectives of the step are the gradient all-reduces.  The work between
+            # them is captured as a CHAIN of hipGraphs and the RCCL calls are issued eagerly in between, on a side stream -- no
+            # collective node inside a hipGraph: [forward + loss + decoder half of backward] -> bucket 0 || [encoder half] -> bucket 1
+            # -> [SGD + EMA].  A bucket boundary inside backward (DataParallelContext.launch_bucket -> bucket_hook) ends the graph
+            # being captured and begins the next one in the same memory pool.
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.s.sc.push()
-                self.out = self.s.device_fwd_bwd(*self.static)
-            with torch.cuda.graph(self.graph_b, capture_error_mode="thread_local"):
+            self.graphs, self.bucket_after = [self.graph], []
+            overlap = bool(getattr(dp, "overlap", False)) and os.environ.get("HPFG_DP_CHAIN", "1") == "1"
+            if overlap:
+                # the boundary runs on autograd's device thread: ending a capture from another thread than the one that began it
+                # needs the relaxed mode (which also tolerates the RCCL watchdog's event queries)
+                mode = "relaxed"
+                pad = torch.zeros(1, device=self.static[0].device)
+                cap = torch.cuda.Stream()
+                torch.cuda.synchronize()
+                cap.wait_stream(torch.cuda.current_stream())
+
+                def hook(t):
+                    self.graphs[-1].capture_end()
+                    self.bucket_after.append(t)
+                    g2 = torch.cuda.CUDAGraph()
+                    g2.capture_begin(pool=self.graph.pool(), capture_error_mode=mode)
+                    self.graphs.append(g2)
+                    pad.add_(1.0)          # no graph of the chain is empty (the last boundary is the end of backward)
+
+                with torch.cuda.stream(cap):
+                    self.graph.capture_begin(capture_error_mode=mode)
+                    dp.bucket_hook = hook
+                    try:
+                        self.out = self.s.device_fwd_bwd(*self.static)
+                    finally:
+                        dp.bucket_hook = None
+                        self.graphs[-1].capture_end()
+                torch.cuda.current_stream().wait_stream(cap)
+                for m in self._models():
+                    m._buckets_launched = False
+            else:
+                prev, dp.overlap = getattr(dp, "overlap", False), False      # one blocking exchange between the two graphs
+                try:
+                    with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                        self.out = self.s.device_fwd_bwd(*self.static)
+                finally:
+                    dp.overlap = prev
+            with torch.cuda.graph(self.graph_b, pool=self.graph.pool(), capture_error_mode="thread_local"):
                 self.s.device_update()
         else:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.s.sc.push()
                 self.out = self.s.device_step(*self.static)
         self._freeze_seed_updates(False)
 
@@ -609,12 +667,22 @@ class GraphedStep:
             if dst is not src:
                 dst.copy_(src, non_blocking=True)
         self.s.host_scalars(cur_itrs, **kw)
+        self.s.sc.push()          # eager H2D copy of this step's scalars from a fresh ring slot, ordered in front of the replay
         for m in self._models():
             m.bump_graph_seed()
-        self.graph.replay()
         if self.split:
-            self.s.exchange()
+            dp = self.s.dp
+            for i, g in enumerate(self.graphs):
+                g.replay()
+                if i < len(self.bucket_after):
+                    dp.launch_bucket(self.bucket_after[i])      # eager RCCL call on the side stream; the next graph runs beside it
+            if self.bucket_after:
+                dp.join_buckets()
+            else:
+                self.s.exchange()
             self.graph_b.replay()
+        else:
+            self.graph.replay()
         self.s.after()
         return self.out
 
@@ -635,7 +703,10 @@ class CTCTStep(CPSStep):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
-# Driver loops with the reference's names / signatures (logging and checkpointing kept minimal; evaluation via hpfg_amd.val)
+# Driver loops with the reference's names / signatures: same iteration law (two labelled iterators restarted on StopIteration,
+# return once cur_itrs > total_itrs), evaluation every ``step_size`` iterations through hpfg_amd.val.test_acdc, and best-Dice
+# checkpoints in the reference's dict format {"model", "optimizer", "lr_scheduler", "cur_itrs", "best_dice"}.
+# TensorBoard / tqdm output is not produced (out of scope); the per-iteration loss stays on the device and is returned.
 # ------------------------------------------------------------------------------------------------------------------------
 def _cycle(loader):
     it = iter(loader)
@@ -647,8 +718,43 @@ def _cycle(loader):
             yield next(it)
 
 
+class _Best:
+    """Periodic evaluation + best-Dice checkpoint of one network (main.py:224-279, 2017_03...py:116-152, sup_ACDC.py:97-116)."""
+
+    def __init__(self, args, key, path_attr=None, path_fmt=None):
+        self.args, self.key, self.best = args, key, 0.0
+        self.path_attr, self.path_fmt = path_attr, path_fmt
+
+    def path(self):
+        if self.path_fmt is not None and getattr(self.args, "save_path", None):
+            return os.path.join(self.args.save_path, "model", self.path_fmt.format(self.best))
+        return getattr(self.args, self.path_attr, None) if self.path_attr else None
+
+    def __call__(self, model, optimizer, lr_scheduler, test_loader, cur_itrs, name="test"):
+        from .val import test_acdc
+        dice, hd95 = test_acdc(model=model, test_loader=test_loader, args=self.args, cur_itrs=cur_itrs, name=name)
+        logger = getattr(self.args, "logger", None)
+        if logger is not None:
+            logger.info("{}_dice: {:.4f} {}_hd95: {:.4f}".format(self.key, dice, self.key, hd95))
+        if dice > self.best:
+            self.best = dice
+            path = self.path()
+            if path:
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                torch.save({"model": model.state_dict(), "optimizer": optimizer.state_dict(), "lr_scheduler": lr_scheduler.state_dict(),
+                            "cur_itrs": cur_itrs, "best_dice": self.best}, path)
+        model.train()
+        return dice
+
+
+def _due(cur_itrs, args, test_loader):
+    return test_loader is not None and cur_itrs % args.step_size == 0
+
+
 def Supervise(model, train_loader, test_loader, args):
+    """sup_ACDC.py:59-125."""
     st = SupervisedStep(model, args, getattr(args, "dp", None))
+    best = _Best(args, "model", path_fmt="model_{:.4f}.pth")
     model.train()
     cur_itrs, log = 0, []
     max_epoch = args.total_itrs // len(train_loader) + 1
@@ -657,18 +763,17 @@ def Supervise(model, train_loader, test_loader, args):
             cur_itrs += 1
             r = st.step(img.to(args.device).float(), label_true.to(args.device), cur_itrs)
             log.append(r["loss"])
-            if cur_itrs % args.step_size == 0 and test_loader is not None:
-                from .val import test_acdc
-                dice, _ = test_acdc(model=model, test_loader=test_loader, args=args, cur_itrs=cur_itrs)
-                args.logger.info("dice: {:.4f}".format(dice))
-                model.train()
-            if cur_itrs >= args.total_itrs:
+            if _due(cur_itrs, args, test_loader):
+                best(model, st.optimizer, st.lr_scheduler, test_loader, cur_itrs)
+            if cur_itrs > args.total_itrs:
                 return torch.stack(log)
     return torch.stack(log)
 
 
 def Mean_Teacher(model, ema_model, label_loader, unlabel_loader, test_loader, args):
+    """2017_03_NIPS_Mean-Teacher_ACDC.py:63-162."""
     st = MeanTeacherStep(model, ema_model, args, getattr(args, "dp", None))
+    best, best_ema = _Best(args, "model", "model_save_path"), _Best(args, "ema", "ema_model_save_path")
     model.train()
     ema_model.train()          # the teacher stays in train mode (2017_03...py:70)
     cur_itrs, log = 0, []
@@ -680,13 +785,18 @@ def Mean_Teacher(model, ema_model, label_loader, unlabel_loader, test_loader, ar
             label_img, target_label = next(labels)
             r = st.step(label_img.to(args.device).float(), target_label.to(args.device), unlabel_img.to(args.device).float(), cur_itrs)
             log.append(r["loss"])
-            if cur_itrs >= args.total_itrs:
+            if _due(cur_itrs, args, test_loader):
+                best(model, st.optimizer, st.lr_scheduler, test_loader, cur_itrs, "model")
+                best_ema(ema_model, st.optimizer, st.lr_scheduler, test_loader, cur_itrs, "ema")
+            if cur_itrs > args.total_itrs:
                 return torch.stack(log)
     return torch.stack(log)
 
 
 def CPS(model1, model2, label_loader, unlabel_loader, test_loader, args, step_cls=None):
+    """2021_06_CVPR_CPS_ACDC.py:61-169 (and, with CTCTStep, 2021_12_MIDL_CTCT_ACDC.py:68-214)."""
     st = (step_cls or CPSStep)(model1, model2, args, getattr(args, "dp", None))
+    best1, best2 = _Best(args, "model1", "model1_save_path"), _Best(args, "model2", "model2_save_path")
     model1.train()
     model2.train()
     cur_itrs, log = 0, []
@@ -698,7 +808,10 @@ def CPS(model1, model2, label_loader, unlabel_loader, test_loader, args, step_cl
             label_img, target_label = next(labels)
             r = st.step(label_img.to(args.device).float(), target_label.to(args.device), unlabel_img.to(args.device).float(), cur_itrs)
             log.append(r["loss"])
-            if cur_itrs >= args.total_itrs:
+            if _due(cur_itrs, args, test_loader):
+                best1(model1, st.optimizer1, st.lr_scheduler1, test_loader, cur_itrs, "model1")
+                best2(model2, st.optimizer2, st.lr_scheduler2, test_loader, cur_itrs, "model2")
+            if cur_itrs > args.total_itrs:
                 return torch.stack(log)
     return torch.stack(log)
 
@@ -709,7 +822,10 @@ def CTCT(model1, model2, label_loader, unlabel_loader, test_loader, args):
 
 
 def HPFG(model1, model2, ema_model, label_loader, unlabel_loader, test_loader, args):
+    """main.py:79-289."""
     st = HPFGStep(model1, model2, ema_model, args, getattr(args, "dp", None))
+    best1, best2 = _Best(args, "model1", "model1_save_path"), _Best(args, "model2", "model2_save_path")
+    best_ema = _Best(args, "ema", "ema_model_save_path")
     model1.train()
     model2.train()
     cur_itrs, log = 0, []
@@ -727,6 +843,10 @@ def HPFG(model1, model2, ema_model, label_loader, unlabel_loader, test_loader, a
                         label_img1.repeat(rep, 1, 1, 1).to(args.device).float(), target_label1.repeat(rep, 1, 1).to(args.device),
                         img_unlabel.to(args.device).float(), cm.to(args.device), cur_itrs)
             log.append(r["loss"])
-            if cur_itrs >= args.total_itrs:
+            if _due(cur_itrs, args, test_loader):
+                best1(model1, st.optimizer1, st.lr_scheduler1, test_loader, cur_itrs, "model1")
+                best2(model2, st.optimizer2, st.lr_scheduler2, test_loader, cur_itrs, "model2")
+                best_ema(ema_model, st.optimizer2, st.lr_scheduler2, test_loader, cur_itrs, "model1")      # main.py:259-272 saves optimizer2 with it
+            if cur_itrs > args.total_itrs:
                 return torch.stack(log)
     return torch.stack(log)

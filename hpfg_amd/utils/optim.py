@@ -123,6 +123,24 @@ class FusedAdamW(torch.optim.Optimizer):
                                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), float(self.grad_scale), st),
                 "adamw_step")
 
+    def state_dict(self):
+        """torch's dict plus the flat Adam moments and the device step count (resuming must not reset them; the reference saves
+        ``optimizer.state_dict()`` in its checkpoints, main.py:262-272)."""
+        d = super().state_dict()
+        d["flat_m"], d["flat_v"], d["step"] = self._m, self._v, self._step_dev
+        return d
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        m, v, st = sd.pop("flat_m", None), sd.pop("flat_v", None), sd.pop("step", None)
+        super().load_state_dict(sd)
+        if m is not None:
+            self._m.copy_(m)
+        if v is not None:
+            self._v.copy_(v)
+        if st is not None:
+            self._step_dev.copy_(torch.as_tensor(st, dtype=torch.float32).reshape(1))
+
 
 def build_optimizer(args, model):
     if args.opt == "sgd":

@@ -9,7 +9,7 @@ import torch.distributed as dist
 
 from hpfg_amd import parallel
 from hpfg_amd.datasets.synthetic import synth_batch
-from hpfg_amd.model import UNet
+from hpfg_amd.model import UNet, reset_dropout_streams
 from hpfg_amd.train import GraphedStep, MeanTeacherStep
 from hpfg_amd.utils import AttrDict
 from tests.helpers import maxerr
@@ -25,6 +25,7 @@ def _args():
 
 def _run(dp, graphed=False, steps=3):
     torch.manual_seed(7)
+    reset_dropout_streams()
     m = UNet(1, 4).to(DEV)
     ema = deepcopy(m)
     for p in ema.parameters():
@@ -98,6 +99,36 @@ def test_local_bn_mode_split_graph(dp):
         dp.sync_bn = True
 
 
+def test_bucketed_overlap_eager_and_graph_chain(dp):
+    """Gradient buckets all-reduced from inside backward on a side stream (decoder bucket while the encoder half computes): the eager
+    form and the chain of hipGraphs bench.py replays for N > 1 give the trajectory of the path without a process group, bit for bit
+    (one rank: the SUM is the identity, so any difference is a missing dependency between the streams / graphs)."""
+    l0, p0 = _run(None, steps=4)
+    dp.sync_bn = False
+    try:
+        assert dp.overlap
+        l1, p1 = _run(dp, steps=4)
+        assert l0 == l1 and torch.equal(p0, p1)
+        torch.manual_seed(7)
+        m = UNet(1, 4).to(DEV)
+        ema = deepcopy(m)
+        for p in ema.parameters():
+            p.requires_grad = False
+        m.train()
+        ema.train()
+        st = MeanTeacherStep(m, ema, _args(), dp)
+        xl, yl = synth_batch(1, 2, 64, 64, 1, 4, 8)
+        xu, _ = synth_batch(2, 2, 64, 64, 1, 4, 8)
+        xl, yl, xu = xl.to(DEV), yl.to(DEV), xu.to(DEV)
+        g = GraphedStep(st, [xl, yl, xu], warmup=1, alias_inputs=True)
+        assert g.split and len(g.graphs) == 3 and len(g.bucket_after) == 2
+        assert g.bucket_after[0].numel() + g.bucket_after[1].numel() == m.flat_grads.numel()
+        losses = [float(g.step([xl, yl, xu], k, cons_w=0.05)["loss"]) for k in range(2, 5)]
+        assert all(x == x and abs(x) < 10 for x in losses)
+    finally:
+        dp.sync_bn = True
+
+
 def test_sync_path_captures_into_a_graph(dp):
     """RCCL collectives inside the captured step (what bench.py does for N > 1 when HPFG_DP_GRAPH=1)."""
     lg, _ = _run(dp, graphed=True, steps=2)
@@ -113,6 +144,7 @@ def test_ctct_step_on_the_data_parallel_path(dp):
 
     def run(ctx):
         torch.manual_seed(9)
+        reset_dropout_streams()
         m1, m2 = UNet(1, 4).to(DEV), SegFormer(image_size=[64, 64], in_channels=1, num_classes=4).to(DEV)
         m1.train()
         m2.train()

@@ -11,7 +11,7 @@ import torch
 
 from hpfg_amd import _lib as L
 from hpfg_amd.datasets.synthetic import synth_batch
-from hpfg_amd.model import build_model
+from hpfg_amd.model import build_model, reset_dropout_streams
 from hpfg_amd.train import CPSStep, HPFGStep, MeanTeacherStep, SupervisedStep
 from hpfg_amd.utils import loadyaml, seg_loss
 
@@ -34,6 +34,7 @@ def _teacher(m):
 def _mt_run(steps=2):
     a = _cfg("mean_teacher_unet_30k_224x224_ACDC.yaml")
     torch.manual_seed(a.seed)
+    reset_dropout_streams()          # same construction order after the same seed -> the same dropout streams in both runs
     m = build_model(a).to(DEV)
     e = _teacher(m)
     m.train()

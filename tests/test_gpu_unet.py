@@ -103,7 +103,9 @@ def test_backward_all_parameter_gradients(n, hw, in_ch, ncls, seed, math):
         errs[k] = float((p.grad.cpu().double() - rg[k].double()).norm() / max(1e-4, float(rg[k].double().norm())))
     # (the per-kernel tests in test_gpu_kernels.py pin dgrad / wgrad / BN-backward / pool / upsample element-wise at 2e-4..5e-4;
     #  this test guards the COMPOSITION: a routing or scaling mistake shows up as an O(1) error, a flip as O(1e-2))
-    tol, med_tol = 5e-2, 1.5e-2
+    # exact-fp32 products leave only summation-order noise (a flip needs a pre-activation within ~1e-6 of zero); the split-bf16 bounds
+    # allow for a handful of flips per tensor
+    tol, med_tol = (5e-3, 1e-3) if math == "f32" else (5e-2, 1.5e-2)
     med = float(np.median([v for k, v in errs.items() if float(rg[k].abs().max()) > 1e-6]))
     assert med < med_tol, f"median relative L2 gradient error {med}"
     bad = {k: v for k, v in errs.items() if not v < tol}

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import laws_ref, losses_ref, steps_ref, unet_ref
+from tests import trace_replay as R
 
 torch.set_num_threads(4)
 
@@ -100,60 +101,68 @@ def test_losses_fixture(golden_dir):
 
 def test_supervised_and_mean_teacher_traces(golden_dir):
     d = np.load(f"{golden_dir}/trace_sup.npz")
-    st, bufs = unet_ref.init_state(1, 1, 4), {}
-    table = laws_ref.cosine_table(0.01, 0, 1e-4, 1e-6, 200, 150)
-    x, lab = torch.from_numpy(d["x"]), torch.from_numpy(d["labels"]).long()
-    losses = [steps_ref.supervised_step(st, bufs, x, lab, laws_ref.cosine_lr(k + 1, table), 0.9, 5e-4, _unpack_masks(d, f"it{k}_mask", 4, 32))["loss"]
-              for k in range(4)]
-    assert np.abs(np.array(losses) - d["losses"]).max() < 2e-5
-    with torch.no_grad():
-        fin = unet_ref.unet_forward(st, x, train=False)
+    r = R.replay_sup(d)
+    assert np.abs(r["losses"] - d["losses"]).max() < 2e-5
+    fin = r["final_eval_logits"]
     assert float((fin - torch.from_numpy(d["final_eval_logits"])).abs().max()) < 2e-4
     assert abs(losses_ref.mean_foreground_dice(fin.argmax(1).numpy(), d["labels"], 4) - float(d["final_dice"])) < 1e-6
 
     d = np.load(f"{golden_dir}/trace_mt.npz")
-    st = unet_ref.init_state(1337, 1, 4)
-    ema, bufs = unet_ref.clone_state(st), {}
-    xl, yl, xu = torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xu"])
-    rows = []
-    for k in range(3):
-        r = steps_ref.mean_teacher_step(st, ema, bufs, xl, yl, xu, laws_ref.medical_lr(k + 1, 0.01, 30000), float(d["cons_w"]),
-                                        laws_ref.ema_alpha(k + 1, 0.99), 0.9, 1e-4, _unpack_masks(d, f"it{k}_s", 4, 32), _unpack_masks(d, f"it{k}_t", 4, 32))
-        rows.append([r["loss"], r["sup"], r["cons"]])
-    assert np.abs(np.array(rows) - d["losses"]).max() < 2e-5
-    assert float((r["logits"] - torch.from_numpy(d["student_logits_last"])).abs().max()) < 1e-4
+    r = R.replay_mt(d)
+    assert np.abs(r["losses"] - d["losses"]).max() < 2e-5
+    assert float((r["student_logits_last"] - torch.from_numpy(d["student_logits_last"])).abs().max()) < 1e-4
 
 
 def test_ict_trace(golden_dir):
     d = np.load(f"{golden_dir}/trace_ict.npz")
-    st = unet_ref.init_state(1337, 1, 4)
-    ema, bufs = unet_ref.clone_state(st), {}
-    xl, yl, xu = torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xu"])
-    rows = []
-    for k in range(3):
-        r = steps_ref.ict_step(st, ema, bufs, xl, yl, xu, torch.from_numpy(d["mixes"][k]), laws_ref.medical_lr(k + 1, 0.01, 30000), float(d["cons_w"]),
-                               laws_ref.ema_alpha(k + 1, 0.99), 0.9, 1e-4, _unpack_masks(d, f"it{k}_s", 4, 32), _unpack_masks(d, f"it{k}_a", 2, 32),
-                               _unpack_masks(d, f"it{k}_b", 2, 32))
-        rows.append([r["loss"], r["sup"], r["cons"]])
-    assert np.abs(np.array(rows) - d["losses"]).max() < 2e-5
-    assert float((r["logits"] - torch.from_numpy(d["student_logits_last"])).abs().max()) < 1e-4
+    r = R.replay_ict(d)
+    assert np.abs(r["losses"] - d["losses"]).max() < 2e-5
+    assert float((r["student_logits_last"] - torch.from_numpy(d["student_logits_last"])).abs().max()) < 1e-4
 
 
 def test_uamt_trace(golden_dir):
     d = np.load(f"{golden_dir}/trace_uamt.npz")
-    st = unet_ref.init_state(1337, 1, 4)
-    ema, bufs = unet_ref.init_state(None, 1, 4), {}
-    xl, yl, xu = torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xu"])
-    rows = []
-    for k in range(2):
-        nz = torch.from_numpy(d["noise"][k])
-        mt = [_unpack_masks(d, f"it{k}_f1_", 2, 32)] + [_unpack_masks(d, f"it{k}_f{j}_", 4, 32) for j in range(2, 6)]
-        r = steps_ref.uamt_step(st, ema, bufs, xl, yl, xu, nz[:2], [nz[2 + 4 * i:6 + 4 * i] for i in range(4)], float(d["thresholds"][k]),
-                                laws_ref.medical_lr(k + 1, 0.01, 30000), float(d["cons_w"]), laws_ref.ema_alpha(k + 1, 0.99), 0.9, 1e-4,
-                                _unpack_masks(d, f"it{k}_f0_", 4, 32), mt)
-        rows.append([r["loss"], r["sup"], r["cons"]])
-    assert np.abs(np.array(rows) - d["losses"]).max() < 2e-5
-    assert float((r["uncertainty"] - torch.from_numpy(d["uncertainty_last"])).abs().max()) < 1e-5
+    r = R.replay_uamt(d)
+    assert np.abs(r["losses"] - d["losses"]).max() < 2e-5
+    assert float((r["uncertainty_last"] - torch.from_numpy(d["uncertainty_last"])).abs().max()) < 1e-5
+
+
+def test_hpfg2_trace_gate_repeat_and_stepped_schedulers(golden_dir):
+    """main.py:142-143 (labelled batch repeated Nu//Nl = 3 times), :186-188 (no MSE before iteration 1000) and :211-212 (both
+    Medical_LR schedulers stepped): three iterations of the reference's own modules at cur_itrs = 999, 1000, 1001, batch 2+6."""
+    d = np.load(f"{golden_dir}/trace_hpfg2.npz")
+    assert d["losses"][0, 5] == 0.0 and d["losses"][1, 5] > 0.0            # the consistency term switches on at 1000
+    for cur, (lr1, lr2) in zip(d["cur_itrs"], d["lrs"]):
+        assert abs(laws_ref.medical_lr(int(cur), 0.01, 30000) - lr1) < 1e-12 and lr1 == lr2
+    r = R.replay_hpfg(d, stepped_lr=True)
+    assert np.abs(r["losses"] - d["losses"][:, :5]).max() < 1e-4
+    for k in ("logits1_last", "logits2_last", "t_logits_last"):
+        assert float((r[k] - torch.from_numpy(d[k])).abs().max()) < 2e-4, k
+
+
+def test_sup224_trace_cfg1_as_written(golden_dir):
+    """BASELINE configs[0] at its real size: 10 supervised iterations on 8 slices of 224x224 (sup_ACDC.py:83-93), inputs and dropout
+    masks regenerated from the seeds the reference run used (checksums stored in the fixture)."""
+    d = np.load(f"{golden_dir}/trace_sup224.npz")
+    r = R.replay_sup224(d)
+    assert np.abs(r["losses"] - d["losses"]).max() < 5e-5
+    fin = r["final_eval_logits"]
+    assert float((fin[:, :, ::8, ::8] - torch.from_numpy(d["final_eval_logits_sub"])).abs().max()) < 5e-4
+    assert abs(float(fin.double().sum()) - float(d["final_eval_logits_sum"])) < 1e-5 * fin.numel()      # mean deviation < 1e-5
+    assert abs(r["final_dice"] - float(d["final_dice"])) < 1e-3
+
+
+def test_augment_fixture_pins_the_augmentation_oracle(golden_dir):
+    """oracle/augment_ref.py against outputs of the reference's own RandomGenerator (datasets/utils.py:99-117) on seeded slices."""
+    import random
+    from oracle import augment_ref
+    d = np.load(f"{golden_dir}/augment.npz")
+    n = int(d["n"])
+    for k, seed in enumerate(d["seeds"]):
+        img, lab = d[f"src_img{k % n}"], d[f"src_lab{k % n}"]
+        oi, ol = augment_ref.random_generator(img, lab, (224, 224), random.Random(int(seed)), np.random.RandomState(int(seed)))
+        assert np.array_equal(oi[0].astype(np.float16), d[f"img{k}"][0]) and abs(float(oi.astype(np.float64).sum()) - float(d[f"img{k}_sum"])) < 1e-6
+        assert np.array_equal(ol.reshape(-1), R.unpack_labels2(d[f"lab{k}"], ol.size))
 
 
 def test_segformer_oracle_matches_reference_fixture(golden_dir):
@@ -207,27 +216,9 @@ def test_ctct_trace(golden_dir):
 
 def test_cps_and_hpfg_traces(golden_dir):
     d = np.load(f"{golden_dir}/trace_cps.npz")
-    torch.manual_seed(1337)
-    sa, sb = unet_ref.init_state(None, 3, 2), unet_ref.init_state(None, 3, 2)
-    ba, bb = {}, {}
-    xl, yl, xu = torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xu"])
-    rows = []
-    for k in range(2):
-        lr = laws_ref.medical_lr(k + 1, 0.01, 30000)
-        r = steps_ref.cps_step(sa, sb, ba, bb, xl, yl, xu, lr, lr, float(d["cons_w"]), 0.9, 1e-4, _unpack_masks(d, f"it{k}_a", 4, 48),
-                               _unpack_masks(d, f"it{k}_b", 4, 48))
-        rows.append([r["loss"], r["sup"], r["semi"]])
-    assert np.abs(np.array(rows) - d["losses"]).max() < 5e-5
+    r = R.replay_cps(d)
+    assert np.abs(r["losses"] - d["losses"]).max() < 5e-5
 
     d = np.load(f"{golden_dir}/trace_hpfg.npz")
-    torch.manual_seed(1)
-    sa, sb = unet_ref.init_state(None, 1, 4, True), unet_ref.init_state(None, 1, 4, True)
-    se, ba, bb = unet_ref.clone_state(sb), {}, {}
-    rows = []
-    for j, cur in enumerate(d["cur_itrs"]):
-        r = steps_ref.hpfg_step(sa, sb, se, ba, bb, torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xl1"]),
-                                torch.from_numpy(d["yl1"]).long(), torch.from_numpy(d["xu"]), torch.from_numpy(d["cutmix"][j]), int(cur), 0.01, 0.01, 0.1,
-                                200.0, 0.99, 0.9, 5e-4, _unpack_masks(d, f"it{j}_a", 4, 64), _unpack_masks(d, f"it{j}_b", 4, 64),
-                                _unpack_masks(d, f"it{j}_t", 4, 64))
-        rows.append([r["loss"], r["sup"], r["semi"], r["pseudo_sup"], r["contrast"]])
-    assert np.abs(np.array(rows) - d["losses"]).max() < 1e-4
+    r = R.replay_hpfg(d)
+    assert np.abs(r["losses"] - d["losses"]).max() < 1e-4

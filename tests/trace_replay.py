@@ -1,0 +1,170 @@
+"""Oracle replays of the golden step traces (tests/golden/trace_*.npz), shared by the CPU pinning tests and by the GPU tests' CONTROL runs.
+
+A control run repeats a trace on the CPU oracle from conv weights perturbed by a relative 1e-6 (uniform in [-1e-6, 1e-6] per element,
+about ten fp32 roundings) and measures how far the trace's final logits move.  The fixtures are tiny (N = 4..8 at 32..64 px: BatchNorm
+over as few as 16 values at the bottleneck, followed by 2-3 SGD steps), so they amplify any such perturbation several hundred times:
+that measured drift, not a hand-picked constant, is what bounds the split-bf16 ("bf16x3") math mode on them
+(tests/test_gpu_steps.py::logit_tol).  The bf16x3 product error is 2^-17 = 7.6e-6 relative, i.e. 7.6x the control's perturbation;
+the tests allow 5x the control's drift.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import laws_ref, steps_ref, unet_ref
+
+CONTROL_EPS = 1e-6
+CONTROL_SEEDS = (0, 1)
+
+
+def unpack_masks(d, prefix, n, hw):
+    out = []
+    for lvl in range(5):
+        c, h = unet_ref.WIDTHS[lvl], hw >> lvl
+        bits = np.unpackbits(d[f"{prefix}{lvl}"])[: n * c * h * h].reshape(n, c, h, h)
+        out.append(torch.from_numpy(bits.astype(np.float32)))
+    return out
+
+
+def perturb(st, seed):
+    """Relative perturbation of every conv weight of an oracle state, in place; seed None = nominal run."""
+    if seed is None:
+        return st
+    g = torch.Generator().manual_seed(1000 + seed)
+    for n_ in st:
+        if n_.endswith(".weight") and st[n_].dim() == 4:
+            r = 2 * torch.rand(st[n_].shape, generator=g, dtype=torch.float64) - 1
+            st[n_] = (st[n_].double() * (1 + CONTROL_EPS * r)).float()
+    return st
+
+
+def replay_sup(d, seed=None):
+    st, bufs = perturb(unet_ref.init_state(1, 1, 4), seed), {}
+    table = laws_ref.cosine_table(0.01, 0, 1e-4, 1e-6, 200, 150)
+    x, lab = torch.from_numpy(d["x"]), torch.from_numpy(d["labels"]).long()
+    losses = [steps_ref.supervised_step(st, bufs, x, lab, laws_ref.cosine_lr(k + 1, table), 0.9, 5e-4, unpack_masks(d, f"it{k}_mask", 4, 32))["loss"]
+              for k in range(4)]
+    with torch.no_grad():
+        fin = unet_ref.unet_forward(st, x, train=False)
+    return {"losses": np.array(losses), "final_eval_logits": fin}
+
+
+def replay_mt(d, seed=None):
+    st = perturb(unet_ref.init_state(1337, 1, 4), seed)
+    ema, bufs = unet_ref.clone_state(st), {}
+    xl, yl, xu = torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xu"])
+    rows = []
+    for k in range(3):
+        r = steps_ref.mean_teacher_step(st, ema, bufs, xl, yl, xu, laws_ref.medical_lr(k + 1, 0.01, 30000), float(d["cons_w"]),
+                                        laws_ref.ema_alpha(k + 1, 0.99), 0.9, 1e-4, unpack_masks(d, f"it{k}_s", 4, 32), unpack_masks(d, f"it{k}_t", 4, 32))
+        rows.append([r["loss"], r["sup"], r["cons"]])
+    return {"losses": np.array(rows), "student_logits_last": r["logits"], "teacher_logits_last": r["t_logits"]}
+
+
+def replay_ict(d, seed=None):
+    st = perturb(unet_ref.init_state(1337, 1, 4), seed)
+    ema, bufs = unet_ref.clone_state(st), {}
+    xl, yl, xu = torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xu"])
+    rows = []
+    for k in range(3):
+        r = steps_ref.ict_step(st, ema, bufs, xl, yl, xu, torch.from_numpy(d["mixes"][k]), laws_ref.medical_lr(k + 1, 0.01, 30000), float(d["cons_w"]),
+                               laws_ref.ema_alpha(k + 1, 0.99), 0.9, 1e-4, unpack_masks(d, f"it{k}_s", 4, 32), unpack_masks(d, f"it{k}_a", 2, 32),
+                               unpack_masks(d, f"it{k}_b", 2, 32))
+        rows.append([r["loss"], r["sup"], r["cons"]])
+    return {"losses": np.array(rows), "student_logits_last": r["logits"]}
+
+
+def replay_uamt(d, seed=None):
+    st = perturb(unet_ref.init_state(1337, 1, 4), seed)
+    ema, bufs = perturb(unet_ref.init_state(None, 1, 4), None if seed is None else seed + 10), {}
+    xl, yl, xu = torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xu"])
+    rows = []
+    for k in range(2):
+        nz = torch.from_numpy(d["noise"][k])
+        mt = [unpack_masks(d, f"it{k}_f1_", 2, 32)] + [unpack_masks(d, f"it{k}_f{j}_", 4, 32) for j in range(2, 6)]
+        r = steps_ref.uamt_step(st, ema, bufs, xl, yl, xu, nz[:2], [nz[2 + 4 * i:6 + 4 * i] for i in range(4)], float(d["thresholds"][k]),
+                                laws_ref.medical_lr(k + 1, 0.01, 30000), float(d["cons_w"]), laws_ref.ema_alpha(k + 1, 0.99), 0.9, 1e-4,
+                                unpack_masks(d, f"it{k}_f0_", 4, 32), mt)
+        rows.append([r["loss"], r["sup"], r["cons"]])
+    return {"losses": np.array(rows), "uncertainty_last": r["uncertainty"], "student_logits_last": r["logits"]}
+
+
+def replay_cps(d, seed=None):
+    torch.manual_seed(1337)
+    sa, sb = unet_ref.init_state(None, 3, 2), unet_ref.init_state(None, 3, 2)
+    perturb(sa, seed)
+    perturb(sb, None if seed is None else seed + 10)
+    ba, bb = {}, {}
+    xl, yl, xu = torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xu"])
+    rows = []
+    for k in range(2):
+        lr = laws_ref.medical_lr(k + 1, 0.01, 30000)
+        r = steps_ref.cps_step(sa, sb, ba, bb, xl, yl, xu, lr, lr, float(d["cons_w"]), 0.9, 1e-4, unpack_masks(d, f"it{k}_a", 4, 48),
+                               unpack_masks(d, f"it{k}_b", 4, 48))
+        rows.append([r["loss"], r["sup"], r["semi"]])
+    return {"losses": np.array(rows), "logits1_last": r["logits1"], "logits2_last": r["logits2"]}
+
+
+def replay_hpfg(d, seed=None, stepped_lr=False):
+    """trace_hpfg.npz (constant lr 0.01, batch 2+2) and trace_hpfg2.npz (stepped Medical_LR, batch 2+6 with the labelled repeat)."""
+    torch.manual_seed(1)
+    sa, sb = unet_ref.init_state(None, 1, 4, True), unet_ref.init_state(None, 1, 4, True)
+    perturb(sa, seed)
+    perturb(sb, None if seed is None else seed + 10)
+    se, ba, bb = unet_ref.clone_state(sb), {}, {}
+    xl, xu = torch.from_numpy(d["xl"]), torch.from_numpy(d["xu"])
+    rep = xu.shape[0] // xl.shape[0]
+    xl1, yl1 = torch.from_numpy(d["xl1"]).repeat(rep, 1, 1, 1), torch.from_numpy(d["yl1"]).long().repeat(rep, 1, 1)
+    n, hw = xl.shape[0] + xu.shape[0], xl.shape[-1]
+    rows = []
+    for j, cur in enumerate(d["cur_itrs"]):
+        lr = laws_ref.medical_lr(int(cur), 0.01, 30000) if stepped_lr else 0.01
+        r = steps_ref.hpfg_step(sa, sb, se, ba, bb, xl, torch.from_numpy(d["yl"]).long(), xl1, yl1, xu, torch.from_numpy(d["cutmix"][j]), int(cur), lr, lr, 0.1,
+                                200.0, 0.99, 0.9, 5e-4, unpack_masks(d, f"it{j}_a", n, hw), unpack_masks(d, f"it{j}_b", n, hw),
+                                unpack_masks(d, f"it{j}_t", n, hw))
+        rows.append([r["loss"], r["sup"], r["semi"], r["pseudo_sup"], r["contrast"]])
+    return {"losses": np.array(rows), "logits1_last": r["logits1"], "logits2_last": r["logits2"], "t_logits_last": r["t_logits"]}
+
+
+def unpack_labels2(packed, n):
+    """Labels stored at 2 bits each (oracle/make_golden_r2.py) -> uint8 [n]."""
+    bits = np.unpackbits(packed)[: 2 * n].reshape(n, 2)
+    return (bits[:, 0] * 2 + bits[:, 1]).astype(np.uint8)
+
+
+def sup224_inputs(d):
+    """Inputs and per-iteration dropout masks of trace_sup224.npz, regenerated from its seeds and verified against its checksums."""
+    from hpfg_amd.datasets.synthetic import synth_batch
+    n, hw, iters, seed_x, seed_m = [int(v) for v in d["meta"]]
+    x, lab = synth_batch(seed_x, n, hw, hw, 1, 4, 32)
+    assert abs(float(x.double().sum()) - float(d["x_sum"])) < 1e-6 and int(lab.long().sum()) == int(d["lab_sum"]), "synthetic input stream differs"
+    masks = []
+    for k in range(1, iters + 1):
+        torch.manual_seed(seed_m + k)
+        ms = unet_ref.draw_dropout_masks(n, hw, hw)
+        assert [float(m.sum()) for m in ms] == list(d["mask_sums"][k - 1]), "torch CPU generator stream differs from the fixture's"
+        masks.append(ms)
+    return x, lab, masks
+
+
+def replay_sup224(d, seed=None):
+    from oracle import losses_ref
+    x, lab, masks = sup224_inputs(d)
+    st, bufs = perturb(unet_ref.init_state(1, 1, 4), seed), {}
+    table = laws_ref.cosine_table(0.01, 0, 1e-4, 1e-6, 200, 150)
+    losses = [steps_ref.supervised_step(st, bufs, x, lab.long(), laws_ref.cosine_lr(k + 1, table), 0.9, 5e-4, masks[k])["loss"] for k in range(len(masks))]
+    with torch.no_grad():
+        fin = unet_ref.unet_forward(st, x, train=False)
+    return {"losses": np.array(losses), "final_eval_logits": fin, "final_dice": losses_ref.mean_foreground_dice(fin.argmax(1).numpy(), lab.numpy(), 4)}
+
+
+def control_drift(replay, d, keys, **kw):
+    """max over the control seeds and `keys` of |perturbed - nominal| on the trace's final tensors."""
+    nom = replay(d, None, **kw)
+    drift = 0.0
+    for s in CONTROL_SEEDS:
+        got = replay(d, s, **kw)
+        for k in keys:
+            drift = max(drift, float((got[k] - nom[k]).abs().max()))
+    return drift
