@@ -4,8 +4,8 @@
   MeanTeacherStep   2017_03_NIPS_Mean-Teacher_ACDC.py:82-113   (Mean_Teacher)
   CPSStep           2021_06_CVPR_CPS_ACDC.py:83-120            (CPS)
   HPFGStep          main.py:125-212              (HPFG, incl. update_ema_variables_backbone main.py:68-76)
-  ICTStep / UAMTStep / CTCTStep   the loop bodies of 2022_02_ISBI_ICT-MedSeg_ACDC.py, 2019_07_MICCAI_Uncertainty_Aware_ACDC.py and
-                    2021_12_MIDL_CTCT_ACDC.py (CTCT) on the same kernels
+  ICTStep / UAMTStep / CTCTStep / S4CVNetStep   the loop bodies of 2022_02_ISBI_ICT-MedSeg_ACDC.py, 2019_07_MICCAI_Uncertainty_Aware_ACDC.py,
+                    2021_12_MIDL_CTCT_ACDC.py (CTCT) and 2022_08_CVPR_S4CVNet_ACDC.py on the same kernels
 
 Each step object owns the optimizer(s) / scheduler(s) built by the reference-compatible factories and exposes
 ``step(batch..., cur_itrs) -> dict of device scalars``.  Nothing in a step synchronises with the host: losses stay on the
@@ -576,6 +576,73 @@ class HPFGStep(_StepBase):
         return r
 
 
+class S4CVNetStep(_StepBase):
+    """S4CVnet (2022_08_CVPR_S4CVNet_ACDC.py:107-167): two students on [labelled ; unlabelled], the EMA teacher
+    of model2 on the unlabelled images + clamp(N(0,1) * 0.1, +-0.2) (on its own stream), cross Dice pseudo supervision weighted 7w, and from
+    iteration 1000 on the softmax MSE of each student against the teacher weighted w (linear ramp-up), SGD on both, EMA(model2 -> teacher).
+    Pure recomposition of the hot-path kernels (noise_add, argmax_labels, the fused loss with an unlabelled-only consistency target)."""
+
+    def __init__(self, model1, model2, ema_model, args, dp=None):
+        super().__init__(next(model1.parameters()).device, dp)
+        self.model1, self.model2, self.ema_model, self.args = model1, model2, ema_model, args
+        for m in (model1, model2, ema_model):
+            self._attach(m)
+        self.optimizer1 = build_optimizer(args=args.model1, model=model1)
+        self.optimizer2 = build_optimizer(args=args.model2, model=model2)
+        self.lr_scheduler1 = build_lr_scheduler(args=args.model1, optimizer=self.optimizer1)
+        self.lr_scheduler2 = build_lr_scheduler(args=args.model2, optimizer=self.optimizer2)
+        self.optimizer1._lr_dev = self.sc.view(S_LR1)
+        self.optimizer2._lr_dev = self.sc.view(S_LR2)
+        self._set_grad_scale(self.optimizer1, self.optimizer2)
+
+    def host_scalars(self, cur_itrs):
+        a = self.args
+        w = a.consistency * linear_rampup(cur_itrs // 150, a.consistency_rampup)
+        h = self.sc.host
+        h[S_LR1], h[S_LR2] = self._lr(self.optimizer1), self._lr(self.optimizer2)
+        h[S_ALPHA] = ema_alpha(cur_itrs, a.ema_decay)
+        h[S_COEF_A:S_COEF_A + 5] = torch.tensor([0.5, 0.5, 0.0, 7.0 * w, 0.0 if cur_itrs < 1000 else w])      # both students (:141-150)
+        return w
+
+    def draw_noise(self, unlabel_img):
+        return torch.randn_like(unlabel_img)          # :109, clamped inside noise_add
+
+    def device_step(self, label_img, target_label, unlabel_img, noise):
+        nl = label_img.shape[0]
+        x = torch.cat([label_img, unlabel_img], 0)
+        ot = self._teacher_forward(self.ema_model, noise_add(unlabel_img, noise))
+        o1 = self.model1(x)
+        o2 = self.model2(x)
+        self._join_teacher(ot)
+        p1 = argmax_labels(o1[nl:])
+        p2 = argmax_labels(o2[nl:])
+        coef = self.sc.view(S_COEF_A, 8)
+        r1 = seg_loss(o1, target_label, nl, coef=coef, pseudo=p2, teacher_logits=ot, dp=self.dp)
+        r2 = seg_loss(o2, target_label, nl, coef=coef, pseudo=p1, teacher_logits=ot, dp=self.dp)
+        loss = r1[0] + r2[0]
+        self.optimizer1.zero_grad()
+        self.optimizer2.zero_grad()
+        loss.backward()
+        self._reduce_grads(self.model1, self.model2)
+        self.optimizer1.step(push_lr=False)
+        self.optimizer2.step(push_lr=False)
+        update_ema_variables(self.model2, self.ema_model, self.args.ema_decay, 0, alpha_dev=self.sc.view(S_ALPHA))
+        return {"loss": loss.detach(), "parts1": r1.detach(), "parts2": r2.detach(), "logits1": o1.detach(), "logits2": o2.detach(), "t_logits": ot}
+
+    def after(self):
+        self.lr_scheduler1.step()
+        self.lr_scheduler2.step()
+
+    def step(self, label_img, target_label, unlabel_img, cur_itrs, noise=None):
+        if noise is None:
+            noise = self.draw_noise(unlabel_img)
+        self.host_scalars(cur_itrs)
+        self.sc.push()
+        r = self.device_step(label_img, target_label, unlabel_img, noise)
+        self.after()
+        return r
+
+
 class GraphedStep:
     """Captures ``step_obj.device_step`` on static input buffers into one hipGraph (torch.cuda.CUDAGraph) and replays it.
     Host scalars are copied to the device eagerly in front of every replay (StepScalars ring); dropout masks change per replay
@@ -819,6 +886,31 @@ def CPS(model1, model2, label_loader, unlabel_loader, test_loader, args, step_cl
 def CTCT(model1, model2, label_loader, unlabel_loader, test_loader, args):
     """Cross teaching between CNN and transformer with the driver's signature (2021_12_MIDL_CTCT_ACDC.py:82)."""
     return CPS(model1, model2, label_loader, unlabel_loader, test_loader, args, step_cls=CTCTStep)
+
+
+def S4CVnet(model1, model2, ema_model, label_loader, unlabel_loader, test_loader, args):
+    """2022_08_CVPR_S4CVNet_ACDC.py:70-230."""
+    st = S4CVNetStep(model1, model2, ema_model, args, getattr(args, "dp", None))
+    best1, best2 = _Best(args, "model1", "model1_save_path"), _Best(args, "model2", "model2_save_path")
+    best_ema = _Best(args, "ema", "ema_model_save_path")
+    model1.train()
+    model2.train()
+    cur_itrs, log = 0, []
+    labels = _cycle(label_loader)
+    max_epoch = args.total_itrs // len(unlabel_loader) + 1
+    for epoch in range(max_epoch):
+        for img_unlabel, _ in unlabel_loader:
+            cur_itrs += 1
+            img_labeled, target_label = next(labels)
+            r = st.step(img_labeled.to(args.device).float(), target_label.to(args.device), img_unlabel.to(args.device).float(), cur_itrs)
+            log.append(r["loss"])
+            if _due(cur_itrs, args, test_loader):
+                best1(model1, st.optimizer1, st.lr_scheduler1, test_loader, cur_itrs, "model1")
+                best2(model2, st.optimizer2, st.lr_scheduler2, test_loader, cur_itrs, "model2")
+                best_ema(ema_model, st.optimizer2, st.lr_scheduler2, test_loader, cur_itrs, "ema")
+            if cur_itrs > args.total_itrs:
+                return torch.stack(log)
+    return torch.stack(log)
 
 
 def HPFG(model1, model2, ema_model, label_loader, unlabel_loader, test_loader, args):

@@ -8,6 +8,7 @@ restatements against them and writes the reference's outputs as fixtures under t
   trace_hpfg2.npz   main.py:125-212 with the branches the first HPFG trace misses: Nu//Nl = 3 label repeat (:142-143, batch 2+6 like the
                     reference YAML's 8+24), cur_itrs = 999 / 1000 / 1001 across the `cur_itrs < 1000` gate (:186-188), both Medical_LR
                     schedulers stepped every iteration (:211-212)
+  trace_s4cvnet.npz 2022_08_CVPR_S4CVNet_ACDC.py:107-167 (two U-Net students + EMA teacher on noisy unlabelled input), iterations 999..1001
   trace_sup224.npz  sup_ACDC.py:83-93, BASELINE configs[0] as written: UNet(1,4), 8 synthetic 224x224 slices, SGD + cosine schedule, 10
                     iterations: per-iteration loss, final eval logits (sub-sampled + checksums) and mean foreground Dice.  Inputs and
                     dropout masks are regenerated from seeds (15 MB of masks otherwise); their checksums are stored so that a different
@@ -216,12 +217,102 @@ def sup224_trace(report):
     report["sup224_dice"] = float(dice)
 
 
+def s4cvnet_trace(report):
+    """2022_08_CVPR_S4CVNet_ACDC.py:107-167 with U-Nets as both students (the reference's s4cvnet_unet YAML), batch 2+4, 64x64,
+    iterations 999 / 1000 / 1001 (the consistency gate opens at 1000)."""
+    R = load_reference()
+    torch.manual_seed(1337)
+    m1 = R.unet.UNet(1, 4)
+    m2 = R.unet.UNet(1, 4)
+    em = copy.deepcopy(m2)
+    for p_ in em.parameters():
+        p_.requires_grad = False
+    m1.train()
+    m2.train()
+    o1 = torch.optim.SGD(m1.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+    o2 = torch.optim.SGD(m2.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+    s1, s2 = R.medlr.Medical_LR(o1, 0.01, 30000), R.medlr.Medical_LR(o2, 0.01, 30000)
+    for _ in range(998):
+        o1.step()
+        o2.step()
+        s1.step()
+        s2.step()
+    torch.manual_seed(1337)
+    sa = unet_ref.init_state(None, 1, 4)
+    sb = unet_ref.init_state(None, 1, 4)
+    se = unet_ref.clone_state(sb)
+    ba, bb = {}, {}
+    NL, NU, HW = 2, 4, 64
+    ce = torch.nn.CrossEntropyLoss(ignore_index=255)
+    dl = R.dice.DiceLoss(4)
+    xl, yl = synth_batch(61, NL, HW, HW)
+    xu, _ = synth_batch(62, NU, HW, HW)
+    yl = yl.long()
+    rl, ol, mm, noises = [], [], [], []
+    c1 = c2 = 0.0
+    for j, cur in enumerate((999, 1000, 1001)):
+        torch.manual_seed(8000 + j)
+        nz = torch.randn_like(xu)
+        noises.append(nz)
+        ema_in = xu + torch.clamp(nz * 0.1, -0.2, 0.2)
+        vol = torch.cat([xl, xu], 0)
+        torch.manual_seed(8100 + j)
+        a = m1(vol)
+        sa_ = torch.softmax(a, 1)
+        b = m2(vol)
+        sb_ = torch.softmax(b, 1)
+        with torch.no_grad():
+            eo = em(ema_in)
+            es = torch.softmax(eo, 1)
+        l1 = 0.5 * (ce(a[:NL], yl) + dl(sa_[:NL], yl.unsqueeze(1)))
+        l2 = 0.5 * (ce(b[:NL], yl) + dl(sb_[:NL], yl.unsqueeze(1)))
+        sup = l1 + l2
+        p1 = torch.argmax(sa_[NL:].detach(), 1)
+        p2 = torch.argmax(sb_[NL:].detach(), 1)
+        ps1 = dl(sa_[NL:], p2.unsqueeze(1))
+        ps2 = dl(sb_[NL:], p1.unsqueeze(1))
+        w = 0.1 * R.utils.linear_rampup(cur // 150, 200.0)
+        if cur < 1000:
+            c1 = c2 = 0.0
+        else:
+            c1 = torch.mean((sa_[NL:] - es) ** 2)
+            c2 = torch.mean((sb_[NL:] - es) ** 2)
+        semi = (7 * w * ps1 + w * c1) + (7 * w * ps2 + w * c2)
+        loss = sup + semi
+        o1.zero_grad()
+        o2.zero_grad()
+        loss.backward()
+        o1.step()
+        o2.step()
+        R.utils.update_ema_variables(m2, em, 0.99, cur)
+        s1.step()
+        s2.step()
+        rl.append([loss.item(), sup.item(), float(semi), ps1.item(), ps2.item(), float(c1), float(c2)])
+        torch.manual_seed(8100 + j)
+        ma = unet_ref.draw_dropout_masks(NL + NU, HW, HW)
+        mb = unet_ref.draw_dropout_masks(NL + NU, HW, HW)
+        mt = unet_ref.draw_dropout_masks(NU, HW, HW)
+        mm.append((ma, mb, mt))
+        lr = laws_ref.medical_lr(cur, 0.01, 30000)
+        r = steps_ref.s4cvnet_step(sa, sb, se, ba, bb, xl, yl, xu, nz, cur, lr, lr, 0.1, 200.0, 0.99, 0.9, 5e-4, ma, mb, mt)
+        ol.append([r["loss"], r["sup"], r["semi"], r["ps1"], r["ps2"], r["cons1"], r["cons2"]])
+    close(rl, ol, 1e-4, "s4cvnet trace")
+    for k_, v_ in em.state_dict().items():
+        close(v_, se[k_], 1e-5, f"s4cvnet ema {k_}")
+    d = dict(xl=xl.numpy(), yl=yl.numpy().astype(np.uint8), xu=xu.numpy(), noise=np.stack([n.numpy() for n in noises]), cur_itrs=np.array([999, 1000, 1001]),
+             losses=np.array(rl), logits1_last=a.detach().numpy(), logits2_last=b.detach().numpy(), t_logits_last=eo.numpy(),
+             **{f"it{k}_{w}{i}": pack(m) for k, trip in enumerate(mm) for w, mlist in zip("abt", trip) for i, m in enumerate(mlist)})
+    np.savez_compressed(os.path.join(OUT, "trace_s4cvnet.npz"), **d)
+    report["s4cvnet_trace_err"] = float(np.abs(np.array(rl) - np.array(ol)).max())
+
+
 def main():
     torch.set_num_threads(8)
     report = {}
     augment_fixture(report)
     hpfg2_trace(report)
     sup224_trace(report)
+    s4cvnet_trace(report)
     import json
     with open(os.path.join(OUT, "pinning_report_r2.json"), "w") as f:
         json.dump({"torch": torch.__version__, "reference": "fakerlove1/HPFG @ /root/reference", "checks": report}, f, indent=1)

@@ -179,6 +179,47 @@ def cps_step(st1, st2, bufs1, bufs2, xl, yl, xu, lr1, lr2, cons_w, momentum=0.9,
             "grads1": g1, "grads2": g2}
 
 
+def s4cvnet_step(st1, st2, ema, bufs1, bufs2, xl, yl, xu, noise, cur_itrs, lr1, lr2, consistency, rampup, ema_decay, momentum=0.9, weight_decay=5e-4,
+                 masks1=None, masks2=None, masks_t=None):
+    """2022_08_CVPR_S4CVNet_ACDC.py:107-167 with two U-Nets: both students see [labelled ; unlabelled], the EMA teacher of model2 sees the
+    unlabelled images plus clamp(noise * 0.1, +-0.2) (noise = the raw normal draw of :109); cross Dice pseudo supervision (7w) and, from
+    iteration 1000 on, the softmax MSE of each student against the teacher (w)."""
+    n1, n2 = _train_state(st1), _train_state(st2)
+    nl = xl.shape[0]
+    vol = torch.cat([xl, xu], 0)
+    o1 = unet_ref.unet_forward(st1, vol, True, masks1)
+    s1 = torch.softmax(o1, 1)
+    o2 = unet_ref.unet_forward(st2, vol, True, masks2)
+    s2 = torch.softmax(o2, 1)
+    with torch.no_grad():
+        ot = unet_ref.unet_forward(ema, xu + torch.clamp(noise * 0.1, -0.2, 0.2), True, masks_t)
+        st_ = torch.softmax(ot, 1)
+    loss1 = 0.5 * (losses_ref.cross_entropy(o1[:nl], yl) + losses_ref.dice_loss(s1[:nl], yl.unsqueeze(1)))
+    loss2 = 0.5 * (losses_ref.cross_entropy(o2[:nl], yl) + losses_ref.dice_loss(s2[:nl], yl.unsqueeze(1)))
+    sup = loss1 + loss2
+    p1 = torch.argmax(s1[nl:].detach(), 1)
+    p2 = torch.argmax(s2[nl:].detach(), 1)
+    ps1 = losses_ref.dice_loss(s1[nl:], p2.unsqueeze(1))
+    ps2 = losses_ref.dice_loss(s2[nl:], p1.unsqueeze(1))
+    w = consistency * laws_ref.linear_rampup(cur_itrs // 150, rampup)
+    if cur_itrs < 1000:
+        c1 = c2 = 0.0
+    else:
+        c1 = losses_ref.mse_consistency(s1[nl:], st_)
+        c2 = losses_ref.mse_consistency(s2[nl:], st_)
+    semi = (7 * w * ps1 + w * c1) + (7 * w * ps2 + w * c2)
+    loss = sup + semi
+    g1, g2 = _grads_joint(loss, [(st1, n1), (st2, n2)])
+    _detach_state(st1)
+    _detach_state(st2)
+    sgd_update(st1, g1, bufs1, lr1, momentum, weight_decay)
+    sgd_update(st2, g2, bufs2, lr2, momentum, weight_decay)
+    ema_update(ema, st2, laws_ref.ema_alpha(cur_itrs, ema_decay))
+    return {"loss": float(loss.detach()), "sup": float(sup.detach()), "semi": float(torch.as_tensor(semi).detach()), "ps1": float(ps1.detach()),
+            "ps2": float(ps2.detach()), "cons1": float(torch.as_tensor(c1).detach()), "cons2": float(torch.as_tensor(c2).detach()), "logits1": o1.detach(),
+            "logits2": o2.detach(), "t_logits": ot}
+
+
 def adamw_update(st, grads, state, lr: float, weight_decay: float, betas=(0.9, 0.999), eps: float = 1e-8):
     """torch.optim.AdamW (decoupled weight decay, bias-corrected moments) over a state dict, in place; `state` keeps step / m / v."""
     state["step"] = state.get("step", 0) + 1

@@ -44,6 +44,24 @@ def test_device_augmentation_equals_host_pipeline(size):
     assert modes == {0, 1, 2}          # the batch exercised: no-op, rot90+flip, rotation
 
 
+def test_device_augmentation_equals_the_reference_fixture(golden_dir):
+    """The device pipeline against outputs of the REFERENCE's own RandomGenerator (datasets/utils.py:99-117; fixture written by
+    oracle/make_golden_r2.py from seeded `random` / `np.random`): images and masks bit for bit, all three branches."""
+    from tests.trace_replay import unpack_labels2
+    d = np.load(f"{golden_dir}/augment.npz")
+    n = int(d["n"])
+    slices = [(d[f"src_img{i}"], d[f"src_lab{i}"]) for i in range(n)]
+    pool = DeviceSlicePool(slices, DEV)
+    gen = RandomGeneratorDevice((224, 224))
+    for k, seed in enumerate(d["seeds"]):
+        img, lab = gen(pool, [k % n], py_rng=random.Random(int(seed)), np_rng=np.random.RandomState(int(seed)))
+        got = img[0].cpu().numpy()
+        assert np.array_equal(got.astype(np.float16), d[f"img{k}"]), (k, int(d["branch"][k]))
+        assert abs(float(got.astype(np.float64).sum()) - float(d[f"img{k}_sum"])) < 1e-6, k          # full-precision checksum
+        assert np.array_equal(lab[0].cpu().numpy().reshape(-1), unpack_labels2(d[f"lab{k}"], 224 * 224)), k
+    assert set(d["branch"].tolist()) == {0, 1, 2}
+
+
 def test_device_pool_loader_contract_and_one_training_step():
     """build_loader("device_synthetic"): DataLoader-shaped device loaders feeding a Mean-Teacher step."""
     from copy import deepcopy

@@ -1,0 +1,117 @@
+"""GPU: the driver loops with the reference's names (Supervise / Mean_Teacher / CPS / HPFG; sup_ACDC.py:59-125,
+2017_03_NIPS_Mean-Teacher_ACDC.py:63-162, 2021_06_CVPR_CPS_ACDC.py:61-169, main.py:79-289) end to end on build_loader("synthetic"):
+iteration law (returns once cur_itrs > total_itrs), evaluation every step_size iterations through test_acdc, best-Dice checkpoints in the
+reference's dict format, and resuming an optimizer from one."""
+import os
+from copy import deepcopy
+
+import pytest
+import torch
+
+from hpfg_amd.datasets import build_loader
+from hpfg_amd.model import build_model
+from hpfg_amd.train import CPS, HPFG, Mean_Teacher, Supervise
+from hpfg_amd.utils import AttrDict, build_optimizer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class _Log:
+    def __init__(self):
+        self.lines = []
+
+    def info(self, msg):
+        self.lines.append(str(msg))
+
+
+def _opt(**kw):
+    d = dict(opt="sgd", lr=0.01, momentum=0.9, weight_decay=1e-4, sched="medical", warmup_epochs=0, warmup_lr=1e-4, min_lr=1e-6, total_itrs=4, step_size=2)
+    d.update(kw)
+    return AttrDict(d)
+
+
+def _args(tmp, datasets="synthetic", **kw):
+    a = _opt(datasets=datasets, model="unet", in_channels=1, num_classes=4, batch_size=2, unlabel_batch_size=2, train_crop_size=(64, 64),
+             test_crop_size=(64, 64), synthetic_labeled=8, synthetic_unlabeled=12, synthetic_test_volumes=2, device=DEV, consistency=0.1,
+             consistency_rampup=200.0, ema_decay=0.99, save_path=str(tmp), logger=_Log())
+    a.update(kw)
+    os.makedirs(os.path.join(str(tmp), "model"), exist_ok=True)
+    for k in ("model", "ema_model", "model1", "model2"):
+        a[f"{k}_save_path"] = os.path.join(str(tmp), "model", f"{k}.pth")
+    return a
+
+
+def _teacher(m):
+    e = deepcopy(m)
+    for p in e.parameters():
+        p.requires_grad = False
+    return e
+
+
+def _check_ckpt(path, model, keys=("model", "optimizer", "lr_scheduler", "cur_itrs", "best_dice")):
+    ck = torch.load(path, weights_only=False)
+    assert set(keys) <= set(ck)
+    assert set(ck["model"].keys()) == set(model.state_dict().keys())
+    assert ck["cur_itrs"] in (2, 4) and 0.0 < ck["best_dice"] <= 1.0
+    return ck
+
+
+def test_supervise_loop(tmp_path):
+    a = _args(tmp_path, datasets="sup_synthetic", weight_decay=5e-4, sched="cosine")
+    torch.manual_seed(1)
+    m = build_model(a).to(DEV)
+    train_loader, test_loader = build_loader(a)
+    log = Supervise(m, train_loader, test_loader, a)
+    assert log.shape == (a.total_itrs + 1,) and torch.isfinite(log).all()          # the reference stops once cur_itrs > total_itrs
+    files = os.listdir(os.path.join(str(tmp_path), "model"))
+    assert any(f.startswith("model_0.") for f in files), files                      # sup_ACDC.py:114 names the file by its Dice
+    assert any("dice" in ln for ln in a.logger.lines)
+    assert m.training
+
+
+def test_mean_teacher_loop_checkpoints_and_resume(tmp_path):
+    a = _args(tmp_path)
+    torch.manual_seed(1337)
+    m = build_model(a).to(DEV)
+    e = _teacher(m)
+    lab, unl, test = build_loader(a)
+    log = Mean_Teacher(m, e, lab, unl, test, a)
+    assert log.shape == (a.total_itrs + 1,) and torch.isfinite(log).all()
+    ck = _check_ckpt(a.model_save_path, m)
+    _check_ckpt(a.ema_model_save_path, e)
+    assert m.training and e.training
+    # resume: a fresh optimizer takes the saved momentum (FusedSGD.state_dict carries the flat buffer)
+    opt = build_optimizer(a, m)
+    opt.load_state_dict(ck["optimizer"])
+    assert float(opt._mom.abs().max()) > 0 and torch.equal(opt._mom, ck["optimizer"]["flat_momentum"].to(opt._mom.device))
+    m2 = build_model(a).to(DEV)
+    m2.load_state_dict(ck["model"])
+    assert torch.equal(m2.state_dict()["decoder.out_conv.weight"], ck["model"]["decoder.out_conv.weight"].to(DEV))
+
+
+def test_cps_loop(tmp_path):
+    a = _args(tmp_path)
+    a.model1, a.model2 = _opt(), _opt()
+    torch.manual_seed(1337)
+    m1, m2 = build_model(a).to(DEV), build_model(a).to(DEV)
+    lab, unl, test = build_loader(a)
+    log = CPS(m1, m2, lab, unl, test, a)
+    assert log.shape == (a.total_itrs + 1,) and torch.isfinite(log).all()
+    _check_ckpt(a.model1_save_path, m1)
+    _check_ckpt(a.model2_save_path, m2)
+
+
+def test_hpfg_loop_with_label_repeat(tmp_path):
+    """main.py:79-289 on a 2+4 batch (the labelled batch of the second iterator is repeated Nu//Nl = 2 times, :142-143)."""
+    a = _args(tmp_path, model="unet_plus", unlabel_batch_size=4, weight_decay=5e-4)
+    a.model1, a.model2 = _opt(weight_decay=5e-4), _opt(weight_decay=5e-4)
+    torch.manual_seed(1)
+    m1, m2 = build_model(a).to(DEV), build_model(a).to(DEV)
+    e = _teacher(m2)
+    lab, unl, test = build_loader(a)
+    log = HPFG(m1, m2, e, lab, unl, test, a)
+    assert log.shape == (a.total_itrs + 1,) and torch.isfinite(log).all()
+    for path, net in ((a.model1_save_path, m1), (a.model2_save_path, m2), (a.ema_model_save_path, e)):
+        _check_ckpt(path, net)
+    assert sum("_dice" in ln for ln in a.logger.lines) >= 6           # three networks evaluated at iterations 2 and 4

@@ -10,7 +10,7 @@ import torch
 
 from hpfg_amd import engine as E
 from hpfg_amd.model import UNet, UNet_Plus
-from hpfg_amd.train import CPSStep, HPFGStep, ICTStep, MeanTeacherStep, SupervisedStep, UAMTStep, noise_add, uncertainty_mask
+from hpfg_amd.train import CPSStep, HPFGStep, ICTStep, MeanTeacherStep, S4CVNetStep, SupervisedStep, UAMTStep, noise_add, uncertainty_mask
 from hpfg_amd.utils import AttrDict
 from oracle import losses_ref
 from tests import trace_replay as R
@@ -304,6 +304,48 @@ def test_hpfg2_trace_gate_repeat_and_stepped_schedulers(golden_dir, math):
     assert np.abs(rows[:, 1] - ref[:, 4]).max() < TOL, (rows, ref)
     assert np.abs(rows[1:, 2] - ref[1:, 5]).max() < 1e-4, (rows, ref)      # the MSE itself once the gate is open (parts2[5])
     tol = logit_tol(math, "hpfg2", R.replay_hpfg, ["logits1_last", "logits2_last", "t_logits_last"], stepped_lr=True)
+    assert maxerr(r["logits1"].cpu(), torch.from_numpy(d["logits1_last"])) < tol
+    assert maxerr(r["logits2"].cpu(), torch.from_numpy(d["logits2_last"])) < tol
+    assert maxerr(r["t_logits"].cpu(), torch.from_numpy(d["t_logits_last"])) < tol
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_s4cvnet_trace(golden_dir, math):
+    """S4CVnet step (2022_08_CVPR_S4CVNet_ACDC.py:107-167) against three iterations of the reference's own
+    modules across the iteration-1000 gate (oracle/make_golden_r2.py): two U-Net students, EMA teacher of model2 on noisy unlabelled input."""
+    d = np.load(f"{golden_dir}/trace_s4cvnet.npz")
+    torch.manual_seed(1337)
+    m1 = UNet(1, 4).to(DEV)
+    m2 = UNet(1, 4).to(DEV)
+    m1.math = m2.math = math
+    ema = deepcopy(m2)
+    for p in ema.parameters():
+        p.requires_grad = False
+    m1.train()
+    m2.train()
+    args = _opt_args()
+    args.model1, args.model2 = _opt_args(weight_decay=5e-4), _opt_args(weight_decay=5e-4)
+    st = S4CVNetStep(m1, m2, ema, args)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(int(d["cur_itrs"][0]) - 1):
+            st.lr_scheduler1.step()
+            st.lr_scheduler2.step()
+    xl, yl, xu = (torch.from_numpy(d[k]).to(DEV) for k in ("xl", "yl", "xu"))
+    rows = []
+    for j, cur in enumerate(d["cur_itrs"]):
+        m1.external_dropout_masks = _masks(d, f"it{j}_a", 6, 64)
+        m2.external_dropout_masks = _masks(d, f"it{j}_b", 6, 64)
+        ema.external_dropout_masks = _masks(d, f"it{j}_t", 4, 64)
+        r = st.step(xl, yl, xu, int(cur), noise=torch.from_numpy(d["noise"][j]).to(DEV))
+        p1, p2 = r["parts1"].cpu(), r["parts2"].cpu()
+        rows.append([float(r["loss"]), float(p1[4]), float(p2[4]), float(p1[5]), float(p2[5])])
+    rows, ref = np.array(rows), d["losses"]
+    assert np.abs(rows[:, 0] - ref[:, 0]).max() < TOL, (rows, ref)
+    assert np.abs(rows[:, 1:3] - ref[:, 3:5]).max() < TOL, (rows, ref)          # the two cross Dice terms
+    assert np.abs(rows[1:, 3:5] - ref[1:, 5:7]).max() < 1e-4, (rows, ref)       # the two MSE terms once the gate is open
+    tol = logit_tol(math, "s4cvnet", R.replay_s4cvnet, ["logits1_last", "logits2_last", "t_logits_last"])
     assert maxerr(r["logits1"].cpu(), torch.from_numpy(d["logits1_last"])) < tol
     assert maxerr(r["logits2"].cpu(), torch.from_numpy(d["logits2_last"])) < tol
     assert maxerr(r["t_logits"].cpu(), torch.from_numpy(d["t_logits_last"])) < tol

@@ -140,6 +140,16 @@ def test_hpfg2_trace_gate_repeat_and_stepped_schedulers(golden_dir):
         assert float((r[k] - torch.from_numpy(d[k])).abs().max()) < 2e-4, k
 
 
+def test_s4cvnet_trace(golden_dir):
+    """2022_08_CVPR_S4CVNet_ACDC.py:107-167: three iterations of the reference's own modules across the iteration-1000 gate."""
+    d = np.load(f"{golden_dir}/trace_s4cvnet.npz")
+    assert d["losses"][0, 5] == 0.0 and d["losses"][1, 5] > 0.0 and d["losses"][1, 6] > 0.0
+    r = R.replay_s4cvnet(d)
+    assert np.abs(r["losses"] - d["losses"]).max() < 1e-4
+    for k in ("logits1_last", "logits2_last", "t_logits_last"):
+        assert float((r[k] - torch.from_numpy(d[k])).abs().max()) < 2e-4, k
+
+
 def test_sup224_trace_cfg1_as_written(golden_dir):
     """BASELINE configs[0] at its real size: 10 supervised iterations on 8 slices of 224x224 (sup_ACDC.py:83-93), inputs and dropout
     masks regenerated from the seeds the reference run used (checksums stored in the fixture)."""

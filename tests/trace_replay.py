@@ -127,6 +127,23 @@ def replay_hpfg(d, seed=None, stepped_lr=False):
     return {"losses": np.array(rows), "logits1_last": r["logits1"], "logits2_last": r["logits2"], "t_logits_last": r["t_logits"]}
 
 
+def replay_s4cvnet(d, seed=None):
+    torch.manual_seed(1337)
+    sa, sb = unet_ref.init_state(None, 1, 4), unet_ref.init_state(None, 1, 4)
+    perturb(sa, seed)
+    perturb(sb, None if seed is None else seed + 10)
+    se, ba, bb = unet_ref.clone_state(sb), {}, {}
+    xl, yl, xu = torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]).long(), torch.from_numpy(d["xu"])
+    nl, nu, hw = xl.shape[0], xu.shape[0], xl.shape[-1]
+    rows = []
+    for j, cur in enumerate(d["cur_itrs"]):
+        lr = laws_ref.medical_lr(int(cur), 0.01, 30000)
+        r = steps_ref.s4cvnet_step(sa, sb, se, ba, bb, xl, yl, xu, torch.from_numpy(d["noise"][j]), int(cur), lr, lr, 0.1, 200.0, 0.99, 0.9, 5e-4,
+                                   unpack_masks(d, f"it{j}_a", nl + nu, hw), unpack_masks(d, f"it{j}_b", nl + nu, hw), unpack_masks(d, f"it{j}_t", nu, hw))
+        rows.append([r["loss"], r["sup"], r["semi"], r["ps1"], r["ps2"], r["cons1"], r["cons2"]])
+    return {"losses": np.array(rows), "logits1_last": r["logits1"], "logits2_last": r["logits2"], "t_logits_last": r["t_logits"]}
+
+
 def unpack_labels2(packed, n):
     """Labels stored at 2 bits each (oracle/make_golden_r2.py) -> uint8 [n]."""
     bits = np.unpackbits(packed)[: 2 * n].reshape(n, 2)
