@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ = range(7)
 LOSS_NSUM = 32
-VERSION = 118
+VERSION = 119
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -95,7 +95,7 @@ PROTOTYPES = {
     "hpfg_bn_bwd_reduce_pool": (_i, [C.POINTER(Act), _p, _i, _i, _i, _i, _p, _p]),
     "hpfg_bn_bwd_pool_blocks": (_i, [_i, _i, _i, _i]),
     "hpfg_bn_bwd_blocks": (_i, [_i, _i, _i, _i]),
-    "hpfg_bn_bwd_finalize": (_i, [_p, _i, _p, _d, _p, _p, _p, _p, _i, _p]),
+    "hpfg_bn_bwd_finalize": (_i, [_p, _i, _p, _d, _p, _p, _p, _p, _i, _f, _p]),
     "hpfg_wgrad": (_i, [C.POINTER(WgradArgs), _p]),
     "hpfg_slab_reduce_multi": (_i, [_p, C.POINTER(SlabDesc), _i, _p]),
     "hpfg_wgrad_splits": (_i, [_i, _i, _i, _i, _i, _i]),
@@ -145,6 +145,14 @@ PROTOTYPES = {
     "hpfg_sgd_step": (_i, [_p, _p, _p, _l, _p, _f, _f, _f, _p]),
     "hpfg_adamw_step": (_i, [_p, _p, _p, _p, _l, _p, _p, _f, _f, _f, _f, _f, _p]),
     "hpfg_ema_update": (_i, [_p, _p, _l, _p, _p]),
+    "hpfg_gemm_f32": (_i, [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _p, _i, _i, _p]),
+    "hpfg_col_sum": (_i, [_p, _l, _i, _l, _p, _p]),
+    "hpfg_relu_bwd": (_i, [_p, _p, _l, _p]),
+    "hpfg_neck_pool_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "hpfg_neck_pool_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "hpfg_l2norm_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "hpfg_l2norm_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "hpfg_ntxent_rows": (_i, [_p, _i, _f, _p, _p, _p]),
 }
 
 _lock = threading.Lock()

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(HpfgAct s, cons
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, const double* __restrict__ sums,
                                                               double count, const float* __restrict__ gamma, float* __restrict__ bn,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int C, float pscale) {
   __shared__ double sh[8];
   const int c = blockIdx.x;
   const double mean = bn[HPFG_BN_MEAN * C + c], rstd = bn[HPFG_BN_RSTD * C + c], ga = gamma[c];
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     bn[HPFG_BN_K1 * C + c] = (float)(ga * rstd);
     bn[HPFG_BN_K2 * C + c] = (float)(-ga * rstd * rstd * m2);
     bn[HPFG_BN_K3 * C + c] = (float)(ga * rstd * (mean * rstd * m2 - m1));
-    if (dgamma) dgamma[c] = (float)sgx;
-    if (dbeta) dbeta[c] = (float)sg;
+    if (dgamma) dgamma[c] = (float)(sgx * pscale);
+    if (dbeta) dbeta[c] = (float)(sg * pscale);
   }
 }
 
@@ -337,9 +337,10 @@ extern "C" int hpfg_bn_bwd_reduce_pool(const HpfgAct* g, const float* dP, int dp
 }
 
 extern "C" int hpfg_bn_bwd_finalize(const float* partials, int nblk, const double* sums, double count, const float* gamma, float* bn,
-                                    float* dgamma, float* dbeta, int C, void* stream) {
+                                    float* dgamma, float* dbeta, int C, float param_grad_scale, void* stream) {
   HPFG_ARG_CHECK((partials && nblk > 0) || sums, "bn_bwd_finalize: need partials or sums");
   HPFG_ARG_CHECK(gamma && bn && C > 0 && count > 0, "bn_bwd_finalize: bad args");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nblk, sums, count, gamma, bn, dgamma, dbeta, C);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nblk, sums, count, gamma, bn, dgamma, dbeta, C,
+                     param_grad_scale);
   return hpfg_launch_status("bn_bwd_finalize_kernel");
 }

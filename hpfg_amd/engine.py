@@ -374,11 +374,11 @@ class UNetEngine:
             sums = self.sums[: 2 * s.cout]
             L.check(self.lib.hpfg_reduce_partials(L.ptr(self.partials), nblk, s.cout, L.ptr(sums), st), "reduce_partials")
             self.allreduce(sums)
-            L.check(self.lib.hpfg_bn_bwd_finalize(None, 0, L.ptr(sums), count, L.ptr(gam), L.ptr(self.bn[s.name]), L.ptr(dg), L.ptr(db), s.cout, st),
-                    "bn_bwd_finalize")
+            L.check(self.lib.hpfg_bn_bwd_finalize(None, 0, L.ptr(sums), count, L.ptr(gam), L.ptr(self.bn[s.name]), L.ptr(dg), L.ptr(db), s.cout,
+                                                  1.0 / self.world, st), "bn_bwd_finalize")      # global sums on every rank: the SUM all-reduce of the gradients restores them
         else:
             L.check(self.lib.hpfg_bn_bwd_finalize(L.ptr(self.partials), nblk, None, count, L.ptr(gam), L.ptr(self.bn[s.name]), L.ptr(dg), L.ptr(db),
-                                                  s.cout, st), "bn_bwd_finalize")
+                                                  s.cout, 1.0, st), "bn_bwd_finalize")
         return g
 
     def _wgrad_dgrad(self, s: ConvSpec, g: L.Act, dgrad_out: torch.Tensor, stats_for: Optional[str] = None):

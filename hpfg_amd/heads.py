@@ -1,20 +1,147 @@
-"""Projection necks of UNet_Plus (reference model/unet.py:120-152).
+"""Projection necks of UNet_Plus (reference model/unet.py:120-152) and the NT-Xent core of Dense_Loss (utils/loss/dense_loss.py:17-40)
+on the HIP library.
 
-GAP -> Linear -> ReLU -> Linear and AdaptiveAvgPool(4x4) -> 1x1 conv -> ReLU -> 1x1 conv on [N,256,14,14] features and on
-the [N,4,224,224] logits: ~1 GFLOP per HPFG step of plain dense GEMMs.  They are issued as library GEMMs through
-PyTorch-ROCm (rocBLAS / hipBLASLt), with torch autograd for their backward; the gradient w.r.t. their inputs flows back into
-the HIP U-Net backward (engine.backward's ``dfeat4`` / ``dlogits``).
+GAP -> Linear -> ReLU -> Linear and AdaptiveAvgPool(4x4) -> 1x1 conv -> ReLU -> 1x1 conv on the [N,256,14,14] bottleneck and on the
+[N,4,224,224] logits: both poolings are ONE kernel (``hpfg_neck_pool_fwd``), every dense product -- forward, input gradient, weight
+gradient -- is ``hpfg_gemm_f32`` (exact fp32 on the matrix cores: the necks are ~1 GFLOP per HPFG step), bias gradients are column
+sums.  The gradient w.r.t. the neck inputs flows back into the HIP U-Net backward (engine.backward's ``dfeat4`` / ``dlogits``).
+No rocBLAS / MIOpen call is left on the HPFG step.
 """
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
+
+from . import _lib as L
+
+
+def _st(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def gemm(a: torch.Tensor, sam: int, sak: int, b: torch.Tensor, sbk: int, sbn: int, m: int, n: int, k: int, bias=None, relu: bool = False,
+         out: torch.Tensor = None) -> torch.Tensor:
+    """out[m,n] = act(sum_k a(m,k) b(k,n) + bias[n]) with explicit element strides (see include/hpfg_hip.h: hpfg_gemm_f32)."""
+    if not a.is_cuda:
+        raise RuntimeError("hpfg_amd necks run on the HIP library only (no CPU fallback)")
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    L.check(L.load().hpfg_gemm_f32(L.ptr(a), sam, sak, L.ptr(b), sbk, sbn, L.ptr(out), n, m, n, k, L.ptr(bias), 1 if relu else 0, 0, _st(a)), "gemm_f32")
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """y = relu?(x W^T + b); x [R,K] contiguous, W [M,K] contiguous (an nn.Linear weight or a flattened 1x1 conv weight)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu: bool):
+        x, w = x.contiguous(), w.contiguous()
+        R, K = x.shape
+        M = w.shape[0]
+        y = gemm(x, K, 1, w, 1, K, R, M, K, bias=b, relu=relu)
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        R, K = x.shape
+        M = w.shape[0]
+        lib = L.load()
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = dy.clone()
+            L.check(lib.hpfg_relu_bwd(L.ptr(dy), L.ptr(y), dy.numel(), _st(dy)), "relu_bwd")
+        dx = gemm(dy, M, 1, w, K, 1, R, K, M) if ctx.needs_input_grad[0] else None              # dY W
+        dw = gemm(dy, 1, M, x, K, 1, M, K, R)                                                    # dY^T X
+        db = torch.empty(M, dtype=torch.float32, device=dy.device)
+        L.check(lib.hpfg_col_sum(L.ptr(dy), R, M, M, L.ptr(db), _st(dy)), "col_sum")
+        return dx, dw, db, None
+
+
+class _NeckPool(torch.autograd.Function):
+    """x [N,C,H,W] (NHWC memory preferred) -> (gap [N,C], pool [N*S*S, C]) = AdaptiveAvgPool2d(1) and (S) (unet.py:141-142,146)."""
+
+    @staticmethod
+    def forward(ctx, x, s: int):
+        v = x.permute(0, 2, 3, 1)
+        if not v.is_contiguous():
+            v = v.contiguous()
+        N, H, W, C = v.shape
+        gap = torch.empty(N, C, dtype=torch.float32, device=x.device)
+        pool = torch.empty(N * s * s, C, dtype=torch.float32, device=x.device)
+        L.check(L.load().hpfg_neck_pool_fwd(L.ptr(v), C, N, H, W, C, s, L.ptr(gap), L.ptr(pool), _st(x)), "neck_pool_fwd")
+        ctx.shape, ctx.s = (N, H, W, C), s
+        return gap, pool
+
+    @staticmethod
+    def backward(ctx, dgap, dpool):
+        N, H, W, C = ctx.shape
+        dx = torch.empty(N, H, W, C, dtype=torch.float32, device=(dgap if dgap is not None else dpool).device)
+        dg = dgap.contiguous() if dgap is not None else None
+        dp = dpool.contiguous() if dpool is not None else None
+        L.check(L.load().hpfg_neck_pool_bwd(L.ptr(dg), L.ptr(dp), N, H, W, C, ctx.s, L.ptr(dx), _st(dx)), "neck_pool_bwd")
+        return dx.permute(0, 3, 1, 2), None
 
 
 def projection_neck(m, x: torch.Tensor, s: int = 4):
-    """x: [N,C,H,W] (any strides).  Returns (g [N,128], d [N,128,s*s]) like projection_conv.forward (unet.py:139-152)."""
-    g = F.adaptive_avg_pool2d(x, 1).flatten(1)
-    g = F.linear(F.relu(F.linear(g, m.mlp["0"].weight, m.mlp["0"].bias)), m.mlp["2"].weight, m.mlp["2"].bias)
-    d = F.adaptive_avg_pool2d(x, s)
-    d = F.conv2d(F.relu(F.conv2d(d, m.mlp_conv["0"].weight, m.mlp_conv["0"].bias)), m.mlp_conv["2"].weight, m.mlp_conv["2"].bias)
-    return g, d.flatten(2)
+    """x: [N,C,H,W] (any strides).  Returns (g [N,128], d [N,128,s*s]) like projection_conv.forward (unet.py:139-152); d is a view of
+    [N, s*s, 128] memory (position-major), which Dense_Loss consumes without a copy."""
+    if not x.is_cuda:
+        raise RuntimeError("hpfg_amd necks run on the HIP library only (no CPU fallback)")
+    gap, pool = _NeckPool.apply(x.float(), s)
+    g = _Linear.apply(_Linear.apply(gap, m.mlp["0"].weight, m.mlp["0"].bias, True), m.mlp["2"].weight, m.mlp["2"].bias, False)
+    w0, w2 = m.mlp_conv["0"].weight, m.mlp_conv["2"].weight
+    d = _Linear.apply(_Linear.apply(pool, w0.flatten(1), m.mlp_conv["0"].bias, True), w2.flatten(1), m.mlp_conv["2"].bias, False)
+    N = x.shape[0]
+    return g, d.view(N, s * s, d.shape[1]).permute(0, 2, 1)
+
+
+class _NTXent(torch.autograd.Function):
+    """contrastive_loss(out_1 = a (student, differentiable), out_2 = b (teacher, constant)) of dense_loss.py:17-36."""
+
+    @staticmethod
+    def forward(ctx, a, b, temperature: float):
+        if not a.is_cuda:
+            raise RuntimeError("hpfg_amd.Dense_Loss runs on the HIP library only (no CPU fallback)")
+        lib = L.load()
+        a, b = a.float(), b.float()
+        if a.dim() == 2:
+            a3, b3 = a.unsqueeze(2), b.unsqueeze(2)
+        else:
+            a3, b3 = a.flatten(2), b.flatten(2)
+        n, D, S = a3.shape
+        # position-major memory ([N, S, D], what projection_neck produces) is used as it is; anything else in the canonical [N, D, S] order
+        pm = S > 1 and a3.permute(0, 2, 1).is_contiguous() and b3.permute(0, 2, 1).is_contiguous()
+        if not pm:
+            a3, b3 = a3.contiguous(), b3.contiguous()
+        sd, ss = (1, D) if pm else (S, 1)
+        F_ = D * S
+        U = torch.empty(2 * n, F_, dtype=torch.float32, device=a.device)
+        norms = torch.empty(2 * n * S, dtype=torch.float32, device=a.device)
+        st = _st(a)
+        L.check(lib.hpfg_l2norm_fwd(L.ptr(a3), n, D, S, sd, ss, L.ptr(U), L.ptr(norms), st), "l2norm_fwd")
+        L.check(lib.hpfg_l2norm_fwd(L.ptr(b3), n, D, S, sd, ss, U.data_ptr() + 4 * n * F_, norms.data_ptr() + 4 * n * S, st), "l2norm_fwd")
+        gram = gemm(U, F_, 1, U, 1, F_, 2 * n, 2 * n, F_)
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        Q = torch.empty(n, 2 * n, dtype=torch.float32, device=a.device)
+        L.check(lib.hpfg_ntxent_rows(L.ptr(gram), n, float(temperature), L.ptr(loss), L.ptr(Q), st), "ntxent_rows")
+        ctx.save_for_backward(U, Q, norms)
+        ctx.geo = (n, D, S, sd, ss, pm, tuple(a.shape))
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        U, Q, norms = ctx.saved_tensors
+        n, D, S, sd, ss, pm, shape = ctx.geo
+        F_ = D * S
+        dU = gemm(Q, 2 * n, 1, U, F_, 1, n, F_, 2 * n)                                    # Q U: gradient w.r.t. the normalised student rows
+        dx = torch.empty(n, F_, dtype=torch.float32, device=U.device)
+        g = gout.reshape(1).float().contiguous()
+        L.check(L.load().hpfg_l2norm_bwd(L.ptr(dU), L.ptr(U), L.ptr(norms), n, D, S, sd, ss, L.ptr(g), L.ptr(dx), _st(U)), "l2norm_bwd")
+        dx = dx.view(n, S, D).permute(0, 2, 1) if pm else dx.view(n, D, S)
+        return dx.reshape(shape), None, None
+
+
+def ntxent(a: torch.Tensor, b: torch.Tensor, temperature: float) -> torch.Tensor:
+    return _NTXent.apply(a, b.detach(), temperature)

@@ -12,7 +12,6 @@ from typing import Optional, Sequence
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import _lib as L
 
@@ -147,23 +146,16 @@ class Med_Sup_Loss(nn.Module):
 
 
 class Dense_Loss(nn.Module):
-    """NT-Xent between student and (detached) teacher neck features (dense_loss.py:17-40).  2N x 2N similarity with
-    N <= 64: a tiny library GEMM + elementwise ops through PyTorch-ROCm."""
+    """NT-Xent between student and (detached) teacher neck features (dense_loss.py:17-40) on the HIP library: L2 normalisation over
+    dim 1, the [2N,2N] Gram matrix (hpfg_gemm_f32), the row losses and the gradient of the student features (hpfg_amd.heads.ntxent)."""
 
     def __init__(self, batch_size: int = 32, device=None, temperature: float = 0.7):
         super().__init__()
         self.batch_size, self.temperature = batch_size, temperature
 
     def contrastive_loss(self, a, b):
-        a = F.normalize(a, dim=1).flatten(1)
-        b = F.normalize(b, dim=1).flatten(1)
-        both = torch.cat([a, b], 0)
-        sim = torch.exp(both @ both.t() / self.temperature)
-        n2 = both.shape[0]
-        denom = sim.masked_fill(torch.eye(n2, dtype=torch.bool, device=sim.device), 0.0).sum(-1)
-        pos = torch.exp((a * b).sum(-1) / self.temperature)
-        pos = torch.cat([pos, pos], 0)
-        return (-torch.log(pos / denom)).mean()
+        from ..heads import ntxent
+        return ntxent(a, b, self.temperature)
 
     def forward(self, x, y):
         return 0.5 * (self.contrastive_loss(x[0], y[0].detach()) + self.contrastive_loss(x[1], y[1].detach()))

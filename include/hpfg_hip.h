@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 118
+#define HPFG_VERSION 119
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -147,8 +147,10 @@ int hpfg_bn_bwd_blocks(int N, int H, int W, int C);
 int hpfg_bn_bwd_reduce_pool(const HpfgAct* g /* DZ source at the un-pooled size */, const float* dP, int dp_pstride, int N, int Hp, int Wp,
                             float* partials /* [hpfg_bn_bwd_pool_blocks()][2][C] */, void* stream);
 int hpfg_bn_bwd_pool_blocks(int N, int Hp, int Wp, int C);
+/* param_grad_scale multiplies dgamma / dbeta only: with all-reduced `sums` (data parallel, R ranks) every rank holds the GLOBAL
+ * sums, so it writes global/R and the SUM all-reduce of the gradient buffer restores the global value; 1 otherwise */
 int hpfg_bn_bwd_finalize(const float* partials, int nblk, const double* sums, double count, const float* gamma,
-                         float* bn, float* dgamma, float* dbeta, int C, void* stream);
+                         float* bn, float* dgamma, float* dbeta, int C, float param_grad_scale, void* stream);
 int hpfg_wgrad(const HpfgWgradArgs* args, void* stream);
 int hpfg_slab_reduce_multi(const HpfgSlabDesc* table_dev, const HpfgSlabDesc* table_host, int nlayers, void* stream);
 int hpfg_wgrad_splits(int N, int H, int W, int CinPad, int CoutPad, int taps);
@@ -291,6 +293,26 @@ int hpfg_adamw_step(float* p, const float* g, float* m, float* v, long n, const 
                     float weight_decay, float grad_scale, void* stream);
 /* EMA teacher: t = alpha*t + (1-alpha)*s over flat buffers (utils/utils.py:82-86); alpha read from device */
 int hpfg_ema_update(float* t, const float* s, long n, const float* alpha_dev, void* stream);
+
+/* ---- projection necks + Dense_Loss (UNet_Plus; reference model/unet.py:120-152, utils/loss/dense_loss.py:17-40) ------------------------ */
+/* C[m,n] = act(sum_k A(m,k) B(k,n) + bias[n]) in exact fp32 on the matrix cores; A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn], C row-major
+ * (ldc); relu: max(.,0) in the epilogue; accumulate: C += (before the activation).  Replaces nn.Linear / 1x1 nn.Conv2d forward and both backward
+ * products of the necks (unet.py:125-138) and torch.mm of dense_loss.py:24.  Deterministic: no split-K, no atomics. */
+int hpfg_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N, int K,
+                  const float* bias, int relu, int accumulate, void* stream);
+int hpfg_col_sum(const float* x, long R, int M, long ldx, float* out /* [M] = sum over rows */, void* stream);   /* bias gradients */
+int hpfg_relu_bwd(float* dy, const float* y, long n, void* stream);                                         /* dy *= (y > 0): nn.ReLU backward */
+/* nn.AdaptiveAvgPool2d((1,1)) and ((S,S)) of an NHWC tensor in one launch (unet.py:141-142,146): gap [N,C], pool [N,S*S,C] */
+int hpfg_neck_pool_fwd(const float* x, int pstride, int N, int H, int W, int C, int S, float* gap, float* pool, void* stream);
+int hpfg_neck_pool_bwd(const float* dgap /* or NULL */, const float* dpool /* or NULL */, int N, int H, int W, int C, int S,
+                       float* dx /* NHWC contiguous, overwritten */, void* stream);
+/* F.normalize(x, dim=1) of x viewed as [G,D,S] with element (g,d,s) at g*D*S + d*sd + s*ss, (sd,ss) = (S,1) or (1,D) (dense_loss.py:18-19) */
+int hpfg_l2norm_fwd(const float* x, int G, int D, int S, int sd, int ss, float* u, float* norms /* [G*S] */, void* stream);
+int hpfg_l2norm_bwd(const float* du, const float* u, const float* norms, int G, int D, int S, int sd, int ss,
+                    const float* scale /* device scalar multiplied into dx, or NULL */, float* dx, void* stream);
+/* NT-Xent of dense_loss.py:24-36 from the Gram matrix [2n,2n] of the normalised rows [student ; teacher]: loss[0] = mean_i -log(pos_i / denom_i);
+ * Q (or NULL) [n,2n] = dL/dGram + its transpose for the student rows, so that dL/d(student row i) = sum_j Q[i,j] * row_j */
+int hpfg_ntxent_rows(const float* gram, int n, float temperature, float* loss, float* Q, void* stream);
 
 #ifdef __cplusplus
 }
