@@ -14,8 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _CHILD = r"""
 import sys, torch
 sys.path.insert(0, {root!r})
-from hpfg_amd.model import UNet
+from hpfg_amd.model import UNet, reset_dropout_streams
 torch.manual_seed(11)
+reset_dropout_streams()
 m = UNet(1, 4).cuda(); m.train(); m.math = "bf16x3"
 x = torch.randn(4, 1, 64, 64, device="cuda")
 out = m(x); out.square().mean().backward()
@@ -29,8 +30,9 @@ def test_ws_kernel_matches_default(tmp_path):
     r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT), path], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     ws = torch.load(path)
-    from hpfg_amd.model import UNet
+    from hpfg_amd.model import UNet, reset_dropout_streams
     torch.manual_seed(11)
+    reset_dropout_streams()          # the child's network is the first of its process: same dropout stream here
     m = UNet(1, 4).cuda()
     m.train()
     m.math = "bf16x3"
