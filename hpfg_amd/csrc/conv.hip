@@ -138,8 +138,8 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
   hipStream_t st = (hipStream_t)stream;
   if (a->bwd_stats) {
     const int kind = hpfg_kind_of(a->a0, a->a1);
-    HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && (kind == HPFG_KIND_DZ || kind == HPFG_KIND_PLAIN),
-                   "conv_fwd: bwd_stats is a dgrad feature of the bf16x3 kernels (DZ or PLAIN source)");
+    HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && (kind == HPFG_KIND_DZ || kind == HPFG_KIND_PLAIN || kind == HPFG_KIND_PLANES),
+                   "conv_fwd: bwd_stats is a dgrad feature of the bf16x3 kernels (DZ, PLAIN or PLANES source)");
     HPFG_ARG_CHECK(a->stat_partials && a->bwd_of.z && a->bwd_of.bn && !a->bias, "conv_fwd: bwd_stats needs stat_partials, bwd_of.z / .bn and no bias");
     HPFG_ARG_CHECK(a->bwd_of.C == a->Cout && a->Cout == a->CoutPad && a->bwd_of.Hs == a->H && a->bwd_of.Ws == a->W && a->bwd_of.pstride % 4 == 0,
                    "conv_fwd: bwd_of must describe a layer with C == Cout == CoutPad (%d/%d/%d) at the output size", a->bwd_of.C, a->Cout, a->CoutPad);
@@ -151,6 +151,9 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
       case HPFG_KIND_POOL: return hpfg_conv16_launch_pool(*a, st, rows_only);
       case HPFG_KIND_CAT: return hpfg_conv16_launch_cat(*a, st, rows_only);
       case HPFG_KIND_DZ: return hpfg_conv16_launch_dz(*a, st, rows_only);
+      case HPFG_KIND_PLANES:
+        HPFG_ARG_CHECK(a->a0.C % 8 == 0 && a->a0.pstride % 8 == 0, "conv_fwd: a PLANES source needs C %% 8 == 0 (got %d)", a->a0.C);
+        return hpfg_conv16_launch_planes(*a, st, rows_only);
       default: break;
     }
     hpfg_set_error("conv_fwd(bf16x3): unsupported source combination (a0.mode=%d, a1.mode=%d)", a->a0.mode, a->a1.mode);

@@ -62,11 +62,11 @@ __device__ __forceinline__ Piece make_piece(int tid, int i) {
   return q;
 }
 
-template <class C>
+template <class C, int KIND = HPFG_KIND_PLAIN>
 __device__ __forceinline__ void store_piece(unsigned char* buf, const Piece& q, const f32x4& v0, const f32x4& v1) {
   if (!q.ok) return;
   bf16x8 hi, lo;
-  split8(v0, v1, hi, lo);
+  split_piece<KIND>(v0, v1, hi, lo);
   *reinterpret_cast<bf16x8*>(buf + q.lds) = hi;
   *reinterpret_cast<bf16x8*>(buf + q.lds + C::PLANE) = lo;
 }
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
       const int gyc = clampi(gy, 0, H - 1), gxc = clampi(gx, 0, W - 1), c0c = chv ? c0 : 0;
       issue_piece<KIND>(raw, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
       finish_piece<KIND>(v0, v1, raw, tab, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
-      store_piece<C>(lds, pc[i], v0, v1);
+      store_piece<C, KIND>(lds, pc[i], v0, v1);
     }
   }
   // B-fragment ring: the fragments of k-step g + BD are requested while k-step g computes (BD = ring size - 1 k-steps of latency
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
               const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
               f32x4 v0, v1;       // also on the last item (more == false): the parked piece lands in the unused buffer, no branch
               finish_piece<SK>(v0, v1, raw[i & 1], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
-              store_piece<C>(nxt, pc[i], v0, v1);
+              store_piece<C, SK>(nxt, pc[i], v0, v1);
             }
             if (s < C::NLD) {
               const int i = s < C::NLD ? s : 0;
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
           const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
           f32x4 v0, v1;
           finish_piece<SK>(v0, v1, raw[DEEP ? i : 0], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
-          store_piece<C>(nxt, pc[i], v0, v1);
+          store_piece<C, SK>(nxt, pc[i], v0, v1);
         }
       }
       HPFG_TR(7)
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int
       const int gyc = clampi(gy, 0, H - 1), gxc = clampi(gx, 0, W - 1), c0c = chv ? c0 : 0;
       issue_piece<KIND>(raw, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
       finish_piece<KIND>(v0, v1, raw, tab, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
-      store_piece<C>(lds, q, v0, v1);
+      store_piece<C, KIND>(lds, q, v0, v1);
     }
     bf16x8 bh[C::NI], bl[C::NI];
     load_b<C>(bh, bl, wpk, ch, ntn, nt0, lane);
@@ -684,7 +684,7 @@ int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
       return hpfg_launch_status("conv_ws_kernel");
     }
     dim3 grid((unsigned)persistent_grid<C, KIND>(a), a.CoutPad / C::BN);
-    if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLAIN) {
+    if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLAIN || KIND == HPFG_KIND_PLANES) {
       if (a.bwd_stats) {
         hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND, true>), grid, dim3(256), 0, st, a, tx, ty);
         return hpfg_launch_status("conv_bf16x3_kernel<bwd stats>");
@@ -746,3 +746,4 @@ int hpfg_conv16_launch_bnact(const HpfgConvArgs& a, hipStream_t st, int* rows_on
 int hpfg_conv16_launch_pool(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
 int hpfg_conv16_launch_cat(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
 int hpfg_conv16_launch_dz(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
+int hpfg_conv16_launch_planes(const HpfgConvArgs& a, hipStream_t st, int* rows_only);

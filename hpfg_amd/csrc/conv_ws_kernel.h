@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(HpfgConvArgs p, int til
       const bool ok = pc[i].ok && mv[SLOT] && gy >= 0 && gy < H && gx >= 0 && gx < W;                            \
       f32x4 v0, v1;                                                                                              \
       finish_piece<KIND>(v0, v1, raw[SLOT][i], tab, p.a0, p.a1, cx0, mn[SLOT], clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), mc[SLOT], ok); \
-      store_piece<C>(lds + (BUF) * C::BUF_BYTES, pc[i], v0, v1);                                                 \
+      store_piece<C, KIND>(lds + (BUF) * C::BUF_BYTES, pc[i], v0, v1);                                                 \
     }                                                                                                            \
   }
     // advance `it` by one position; past the end it parks on the last position (reloads of valid addresses, results unused)

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
         finish_piece<SA>(v0, v1, rawA[PREA ? i : 0], ta, p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);
         if (pa[i].real) {
           bf16x8 hi, lo;
-          split8(v0, v1, hi, lo);
+          split_piece<SA>(v0, v1, hi, lo);
           *reinterpret_cast<bf16x8*>(ldsA + pa[i].lds) = hi;
           *reinterpret_cast<bf16x8*>(ldsA + pa[i].lds + A_PLANE) = lo;
         }
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
           finish_piece<GK>(v0, v1, rawG[i], tg, p.g, none, cxg, n, gyc, gxc, cgc, ok);
           if (pg[b * GB + i].real) {
             bf16x8 hi, lo;
-            split8(v0, v1, hi, lo);
+            split_piece<GK>(v0, v1, hi, lo);
             *reinterpret_cast<bf16x8*>(ldsG + pg[b * GB + i].lds) = hi;
             *reinterpret_cast<bf16x8*>(ldsG + pg[b * GB + i].lds + G_PLANE) = lo;
           }
@@ -428,4 +428,5 @@ int launch_wgrad16(const HpfgWgradArgs& a, hipStream_t st) {
 
 int hpfg_wgrad16_launch_dz(const HpfgWgradArgs& a, int akind, hipStream_t st);
 int hpfg_wgrad16_launch_plain(const HpfgWgradArgs& a, int akind, hipStream_t st);
+int hpfg_wgrad16_launch_planes(const HpfgWgradArgs& a, int akind, hipStream_t st);   // dZ as a PLANES source (A: PLANES too)
 int hpfg_wgrad16_launch_1x1(const HpfgWgradArgs& a, int akind, hipStream_t st);   // 1x1 convs: dZ is a plain gradient tensor

@@ -122,6 +122,13 @@ class UNetEngine:
         self.math = L.MATH_F32      # L.MATH_BF16X3 selects the split-bf16 matrix-core kernels for conv forward / dgrad
         self.ext_masks: Dict[str, torch.Tensor] = {}   # conv name -> uint8 NHWC keep-mask (parity tests replaying torch's masks)
         self.allreduce = None    # callable(tensor) -> in-place sum across ranks (data parallel), set by hpfg_amd.parallel
+        # Channel-rich layers (>= 64 channels in and out, <= 56x56): in the split-bf16 math mode their input activation (and, in backward,
+        # dZ) is MATERIALISED once in split-bf16 form (hpfg_act_to_planes -> HPFG_ACT_PLANES) and the conv / dgrad / wgrad kernels stage
+        # it with no arithmetic.  On-load fusion stays where it is free: the thin 224x224 / 112x112 layers are byte-bound and stage each
+        # tile once, these layers re-stage every tile once per output-channel slice (wgrad: Cout/32 + Cin/32 times).
+        self.use_planes = os.environ.get("HPFG_PLANES", "1") == "1"
+        self.planes: Dict[str, torch.Tensor] = {}
+        self.dz_planes: Optional[torch.Tensor] = None
         self.probe = None        # bench.py: (conv name, [(event, event), ...]) -- HIP events around that layer's forward launch (eager steps only)
 
     # ---------------------------------------------------------------------------------------------------------
@@ -165,6 +172,41 @@ class UNetEngine:
             a.drop_p, a.drop_seed, a.seed_dev = s.drop_p, self.layer_seed(s), L.ptr(self.seed_dev)
             a.drop_mask = L.ptr(self.ext_masks.get(name)) if self.ext_masks else None
         return a
+
+    def is_deep(self, s: ConvSpec) -> bool:
+        return (self.use_planes and self.math == L.MATH_BF16X3 and not self.wgrad_overlap and s.taps == 9 and s.cin >= 64 and s.cout >= 64
+                and s.h <= 56 and s.w <= 56 and s.cin % 8 == 0 and s.cout % 8 == 0)
+
+    def _act_planes(self, t: torch.Tensor, C_: int, h: int, w: int) -> L.Act:
+        a = L.Act()
+        a.z, a.mode, a.C, a.Hs, a.Ws, a.pstride = L.ptr(t), L.ACT_PLANES, C_, h, w, C_
+        return a
+
+    def _to_planes(self, a0: L.Act, a1: Optional[L.Act], s: ConvSpec, C_: int, out: torch.Tensor) -> L.Act:
+        L.check(self.lib.hpfg_act_to_planes(C.byref(a0), C.byref(a1) if a1 is not None else None, self.N, s.h, s.w, L.ptr(out), self._stream()),
+                f"act_to_planes[{s.name}]")
+        return self._act_planes(out, C_, s.h, s.w)
+
+    def staged_inputs(self, s: ConvSpec, fresh: bool):
+        """(a0, a1) the conv / wgrad kernels of layer s read: the on-load description, or for a channel-rich layer its materialised
+        split-bf16 planes (written when `fresh`, i.e. by the forward pass; backward re-uses them for the weight gradient)."""
+        if not self.is_deep(s):
+            return self.input_acts(s.name)
+        if s.name not in self.planes:
+            self.planes[s.name] = torch.empty(self.N, s.h, s.w, s.cin, dtype=torch.float32, device=self.dev)   # 4 B per channel: bf16 hi + bf16 lo
+        if fresh:
+            a0, a1 = self.input_acts(s.name)
+            self._to_planes(a0, a1, s, s.cin, self.planes[s.name])
+        return self._act_planes(self.planes[s.name], s.cin, s.h, s.w), L.Act()
+
+    def staged_dz(self, s: ConvSpec, g: L.Act) -> L.Act:
+        """dZ source of layer s for dgrad / wgrad: the DZ description, or for a channel-rich layer dZ materialised once as planes."""
+        if not self.is_deep(s):
+            return g
+        if self.dz_planes is None:
+            need = max(self.N * t.h * t.w * t.cout for t in self.order if self.is_deep(t))
+            self.dz_planes = torch.empty(need, dtype=torch.float32, device=self.dev)
+        return self._to_planes(g, None, s, s.cout, self.dz_planes)
 
     def input_acts(self, name: str):
         """(a0, a1) virtual input of conv `name` (forward view)."""
@@ -243,7 +285,7 @@ class UNetEngine:
         self.pack(with_dgrad=bool(train and needs_grad))
         logits = torch.empty(self.N, self.H, self.W, self.ncls, dtype=torch.float32, device=self.dev)
         for s in self.order:
-            a0, a1 = self.input_acts(s.name)
+            a0, a1 = self.staged_inputs(s, fresh=True)
             out = logits if s.name == "decoder.out_conv" else self.z[s.name]
             want_stats = bool(s.bn) and train
             nblk = self.lib.hpfg_conv_stat_blocks(self.N, s.h, s.w)
@@ -383,6 +425,7 @@ class UNetEngine:
 
     def _wgrad_dgrad(self, s: ConvSpec, g: L.Act, dgrad_out: torch.Tensor, stats_for: Optional[str] = None):
         """Both gradients of layer s from the same dZ source (they only read it, so their order is free)."""
+        g = self.staged_dz(s, g)
         if self.wgrad_overlap == 2:
             self._dgrad(s, g, dgrad_out, stats_for)
             self._wgrad(s, g)
@@ -403,7 +446,7 @@ class UNetEngine:
         else:
             stream = main.cuda_stream
         wa = L.WgradArgs()
-        wa.a0, wa.a1 = self.input_acts(s.name)
+        wa.a0, wa.a1 = self.staged_inputs(s, fresh=False)
         wa.g = g
         wa.slab, wa.dw_oihw, wa.defer_reduce = L.ptr(self.slab_of[s.name]), L.ptr(self.grads[f"{s.name}.weight"]), 1
         wa.Cin, wa.CinPad, wa.Cout, wa.CoutPad = s.cin, s.cin_pad, s.cout, s.cout_pad

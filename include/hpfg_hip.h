@@ -37,7 +37,12 @@ enum {
   HPFG_ACT_BNACT = 3,      /* v = drop(lrelu(z*scale+shift))       unet.py:19-21,23-24 (BN train, LeakyReLU .01, Dropout) */
   HPFG_ACT_BNACT_POOL = 4, /* v = max 2x2 of lrelu(z*scale+shift)  unet.py:37 (MaxPool2d(2)) fused on load   */
   HPFG_ACT_UP2X = 5,       /* v = bilinear x2, align_corners=True  unet.py:51,56 fused on load               */
-  HPFG_ACT_DZ = 6          /* v = k1*g + k2*z + k3, g = aux*dropmask*lrelu'(z*scale+shift): BN/LeakyReLU/Dropout backward */
+  HPFG_ACT_DZ = 6,         /* v = k1*g + k2*z + k3, g = aux*dropmask*lrelu'(z*scale+shift): BN/LeakyReLU/Dropout backward */
+  HPFG_ACT_PLANES = 7      /* a MATERIALISED activation in split-bf16 form (hpfg_act_to_planes): per pixel and group of 8 channels
+                              32 bytes = 8 x bf16 hi, 8 x bf16 lo (x = hi + lo); z points at it, pstride = C (4-byte units), C % 8 == 0.
+                              Consumed by the bf16x3 conv / dgrad / wgrad kernels with no arithmetic in their loaders: the channel-rich
+                              layers re-stage every input tile once per output-channel slice, so the producer chain + split is done
+                              ONCE by a streaming pass instead (bf16x3 math mode only) */
 };
 
 typedef struct HpfgAct {
@@ -135,6 +140,9 @@ int hpfg_pack_weights(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_h
 /* evaluate a virtual activation into memory (tests, projection-neck inputs): out [N,H,W,a0.C+a1.C] */
 int hpfg_act_materialize(const HpfgAct* a0, const HpfgAct* a1, int N, int H, int W, float* out, void* stream);
 /* the dropout keep-mask the loaders use, as bytes [n_elems] (tests feed it to the oracle) */
+/* planes[n,y,x, C/8 groups][hi 8 x bf16 | lo 8 x bf16] = split-bf16 form of the virtual activation [a0 | a1] (any source kinds, incl. the
+ * max-pooled, concatenated + upsampled and DZ ones); C_total % 8 == 0.  See HPFG_ACT_PLANES. */
+int hpfg_act_to_planes(const HpfgAct* a0, const HpfgAct* a1 /* or NULL */, int N, int H, int W, void* planes, void* stream);
 int hpfg_dropout_mask(uint8_t* out, long n_elems, float p, uint32_t seed, const uint32_t* seed_dev, void* stream);
 
 /* ---- backward ------------------------------------------------------------------------------------------ */
