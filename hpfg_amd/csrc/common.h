@@ -178,7 +178,7 @@ __device__ static inline f32x4 act_load4(const HpfgAct& s, const ActCtx& cx, int
         float gg = (km >> j) & 1u ? g[j] * cx.inv_keep : 0.f;
         float yv = z[j] * sc[j] + sh[j];
         gg = yv > 0.f ? gg : HPFG_LEAKY * gg;
-        v[j] = k1[j] * gg + k2[j] * z[j] + k3[j];
+        v[j] = k1[j] * gg + (k2[j] * z[j] + k3[j]);      // same association as the staged loaders (stage.h finish_piece)
       }
       break;
     }

@@ -359,6 +359,7 @@ inline int ws_mask() {
 }
 template <class C, int KIND>
 inline bool ws_enabled() {
+  if (KIND == HPFG_KIND_PLANES) return false;      // the experiment predates the PLANES source (its loader waves keep BatchNorm tables in LDS)
   const int cls = C::KC == 32 ? 1 : (RawCount<KIND>::N <= 2 ? 2 : (RawCount<KIND>::N == 4 ? 4 : 8));
   return (ws_mask() & cls) != 0;
 }

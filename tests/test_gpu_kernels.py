@@ -306,10 +306,11 @@ def test_planes_source_equals_the_on_load_chain(N, H, W, cin, cout, p):
     dp, keep_d = _planes(d, None, N, H, W, cout)
     dx_ref, _ = layer.conv(d, None, N, H, W, dgrad=True, math=L.MATH_BF16X3)
     dx, _ = layer.conv(dp, None, N, H, W, dgrad=True, math=L.MATH_BF16X3)
-    assert torch.equal(dx, dx_ref)
+    # (the two dZ evaluations may contract their multiply-adds differently: equal to an fp32 rounding of dZ, not bit for bit)
+    assert maxerr(dx.cpu(), dx_ref.cpu()) < 2e-6 * max(1.0, float(dx_ref.abs().max()))
     dw_ref = layer.wgrad(a, None, d, N, H, W, math=L.MATH_BF16X3)
     dw = layer.wgrad(ap, None, dp, N, H, W, math=L.MATH_BF16X3)
-    assert torch.equal(dw, dw_ref)
+    assert maxerr(dw.cpu(), dw_ref.cpu()) < 2e-6 * max(1.0, float(dw_ref.abs().max()))
 
 
 def test_planes_from_pooled_and_concatenated_sources():
@@ -322,7 +323,8 @@ def test_planes_from_pooled_and_concatenated_sources():
     a.z, a.bn, a.mode, a.C, a.Hs, a.Ws, a.pstride, a.bn_stride = L.ptr(zd), L.ptr(tabd), L.ACT_BNACT_POOL, C_, 2 * H, 2 * W, C_, C_
     layer = AdHocConv(C_, 64, 9, DEV, seed=1, hw=(H, W))
     ref, _ = layer.conv(a, None, N, H, W, math=L.MATH_BF16X3)
-    got, _ = layer.conv(_planes(a, None, N, H, W, C_)[0], None, N, H, W, math=L.MATH_BF16X3)
+    pa, keep0 = _planes(a, None, N, H, W, C_)
+    got, _ = layer.conv(pa, None, N, H, W, math=L.MATH_BF16X3)
     assert torch.equal(got, ref)
     sk = torch.randn(N, H, W, C_, generator=g).to(DEV)
     ud = torch.randn(N, H // 2, W // 2, C_, generator=g).to(DEV)
