@@ -133,3 +133,184 @@ extern "C" int hpfg_relu_bwd(float* dy, const float* y, long n, void* stream) {
   hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, y, n);
   return hpfg_launch_status("relu_bwd_kernel");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") GEMM for the token-layout layers of the SegFormer branch (reference model/segformer.py: every nn.Linear, the
+// kernel == stride spatial-reduction conv, the patch embeddings after im2col, the head's 1x1 convs): fp32 operands are split as
+// x = hi + lo (bf16 each) while they are staged into LDS and every product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32
+// accumulation -- the arithmetic of conv_bf16_kernel.h, ~2^-17 relative per product at a sixth of the fp32-MFMA cycles.
+// Same contract as hpfg_gemm_f32 (explicit element strides, so Y = X W^T + b, dX = dY W and dW = dY^T X are one kernel), plus the
+// requirement that each operand has a unit stride along m/n or k and 4-element alignment (checked by the host wrapper, which falls back
+// to hpfg_gemm_f32 otherwise).
+//   Workgroup = 256 threads, 128 x 128 output tile (wave w: rows (w & 1) * 64.., cols (w >> 1) * 64..: 4 x 4 MFMA tiles), K chunks of 32.
+//   LDS image per operand: [128 rows][32 k] bf16, hi and lo planes, row stride 80 B (16 rows of a fragment read start on distinct banks).
+//   The MFMA is issued as D = B-fragment x A-fragment, so a lane ends up with 4 consecutive n of one m: 16-byte stores.
+//   Global loads of chunk c+1 are in flight (registers) while chunk c multiplies.
+namespace {
+
+typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 g_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 g_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float g_f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 128, BK = 32, ROWB = 80;               // bytes per LDS row (64 B of bf16 + 16 B pad)
+constexpr int PLANE_B = BM * ROWB;                        // one hi or lo plane of one operand
+
+__device__ __forceinline__ void split4(const f32x4& v, g_bf16x4& hi, g_bf16x4& lo) {
+  const g_bf16x2 h0 = __builtin_convertvector(g_f32x2{v[0], v[1]}, g_bf16x2), h1 = __builtin_convertvector(g_f32x2{v[2], v[3]}, g_bf16x2);
+  const uint32_t w0 = __builtin_bit_cast(uint32_t, h0), w1 = __builtin_bit_cast(uint32_t, h1);
+  const g_f32x2 f0 = {__builtin_bit_cast(float, w0 << 16), __builtin_bit_cast(float, w0 & 0xFFFF0000u)};
+  const g_f32x2 f1 = {__builtin_bit_cast(float, w1 << 16), __builtin_bit_cast(float, w1 & 0xFFFF0000u)};
+  const g_bf16x2 l0 = __builtin_convertvector(g_f32x2{v[0], v[1]} - f0, g_bf16x2), l1 = __builtin_convertvector(g_f32x2{v[2], v[3]} - f1, g_bf16x2);
+  hi = g_bf16x4{h0[0], h0[1], h1[0], h1[1]};
+  lo = g_bf16x4{l0[0], l0[1], l1[0], l1[1]};
+}
+
+// One operand tile: `rows` index m (or n), element (row, k) at base[row * srow + k * sk]; exactly one of srow / sk is 1.
+struct OpTile {
+  const float* base;
+  long srow, sk;
+  int nrows, K;
+};
+
+// global -> registers: 4 float4 per thread.  k-fast: thread owns k quad (t & 7) of rows (t >> 3) + 32 i; row-fast: row quad (t & 31) at
+// k = (t >> 5) + 8 i.  Out-of-range quads read as zero (nrows and K are multiples of 4 where the quad runs along them).
+__device__ __forceinline__ void tile_load(const OpTile& o, int row0, int k0, int tid, f32x4 (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (o.sk == 1) {
+      const int row = row0 + (tid >> 3) + 32 * i, k = k0 + 4 * (tid & 7);
+      if (row < o.nrows && k < o.K) r[i] = *reinterpret_cast<const f32x4*>(o.base + (long)row * o.srow + k);
+    } else {
+      const int row = row0 + 4 * (tid & 31), k = k0 + (tid >> 5) + 8 * i;
+      if (row < o.nrows && k < o.K) r[i] = *reinterpret_cast<const f32x4*>(o.base + (long)k * o.sk + row);
+    }
+  }
+}
+
+__device__ __forceinline__ void tile_store(const OpTile& o, unsigned char* lds, int tid, const f32x4 (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    g_bf16x4 hi, lo;
+    split4(r[i], hi, lo);
+    if (o.sk == 1) {
+      unsigned char* p = lds + ((tid >> 3) + 32 * i) * ROWB + 8 * (tid & 7);
+      *reinterpret_cast<g_bf16x4*>(p) = hi;
+      *reinterpret_cast<g_bf16x4*>(p + PLANE_B) = lo;
+    } else {
+      unsigned char* p = lds + (4 * (tid & 31)) * ROWB + 2 * ((tid >> 5) + 8 * i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<__bf16*>(p + j * ROWB) = hi[j];
+        *reinterpret_cast<__bf16*>(p + j * ROWB + PLANE_B) = lo[j];
+      }
+    }
+  }
+}
+
+struct Gemm16Args {
+  OpTile a, b;            // a: rows = m, b: rows = n
+  float* C;
+  const float* bias;
+  long ldc;
+  int M, N, K, relu, accumulate;
+};
+
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(Gemm16Args p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * PLANE_B];      // A hi | A lo | B hi | B lo
+  unsigned char* ldsA = lds;
+  unsigned char* ldsB = lds + 2 * PLANE_B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BM;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 ra[4], rb[4];
+  tile_load(p.a, m0, 0, tid, ra);
+  tile_load(p.b, n0, 0, tid, rb);
+  const int frag = (lane & 15) * ROWB + (lane >> 4) * 16;      // this lane's row and k group inside a 16-row fragment
+  for (int k0 = 0; k0 < p.K; k0 += BK) {
+    __syncthreads();            // the previous chunk's fragment reads are done
+    tile_store(p.a, ldsA, tid, ra);
+    tile_store(p.b, ldsB, tid, rb);
+    __syncthreads();
+    if (k0 + BK < p.K) {        // next chunk's global loads fly across the MFMA phase
+      tile_load(p.a, m0, k0 + BK, tid, ra);
+      tile_load(p.b, n0, k0 + BK, tid, rb);
+    }
+    g_bf16x8 bh[4], bl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bh[j] = *reinterpret_cast<const g_bf16x8*>(ldsB + (wn + 16 * j) * ROWB + frag);
+      bl[j] = *reinterpret_cast<const g_bf16x8*>(ldsB + (wn + 16 * j) * ROWB + frag + PLANE_B);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const g_bf16x8 ah = *reinterpret_cast<const g_bf16x8*>(ldsA + (wm + 16 * i) * ROWB + frag);
+      const g_bf16x8 al = *reinterpret_cast<const g_bf16x8*>(ldsA + (wm + 16 * i) * ROWB + frag + PLANE_B);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  // D[n = (lane >> 4) * 4 + r][m = lane & 15]
+  const bool vec = (p.N & 3) == 0 && (p.ldc & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gm = m0 + wm + 16 * i + (lane & 15);
+    if (gm >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gn = n0 + wn + 16 * j + (lane >> 4) * 4;
+      if (gn >= p.N) continue;
+      f32x4 v = acc[i][j];
+      float* c = p.C + (long)gm * p.ldc + gn;
+      if (vec) {
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + gn);
+        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(c);
+        if (p.relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+        *reinterpret_cast<f32x4*>(c) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (gn + r >= p.N) break;
+          float t = v[r] + (p.bias ? p.bias[gn + r] : 0.f);
+          if (p.accumulate) t += c[r];
+          if (p.relu) t = fmaxf(t, 0.f);
+          c[r] = t;
+        }
+      }
+    }
+  }
+}
+
+inline bool op_ok(const float* base, long srow, long sk, int nrows, int K) {
+  if (((uintptr_t)base & 15) != 0) return false;
+  if (sk == 1) return (K & 3) == 0 && (srow & 3) == 0;
+  if (srow == 1) return (nrows & 3) == 0 && (sk & 3) == 0;
+  return false;
+}
+
+}  // namespace
+
+// 1 if hpfg_gemm_bf16x3 accepts these operands (unit stride along one index of each, 4-element alignment), else 0
+extern "C" int hpfg_gemm_bf16x3_ok(const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M, int N, int K) {
+  return op_ok(A, sam, sak, M, K) && op_ok(B, sbn, sbk, N, K) ? 1 : 0;
+}
+
+extern "C" int hpfg_gemm_bf16x3(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* Cm, long ldc, int M, int N, int K,
+                                const float* bias, int relu, int accumulate, void* stream) {
+  HPFG_ARG_CHECK(A && B && Cm && M > 0 && N > 0 && K > 0 && ldc >= N, "gemm_bf16x3: bad args (M=%d N=%d K=%d ldc=%ld)", M, N, K, ldc);
+  HPFG_ARG_CHECK(hpfg_gemm_bf16x3_ok(A, sam, sak, B, sbk, sbn, M, N, K), "gemm_bf16x3: operands need a unit stride and 4-element alignment");
+  Gemm16Args p{{A, sam, sak, M, K}, {B, sbn, sbk, N, K}, Cm, bias, ldc, M, N, K, relu, accumulate};
+  dim3 grid((N + BM - 1) / BM, (M + BM - 1) / BM);
+  hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  return hpfg_launch_status("gemm_bf16x3_kernel");
+}

@@ -200,45 +200,75 @@ def bn_relu_dropout(x, gamma, beta, mask=None, keep: float = 0.9, eps: float = 1
 TALL_ROWS = 8192          # from this many tokens on, the weight gradient of a Linear runs on the row-split HIP kernel
 
 
-class _LinearTall(torch.autograd.Function):
-    """y = x W^T + b over tokens x [.., K]: forward and dX are library GEMMs, dW (tall-skinny: rows >> N, K) and db are HIP."""
+def _gemm(a, sam, sak, b, sbk, sbn, m, n, k, bias=None, math="bf16x3"):
+    """out[m,n] = sum_k a(m,k) b(k,n) + bias[n] on the HIP library: split-bf16 MFMA when the operands allow it (unit stride along one
+    index, 4-element alignment) and `math` asks for it, exact-fp32 MFMA otherwise (include/hpfg_hip.h: hpfg_gemm_bf16x3 / hpfg_gemm_f32)."""
+    lib = L.load()
+    out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    if math == "bf16x3" and lib.hpfg_gemm_bf16x3_ok(L.ptr(a), sam, sak, L.ptr(b), sbk, sbn, m, n, k):
+        L.check(lib.hpfg_gemm_bf16x3(L.ptr(a), sam, sak, L.ptr(b), sbk, sbn, L.ptr(out), n, m, n, k, L.ptr(bias), 0, 0, _st(a)), "gemm_bf16x3")
+    else:
+        L.check(lib.hpfg_gemm_f32(L.ptr(a), sam, sak, L.ptr(b), sbk, sbn, L.ptr(out), n, m, n, k, L.ptr(bias), 0, 0, _st(a)), "gemm_f32")
+    return out
+
+
+MATH = {"mode": None}
+
+
+def gemm_math() -> str:
+    """Arithmetic of the token GEMMs: HPFG_MATH (default bf16x3), like the U-Net convolutions."""
+    import os
+    return MATH["mode"] or os.environ.get("HPFG_MATH", "bf16x3")
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b over tokens x [.., K] -- nn.Linear, the kernel == stride spatial-reduction conv, the patch embeddings after im2col and
+    the head's 1x1 convs of reference model/segformer.py -- entirely on the HIP library: forward and dX on hpfg_gemm_bf16x3 (or the exact
+    fp32 GEMM), dW on the row-split deterministic kernel when there are many tokens (tall-skinny dY^T X) and on the GEMM otherwise, db as
+    a column sum."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        _need_gpu(x, "linear")
+        N, K = weight.shape
+        xc = x.reshape(-1, K).contiguous().float()
+        w = weight.contiguous()
+        math = gemm_math()
+        y = _gemm(xc, K, 1, w, 1, K, xc.shape[0], N, K, bias, math)
+        ctx.save_for_backward(xc, w)
+        ctx.has_bias, ctx.math, ctx.xshape = bias is not None, math, x.shape
+        return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         lib = L.load()
-        x, w = ctx.saved_tensors
+        xc, w = ctx.saved_tensors
         N, K = w.shape
-        dyc = dy.reshape(-1, N).contiguous()
-        xc = x.reshape(-1, K).contiguous()
         R = xc.shape[0]
-        dx = torch.matmul(dyc, w).view_as(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(w)
-        part = torch.empty(lib.hpfg_linear_wgrad_splits(R, N, K) * N * K, dtype=torch.float32, device=w.device)
-        L.check(lib.hpfg_linear_wgrad(L.ptr(dyc), L.ptr(xc), L.ptr(dw), L.ptr(part), R, N, K, _st(w)), "linear_wgrad")
+        dyc = dy.reshape(-1, N).contiguous()
+        dx = _gemm(dyc, N, 1, w, K, 1, R, K, N, None, ctx.math).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        if R >= TALL_ROWS and N % 4 == 0 and K % 4 == 0:
+            dw = torch.empty_like(w)
+            part = torch.empty(lib.hpfg_linear_wgrad_splits(R, N, K) * N * K, dtype=torch.float32, device=w.device)
+            L.check(lib.hpfg_linear_wgrad(L.ptr(dyc), L.ptr(xc), L.ptr(dw), L.ptr(part), R, N, K, _st(w)), "linear_wgrad")
+        else:
+            dw = _gemm(dyc, 1, N, xc, K, 1, N, K, R, None, ctx.math)                   # dY^T X
         db = None
         if ctx.has_bias:
             if N % 4 == 0 and N <= 1024 and 256 % (N // 4) == 0:
                 p2 = torch.empty(lib.hpfg_tok_stat_blocks(R) * 2 * N, dtype=torch.float32, device=w.device)
                 sums = torch.empty(2, N, dtype=torch.float32, device=w.device)
                 L.check(lib.hpfg_tok_col_stats(L.ptr(dyc), R, N, L.ptr(p2), L.ptr(sums), _st(w)), "tok_col_stats")
-                db = sums[0].clone()
+                db = sums[0]
             else:
-                db = dyc.sum(0)
+                db = torch.empty(N, dtype=torch.float32, device=w.device)
+                L.check(lib.hpfg_col_sum(L.ptr(dyc), R, N, N, L.ptr(db), _st(w)), "col_sum")
         return dx, dw, db
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
-    """F.linear, with the weight / bias gradients on the HIP row-split kernels when there are many tokens."""
-    rows = x.numel() // x.shape[-1]
-    if x.is_cuda and rows >= TALL_ROWS and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0 and x.dtype == torch.float32:
-        return _LinearTall.apply(x, weight, bias)
-    return F.linear(x, weight, bias)
+    """F.linear on the HIP library (no rocBLAS call): see _Linear."""
+    return _Linear.apply(x, weight, bias)
 
 
 class _Im2col(torch.autograd.Function):

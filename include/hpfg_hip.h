@@ -308,6 +308,13 @@ int hpfg_ema_update(float* t, const float* s, long n, const float* alpha_dev, vo
  * products of the necks (unet.py:125-138) and torch.mm of dense_loss.py:24.  Deterministic: no split-K, no atomics. */
 int hpfg_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N, int K,
                   const float* bias, int relu, int accumulate, void* stream);
+/* the same contract in split-bf16 arithmetic (hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate; 128 x 128 tiles): every
+ * nn.Linear / kernel==stride conv / 1x1 conv of the SegFormer branch (reference model/segformer.py:92-177, 298-320), forward and input
+ * gradient, and the weight gradient of layers with few tokens.  Operands need a unit stride along one index and 4-element alignment:
+ * hpfg_gemm_bf16x3_ok() tells; callers fall back to hpfg_gemm_f32 otherwise. */
+int hpfg_gemm_bf16x3(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N, int K,
+                     const float* bias, int relu, int accumulate, void* stream);
+int hpfg_gemm_bf16x3_ok(const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M, int N, int K);
 int hpfg_col_sum(const float* x, long R, int M, long ldx, float* out /* [M] = sum over rows */, void* stream);   /* bias gradients */
 int hpfg_relu_bwd(float* dy, const float* y, long n, void* stream);                                         /* dy *= (y > 0): nn.ReLU backward */
 /* nn.AdaptiveAvgPool2d((1,1)) and ((S,S)) of an NHWC tensor in one launch (unet.py:141-142,146): gap [N,C], pool [N,S*S,C] */

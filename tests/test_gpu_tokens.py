@@ -149,3 +149,29 @@ def test_residual_scale():
         out.backward(d.to(DEV))
         assert maxerr(out.detach().cpu(), x + (y * sc if sc is not None else y)) < 1e-6
         assert maxerr(xd.grad.cpu(), xr.grad) < 1e-6 and maxerr(yd.grad.cpu(), yr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("R,N,K", [(1568, 256, 1024), (6272, 640, 160), (25088, 128, 64), (392, 160, 640), (100, 4, 256), (3136, 32, 49), (130, 36, 20)])
+@pytest.mark.parametrize("math", ["bf16x3", "f32"])
+def test_linear_on_the_hip_gemms(R, N, K, math):
+    """nn.Linear / 1x1 conv of the SegFormer branch on hpfg_gemm_bf16x3 (split-bf16 MFMA; all three products: X W^T + b, dY W, dY^T X)
+    and, where an operand is not 4-aligned (the 7x7x1 patch embedding: K = 49) or HPFG_MATH=f32, on the exact-fp32 MFMA GEMM."""
+    from hpfg_amd import ops_tokens
+    g = torch.Generator().manual_seed(R + N)
+    x, w, b = torch.randn(R, K, generator=g), torch.randn(N, K, generator=g) * 0.2, torch.randn(N, generator=g)
+    dy = torch.randn(R, N, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.linear(xr, wr, br)
+    yr.backward(dy.double())
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    ops_tokens.MATH["mode"] = math
+    try:
+        y = linear(xd, wd, bd)
+        y.backward(dy.to(DEV))
+    finally:
+        ops_tokens.MATH["mode"] = None
+    rel = 3e-5 if math == "bf16x3" else 2e-6              # per-product 2^-17 (split-bf16) / fp32 rounding, accumulated over K or R terms
+    assert maxerr(y.detach().cpu().double(), yr.detach()) < rel * K ** 0.5 * 3
+    assert maxerr(xd.grad.cpu().double(), xr.grad) < rel * N ** 0.5 * 3
+    assert maxerr(wd.grad.cpu().double(), wr.grad) < rel * R ** 0.5 * 4 * 3
+    assert maxerr(bd.grad.cpu().double(), br.grad) < 2e-6 * R ** 0.5 * 4 * 3

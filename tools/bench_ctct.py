@@ -31,6 +31,8 @@ for i in range(n):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / n * 1e3
 print(f"CTCT 8+24 x 224^2: {ms:.3f} ms/step = {32 / ms * 1e3:.0f} img/s")
+res = {"workload": "CTCT U-Net + SegFormer-B0 cross teaching (BASELINE configs[4]): 8 labelled + 24 unlabelled 224x224 per step, both networks forward + backward "
+                   "on all 32 images, FusedSGD + FusedAdamW", "math": m1.math, "eager_ms_per_step": round(ms, 3), "eager_images_per_s": round(32 / ms * 1e3, 1)}
 if os.environ.get("GRAPH", "1") == "1":
     from hpfg_amd.train import GraphedStep  # noqa: E402
     try:
@@ -44,5 +46,8 @@ if os.environ.get("GRAPH", "1") == "1":
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
         print(f"CTCT 8+24 x 224^2, hipGraph: {ms:.3f} ms/step = {32 / ms * 1e3:.0f} img/s")
+        res.update(hipgraph_ms_per_step=round(ms, 3), hipgraph_images_per_s=round(32 / ms * 1e3, 1))
     except Exception as e:
         print("hipGraph capture of the CTCT step failed:", type(e).__name__, str(e)[:300])
+import json  # noqa: E402
+print(json.dumps(res))
