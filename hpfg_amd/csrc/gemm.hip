@@ -314,3 +314,204 @@ extern "C" int hpfg_gemm_bf16x3(const float* A, long sam, long sak, const float*
   hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
   return hpfg_launch_status("gemm_bf16x3_kernel");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a token-layout layer on the matrix cores:  dW[n][k] = sum_r dY[r][n] * X[r][k]   (R tokens, N x K weights)
+// The contraction index r is the SLOW index of both operands.  They are staged exactly as they lie in memory ([r][n], [r][k]: coalesced
+// float4 loads, 8-byte LDS stores of the hi / lo bf16 quads) and gfx950's transposing LDS read ds_read_b64_tr_b16 hands every lane the
+// r-contiguous fragment v_mfma_f32_16x16x32_bf16 wants (same idiom as wgrad_bf16_kernel.h).  The rows are split over blockIdx.z; each
+// split writes a partial [N][K] matrix and gemm_rows_sum_kernel adds the partials in a fixed order (deterministic, no atomics).
+//   Workgroup = 256 threads, 64 (n) x 64 (k) output tile, 32 rows per step; wave w owns n-range (w & 1) * 32, k-range (w >> 1) * 32.
+namespace {
+
+typedef short g_s16x4 __attribute__((ext_vector_type(4)));
+typedef short g_s16x8 __attribute__((ext_vector_type(8)));
+constexpr int TR = 32, TT = 64, TRS = 144;            // rows per step, tile edge, LDS row stride in bytes (128 B of bf16 + 16 B: conflict-free tr reads)
+constexpr int TPLANE = TR * TRS;
+
+__device__ __forceinline__ g_bf16x8 tn_frag(const unsigned char* p) {      // p: this lane's address in the first 4-row block; the second is 4 rows below
+  const g_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((g_s16x4 __attribute__((address_space(3)))*)(p));
+  const g_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((g_s16x4 __attribute__((address_space(3)))*)(p + 4 * TRS));
+  return __builtin_bit_cast(g_bf16x8, (g_s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}));
+}
+
+// rows [r0, r0 + 32) x columns [c0, c0 + 64) of M ([R][C], leading dimension ld) -> hi / lo planes [32][64] bf16 (row stride TRS)
+template <bool ALIGNED>
+__device__ __forceinline__ void tn_load(const float* __restrict__ Mx, long ld, long r0, long r1, int c0, int C, int tid, f32x4 (&v)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rr = (tid >> 4) + 16 * i, c = c0 + 4 * (tid & 15);
+    const long r = r0 + rr;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (r < r1 && c < C) {
+      const float* p = Mx + r * ld + c;
+      if (ALIGNED) {
+        v[i] = *reinterpret_cast<const f32x4*>(p);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < C) v[i][j] = p[j];
+      }
+    }
+  }
+}
+__device__ __forceinline__ void tn_store(unsigned char* lds, int tid, const f32x4 (&v)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    g_bf16x4 hi, lo;
+    split4(v[i], hi, lo);
+    unsigned char* p = lds + ((tid >> 4) + 16 * i) * TRS + 8 * (tid & 15);
+    *reinterpret_cast<g_bf16x4*>(p) = hi;
+    *reinterpret_cast<g_bf16x4*>(p + TPLANE) = lo;
+  }
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void gemm_tn_bf16x3_kernel(const float* __restrict__ dy, long ldy, const float* __restrict__ x, long ldx,
+                                                             float* __restrict__ part, long R, int N, int K, int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * TPLANE];      // dY hi | dY lo | X hi | X lo
+  unsigned char* ldsA = lds;
+  unsigned char* ldsB = lds + 2 * TPLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * TT, k0 = blockIdx.y * TT;
+  const int wn = (wave & 1) * 32, wk = (wave >> 1) * 32;
+  const long r0 = (long)blockIdx.z * rows_per_split, r1 = r0 + rows_per_split < R ? r0 + rows_per_split : R;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // transposed-read address of this lane: k-group g = lane >> 4 covers rows 8g .. 8g+7; lane 4q + p of the group addresses row 8g + q, columns 4p ..
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int fr = (8 * g + q) * TRS + 8 * pp;
+  f32x4 va[2], vb[2];
+  tn_load<ALIGNED>(dy, ldy, r0, r1, n0, N, tid, va);
+  tn_load<ALIGNED>(x, ldx, r0, r1, k0, K, tid, vb);
+  for (long rb = r0; rb < r1; rb += TR) {
+    __syncthreads();
+    tn_store(ldsA, tid, va);
+    tn_store(ldsB, tid, vb);
+    __syncthreads();
+    if (rb + TR < r1) {
+      tn_load<ALIGNED>(dy, ldy, rb + TR, r1, n0, N, tid, va);
+      tn_load<ALIGNED>(x, ldx, rb + TR, r1, k0, K, tid, vb);
+    }
+    g_bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ah[i] = tn_frag(ldsA + fr + (wn + 16 * i) * 2);
+      al[i] = tn_frag(ldsA + fr + (wn + 16 * i) * 2 + TPLANE);
+      bh[i] = tn_frag(ldsB + fr + (wk + 16 * i) * 2);
+      bl[i] = tn_frag(ldsB + fr + (wk + 16 * i) * 2 + TPLANE);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {      // D[row = k][col = n]: a lane ends up with 4 consecutive k of one n
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+      }
+  }
+  float* o = part + (long)blockIdx.z * N * K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = n0 + wn + 16 * i + (lane & 15);
+    if (n >= N) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wk + 16 * j + (lane >> 4) * 4;
+      if (ALIGNED) {
+        if (k < K) *reinterpret_cast<f32x4*>(o + (long)n * K + k) = acc[i][j];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (k + r < K) o[(long)n * K + k + r] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+// out[o] = sum_s part[s * n + o]: lane <-> output (coalesced), the four waves take every fourth partial, fixed combination order
+__global__ __launch_bounds__(256) void gemm_rows_sum_kernel(const float* __restrict__ part, int S, long n, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long o = (long)blockIdx.x * 64 + lane;
+  float a0 = 0.f, a1 = 0.f;
+  if (o < n) {
+    int s = wave;
+    for (; s + 4 < S; s += 8) {
+      a0 += part[(long)s * n + o];
+      a1 += part[(long)(s + 4) * n + o];
+    }
+    if (s < S) a0 += part[(long)s * n + o];
+  }
+  red[wave][lane] = a0 + a1;
+  __syncthreads();
+  if (wave == 0 && o < n) out[o] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// column sums, stage 1: grid (ceil(M / 64), S); a workgroup = 4 row lanes x 64 columns over its slice of the rows
+__global__ __launch_bounds__(256) void col_sum_part_kernel(const float* __restrict__ x, long R, int M, long ldx, int rows_per_split, float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const long r0 = (long)blockIdx.y * rows_per_split, r1 = r0 + rows_per_split < R ? r0 + rows_per_split : R;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < M) {
+    long r = r0 + wave;
+    for (; r + 4 < r1; r += 8) {
+      a0 += x[r * ldx + c];
+      a1 += x[(r + 4) * ldx + c];
+    }
+    if (r < r1) a0 += x[r * ldx + c];
+  }
+  red[wave][lane] = a0 + a1;
+  __syncthreads();
+  if (wave == 0 && c < M) part[(long)blockIdx.y * M + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+inline int tn_splits(long R, int N, int K) {
+  const long tiles = (long)((N + TT - 1) / TT) * ((K + TT - 1) / TT);
+  long s = 1024 / tiles;                       // ~4 workgroups per CU in total
+  const long by_rows = (R + 255) / 256;        // at least 256 rows per split
+  if (s > by_rows) s = by_rows;
+  return (int)(s < 1 ? 1 : (s > 512 ? 512 : s));
+}
+
+}  // namespace
+
+extern "C" int hpfg_gemm_tn_splits(long R, int N, int K) { return tn_splits(R, N, K); }
+
+/* dW[N][K] = dY^T X over R rows (dY [R][N], X [R][K], contiguous); partials: hpfg_gemm_tn_splits(R, N, K) * N * K floats of scratch */
+extern "C" int hpfg_gemm_tn_bf16x3(const float* dy, const float* x, float* dw, float* partials, long R, int N, int K, void* stream) {
+  HPFG_ARG_CHECK(dy && x && dw && partials && R > 0 && N > 0 && K > 0, "gemm_tn_bf16x3: bad args");
+  const int S = tn_splits(R, N, K);
+  int per = (int)((R + S - 1) / S);
+  per = (per + TR - 1) / TR * TR;
+  dim3 grid((N + TT - 1) / TT, (K + TT - 1) / TT, S);
+  const bool aligned = (N & 3) == 0 && (K & 3) == 0 && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)partials) & 15) == 0;
+  float* dst = S == 1 ? dw : partials;
+  if (aligned && (((uintptr_t)dw & 15) == 0)) hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, (long)N, x, (long)K, dst, R, N, K, per);
+  else hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, (long)N, x, (long)K, dst, R, N, K, per);
+  if (S > 1) {
+    const long NK = (long)N * K;
+    hipLaunchKernelGGL(gemm_rows_sum_kernel, dim3((unsigned)((NK + 63) / 64)), dim3(256), 0, (hipStream_t)stream, partials, S, NK, dw);
+  }
+  return hpfg_launch_status("gemm_tn_bf16x3_kernel");
+}
+
+extern "C" int hpfg_col_sum_splits(long R) {
+  const long s = (R + 511) / 512;
+  return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
+}
+
+/* out[c] = sum_r x[r][c] in two deterministic stages; scratch: hpfg_col_sum_splits(R) * M floats */
+extern "C" int hpfg_col_sum2(const float* x, long R, int M, long ldx, float* out, float* scratch, void* stream) {
+  HPFG_ARG_CHECK(x && out && scratch && R > 0 && M > 0 && ldx >= M, "col_sum2: bad args");
+  const int S = hpfg_col_sum_splits(R);
+  const int per = (int)((R + S - 1) / S);
+  hipLaunchKernelGGL(col_sum_part_kernel, dim3((M + 63) / 64, S), dim3(256), 0, (hipStream_t)stream, x, R, M, ldx, per, S == 1 ? out : scratch);
+  if (S > 1) hipLaunchKernelGGL(gemm_rows_sum_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, scratch, S, (long)M, out);
+  return hpfg_launch_status("col_sum_part_kernel");
+}

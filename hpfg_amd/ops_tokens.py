@@ -247,22 +247,21 @@ class _Linear(torch.autograd.Function):
         R = xc.shape[0]
         dyc = dy.reshape(-1, N).contiguous()
         dx = _gemm(dyc, N, 1, w, K, 1, R, K, N, None, ctx.math).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        if R >= TALL_ROWS and N % 4 == 0 and K % 4 == 0:
+        if ctx.math == "bf16x3":
+            dw = torch.empty_like(w)
+            part = torch.empty(lib.hpfg_gemm_tn_splits(R, N, K) * N * K, dtype=torch.float32, device=w.device)
+            L.check(lib.hpfg_gemm_tn_bf16x3(L.ptr(dyc), L.ptr(xc), L.ptr(dw), L.ptr(part), R, N, K, _st(w)), "gemm_tn_bf16x3")      # dY^T X on MFMA
+        elif R >= TALL_ROWS and N % 4 == 0 and K % 4 == 0:
             dw = torch.empty_like(w)
             part = torch.empty(lib.hpfg_linear_wgrad_splits(R, N, K) * N * K, dtype=torch.float32, device=w.device)
             L.check(lib.hpfg_linear_wgrad(L.ptr(dyc), L.ptr(xc), L.ptr(dw), L.ptr(part), R, N, K, _st(w)), "linear_wgrad")
         else:
-            dw = _gemm(dyc, 1, N, xc, K, 1, N, K, R, None, ctx.math)                   # dY^T X
+            dw = _gemm(dyc, 1, N, xc, K, 1, N, K, R, None, ctx.math)                   # dY^T X, exact fp32
         db = None
         if ctx.has_bias:
-            if N % 4 == 0 and N <= 1024 and 256 % (N // 4) == 0:
-                p2 = torch.empty(lib.hpfg_tok_stat_blocks(R) * 2 * N, dtype=torch.float32, device=w.device)
-                sums = torch.empty(2, N, dtype=torch.float32, device=w.device)
-                L.check(lib.hpfg_tok_col_stats(L.ptr(dyc), R, N, L.ptr(p2), L.ptr(sums), _st(w)), "tok_col_stats")
-                db = sums[0]
-            else:
-                db = torch.empty(N, dtype=torch.float32, device=w.device)
-                L.check(lib.hpfg_col_sum(L.ptr(dyc), R, N, N, L.ptr(db), _st(w)), "col_sum")
+            db = torch.empty(N, dtype=torch.float32, device=w.device)
+            scratch = torch.empty(lib.hpfg_col_sum_splits(R) * N, dtype=torch.float32, device=w.device)
+            L.check(lib.hpfg_col_sum2(L.ptr(dyc), R, N, N, L.ptr(db), L.ptr(scratch), _st(w)), "col_sum2")
         return dx, dw, db
 
 

@@ -315,7 +315,14 @@ int hpfg_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, 
 int hpfg_gemm_bf16x3(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N, int K,
                      const float* bias, int relu, int accumulate, void* stream);
 int hpfg_gemm_bf16x3_ok(const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M, int N, int K);
+/* weight gradient dW[N][K] = dY^T X over R tokens (dY [R][N], X [R][K] contiguous) in split-bf16 arithmetic: operands staged as they lie in
+ * memory, fragments through the transposing LDS read, rows split over workgroups, partials summed in a fixed order.
+ * partials: hpfg_gemm_tn_splits(R, N, K) * N * K floats of scratch.  (autograd's mm for the weight of nn.Linear, segformer.py) */
+int hpfg_gemm_tn_bf16x3(const float* dy, const float* x, float* dw, float* partials, long R, int N, int K, void* stream);
+int hpfg_gemm_tn_splits(long R, int N, int K);
 int hpfg_col_sum(const float* x, long R, int M, long ldx, float* out /* [M] = sum over rows */, void* stream);   /* bias gradients */
+int hpfg_col_sum2(const float* x, long R, int M, long ldx, float* out, float* scratch /* hpfg_col_sum_splits(R) * M floats */, void* stream);
+int hpfg_col_sum_splits(long R);
 int hpfg_relu_bwd(float* dy, const float* y, long n, void* stream);                                         /* dy *= (y > 0): nn.ReLU backward */
 /* nn.AdaptiveAvgPool2d((1,1)) and ((S,S)) of an NHWC tensor in one launch (unet.py:141-142,146): gap [N,C], pool [N,S*S,C] */
 int hpfg_neck_pool_fwd(const float* x, int pstride, int N, int H, int W, int C, int S, float* gap, float* pool, void* stream);
