@@ -146,6 +146,9 @@ PROTOTYPES = {
     "hpfg_sgd_step": (_i, [_p, _p, _p, _l, _p, _f, _f, _f, _p]),
     "hpfg_adamw_step": (_i, [_p, _p, _p, _p, _l, _p, _p, _f, _f, _f, _f, _f, _p]),
     "hpfg_ema_update": (_i, [_p, _p, _l, _p, _p]),
+    "hpfg_attn_mfma_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "hpfg_attn_mfma_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "hpfg_attn_mfma_blocks": (_i, [_i]),
     "hpfg_gemm_f32": (_i, [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _p, _i, _i, _p]),
     "hpfg_gemm_bf16x3": (_i, [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _p, _i, _i, _p]),
     "hpfg_gemm_bf16x3_ok": (_i, [_p, _l, _l, _p, _l, _l, _i, _i, _i]),

@@ -189,24 +189,30 @@ __device__ __forceinline__ void tile_load(const OpTile& o, int row0, int k0, int
   }
 }
 
+constexpr int TRS2 = 288;       // row-fast operands: LDS image [32 k][128 rows] bf16, k-row stride in bytes (256 B + 32 B: the 4 k rows of a transposing read sit 8 banks apart)
+
 __device__ __forceinline__ void tile_store(const OpTile& o, unsigned char* lds, int tid, const f32x4 (&r)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     g_bf16x4 hi, lo;
     split4(r[i], hi, lo);
-    if (o.sk == 1) {
-      unsigned char* p = lds + ((tid >> 3) + 32 * i) * ROWB + 8 * (tid & 7);
-      *reinterpret_cast<g_bf16x4*>(p) = hi;
-      *reinterpret_cast<g_bf16x4*>(p + PLANE_B) = lo;
-    } else {
-      unsigned char* p = lds + (4 * (tid & 31)) * ROWB + 2 * ((tid >> 5) + 8 * i);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<__bf16*>(p + j * ROWB) = hi[j];
-        *reinterpret_cast<__bf16*>(p + j * ROWB + PLANE_B) = lo[j];
-      }
-    }
+    // k-fast: [row][k] image, the fragment is a plain 16-byte read.  row-fast (the contraction index is the operand's slow index, e.g. W in
+    // dX = dY W): stored as it lies in memory, [k][row], and read through ds_read_b64_tr_b16 -- no scattered 2-byte stores.
+    unsigned char* p = o.sk == 1 ? lds + ((tid >> 3) + 32 * i) * ROWB + 8 * (tid & 7) : lds + ((tid >> 5) + 8 * i) * TRS2 + 8 * (tid & 31);
+    *reinterpret_cast<g_bf16x4*>(p) = hi;
+    *reinterpret_cast<g_bf16x4*>(p + PLANE_B) = lo;
   }
+}
+
+typedef short g2_s16x4 __attribute__((ext_vector_type(4)));
+typedef short g2_s16x8 __attribute__((ext_vector_type(8)));
+// fragment (16 rows starting at row0, this lane's 8 k values) of an operand image, either layout
+__device__ __forceinline__ g_bf16x8 op_frag(const unsigned char* plane, bool tr, int row0, int lane) {
+  if (!tr) return *reinterpret_cast<const g_bf16x8*>(plane + (row0 + (lane & 15)) * ROWB + (lane >> 4) * 16);
+  const unsigned char* p = plane + (8 * (lane >> 4) + ((lane & 15) >> 2)) * TRS2 + (row0 + 4 * (lane & 3)) * 2;
+  const g2_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((g2_s16x4 __attribute__((address_space(3)))*)(p));
+  const g2_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((g2_s16x4 __attribute__((address_space(3)))*)(p + 4 * TRS2));
+  return __builtin_bit_cast(g_bf16x8, (g2_s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}));
 }
 
 struct Gemm16Args {
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(Gemm16Args p) {
   f32x4 ra[4], rb[4];
   tile_load(p.a, m0, 0, tid, ra);
   tile_load(p.b, n0, 0, tid, rb);
-  const int frag = (lane & 15) * ROWB + (lane >> 4) * 16;      // this lane's row and k group inside a 16-row fragment
+  const bool atr = p.a.sk != 1, btr = p.b.sk != 1;          // workgroup-uniform
   for (int k0 = 0; k0 < p.K; k0 += BK) {
     __syncthreads();            // the previous chunk's fragment reads are done
     tile_store(p.a, ldsA, tid, ra);
@@ -245,13 +251,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(Gemm16Args p) {
     g_bf16x8 bh[4], bl[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      bh[j] = *reinterpret_cast<const g_bf16x8*>(ldsB + (wn + 16 * j) * ROWB + frag);
-      bl[j] = *reinterpret_cast<const g_bf16x8*>(ldsB + (wn + 16 * j) * ROWB + frag + PLANE_B);
+      bh[j] = op_frag(ldsB, btr, wn + 16 * j, lane);
+      bl[j] = op_frag(ldsB + PLANE_B, btr, wn + 16 * j, lane);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const g_bf16x8 ah = *reinterpret_cast<const g_bf16x8*>(ldsA + (wm + 16 * i) * ROWB + frag);
-      const g_bf16x8 al = *reinterpret_cast<const g_bf16x8*>(ldsA + (wm + 16 * i) * ROWB + frag + PLANE_B);
+      const g_bf16x8 ah = op_frag(ldsA, atr, wm + 16 * i, lane);
+      const g_bf16x8 al = op_frag(ldsA + PLANE_B, atr, wm + 16 * i, lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);

@@ -12,6 +12,15 @@ def _st(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+MATH = {"mode": None}
+
+
+def gemm_math() -> str:
+    """Arithmetic of the token GEMMs and the attention core: HPFG_MATH (default bf16x3), like the U-Net convolutions."""
+    import os
+    return MATH["mode"] or os.environ.get("HPFG_MATH", "bf16x3")
+
+
 def _need_gpu(t, what):
     if not t.is_cuda:
         raise RuntimeError(f"hpfg_amd.{what} runs on the HIP library only (no CPU fallback)")
@@ -54,6 +63,9 @@ def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torc
 
 
 class _Attention(torch.autograd.Function):
+    """softmax(scale q k^T) v on the matrix cores (csrc/attn.hip): split-bf16 MFMA products in the default math mode; HPFG_MATH=f32 keeps
+    the exact-fp32 one-thread-per-query kernels of csrc/tokens.hip (dK / dV then through the exact GEMM)."""
+
     @staticmethod
     def forward(ctx, q, kv, heads, scale):
         _need_gpu(q, "attention")
@@ -62,7 +74,11 @@ class _Attention(torch.autograd.Function):
         B, N, C_ = qc.shape
         M = kvc.shape[1]
         out = torch.empty_like(qc)
-        L.check(lib.hpfg_attn_fwd(L.ptr(qc), L.ptr(kvc), L.ptr(out), B, N, M, heads, scale, _st(q)), "attn_fwd")
+        ctx.math = gemm_math()
+        if ctx.math == "bf16x3":
+            L.check(lib.hpfg_attn_mfma_fwd(L.ptr(qc), L.ptr(kvc), L.ptr(out), B, N, M, heads, scale, _st(q)), "attn_mfma_fwd")
+        else:
+            L.check(lib.hpfg_attn_fwd(L.ptr(qc), L.ptr(kvc), L.ptr(out), B, N, M, heads, scale, _st(q)), "attn_fwd")
         ctx.save_for_backward(qc, kvc)
         ctx.heads, ctx.scale = heads, scale
         return out
@@ -76,10 +92,16 @@ class _Attention(torch.autograd.Function):
         d = C_ // h
         do = dout.contiguous()
         dq = torch.empty_like(q)
+        if ctx.math == "bf16x3":
+            dkv = torch.empty_like(kv)
+            scratch = torch.empty(B * h * lib.hpfg_attn_mfma_blocks(N) * 2 * 64 * 32, dtype=torch.float32, device=q.device)
+            L.check(lib.hpfg_attn_mfma_bwd(L.ptr(q), L.ptr(kv), L.ptr(do), L.ptr(dq), L.ptr(dkv), L.ptr(scratch), B, N, M, h, ctx.scale, _st(q)),
+                    "attn_mfma_bwd")
+            return dq, dkv, None, None
         P = torch.empty(B, h, N, M, dtype=torch.float32, device=q.device)
         dS = torch.empty_like(P)
         L.check(lib.hpfg_attn_bwd(L.ptr(q), L.ptr(kv), L.ptr(do), L.ptr(dq), L.ptr(P), L.ptr(dS), B, N, M, h, ctx.scale, _st(q)), "attn_bwd")
-        # dV = P^T dO, dK = scale * dS^T Q : plain batched GEMMs (library)
+        # dV = P^T dO, dK = scale * dS^T Q per (image, head)
         doh = do.view(B, N, h, d).permute(0, 2, 1, 3)
         qh = q.view(B, N, h, d).permute(0, 2, 1, 3)
         dv = torch.matmul(P.transpose(-1, -2), doh)                    # [B,h,M,d]
@@ -210,15 +232,6 @@ def _gemm(a, sam, sak, b, sbk, sbn, m, n, k, bias=None, math="bf16x3"):
     else:
         L.check(lib.hpfg_gemm_f32(L.ptr(a), sam, sak, L.ptr(b), sbk, sbn, L.ptr(out), n, m, n, k, L.ptr(bias), 0, 0, _st(a)), "gemm_f32")
     return out
-
-
-MATH = {"mode": None}
-
-
-def gemm_math() -> str:
-    """Arithmetic of the token GEMMs: HPFG_MATH (default bf16x3), like the U-Net convolutions."""
-    import os
-    return MATH["mode"] or os.environ.get("HPFG_MATH", "bf16x3")
 
 
 class _Linear(torch.autograd.Function):

@@ -302,6 +302,15 @@ int hpfg_adamw_step(float* p, const float* g, float* m, float* v, long n, const 
 /* EMA teacher: t = alpha*t + (1-alpha)*s over flat buffers (utils/utils.py:82-86); alpha read from device */
 int hpfg_ema_update(float* t, const float* s, long n, const float* alpha_dev, void* stream);
 
+/* ---- attention core on the matrix cores (SegFormer branch; reference model/segformer.py:92-128 after the q / kv projections) -------------- */
+/* out = softmax(scale * q k^T) v per (image, head): q [B,N,heads,32], kv [B,M,2,heads,32] (the kv Linear's output), M <= 64 keys, head dim 32;
+ * split-bf16 MFMA products, fp32 softmax.  Backward: dq like q, dkv like kv; scratch B * heads * hpfg_attn_mfma_blocks(N) * 2*64*32 floats
+ * (per-workgroup dK / dV partials, summed in a fixed order). */
+int hpfg_attn_mfma_fwd(const float* q, const float* kv, float* out, int B, int N, int M, int heads, float scale, void* stream);
+int hpfg_attn_mfma_bwd(const float* q, const float* kv, const float* dout, float* dq, float* dkv, float* scratch, int B, int N, int M, int heads,
+                       float scale, void* stream);
+int hpfg_attn_mfma_blocks(int N);
+
 /* ---- projection necks + Dense_Loss (UNet_Plus; reference model/unet.py:120-152, utils/loss/dense_loss.py:17-40) ------------------------ */
 /* C[m,n] = act(sum_k A(m,k) B(k,n) + bias[n]) in exact fp32 on the matrix cores; A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn], C row-major
  * (ldc); relu: max(.,0) in the epilogue; accumulate: C += (before the activation).  Replaces nn.Linear / 1x1 nn.Conv2d forward and both backward

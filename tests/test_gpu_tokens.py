@@ -26,8 +26,13 @@ def test_layer_norm(rows, C_):
     assert maxerr(wd.grad.cpu(), wr.grad) < 2e-4 and maxerr(bd.grad.cpu(), br.grad) < 2e-4
 
 
-@pytest.mark.parametrize("B,N,M,heads", [(2, 256, 4, 1), (2, 64, 4, 2), (1, 16, 4, 5), (2, 4, 4, 8), (1, 300, 49, 2), (1, 49, 49, 8), (1, 10, 64, 1)])
-def test_attention_core(B, N, M, heads):
+@pytest.mark.parametrize("math", ["bf16x3", "f32"])
+@pytest.mark.parametrize("B,N,M,heads", [(2, 256, 4, 1), (2, 64, 4, 2), (1, 16, 4, 5), (2, 4, 4, 8), (1, 300, 49, 2), (1, 49, 49, 8), (1, 10, 64, 1),
+                                         (2, 3136, 49, 1), (1, 784, 49, 2), (3, 1100, 33, 5)])
+def test_attention_core(B, N, M, heads, math):
+    """softmax(scale q k^T) v and its three gradients: the MFMA kernels (csrc/attn.hip, split-bf16 products: default math mode) and the exact-fp32
+    thread-per-query kernels (HPFG_MATH=f32) against plain PyTorch fp32."""
+    from hpfg_amd import ops_tokens
     g = torch.Generator().manual_seed(N + M)
     C_ = heads * 32
     q, kv, do = torch.randn(B, N, C_, generator=g), torch.randn(B, M, 2 * C_, generator=g), torch.randn(B, N, C_, generator=g)
@@ -41,10 +46,16 @@ def test_attention_core(B, N, M, heads):
     qr, kr = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
     ref(qr, kr).backward(do)
     qd, kd = q.to(DEV).requires_grad_(True), kv.to(DEV).requires_grad_(True)
-    out = attention(qd, kd, heads, scale)
-    out.backward(do.to(DEV))
-    assert maxerr(out.detach().cpu(), ref(q, kv)) < 2e-5
-    assert maxerr(qd.grad.cpu(), qr.grad) < 5e-5 and maxerr(kd.grad.cpu(), kr.grad) < 2e-4
+    ops_tokens.MATH["mode"] = math
+    try:
+        out = attention(qd, kd, heads, scale)
+        out.backward(do.to(DEV))
+    finally:
+        ops_tokens.MATH["mode"] = None
+    k = 1.0 if math == "f32" else 8.0          # split-bf16 products: 2^-17 relative per product instead of fp32 rounding
+    assert maxerr(out.detach().cpu(), ref(q, kv)) < 2e-5 * k
+    assert maxerr(qd.grad.cpu(), qr.grad) < 5e-5 * k
+    assert maxerr(kd.grad.cpu(), kr.grad) < 2e-4 * k * max(1.0, (N / 256) ** 0.5)        # dK / dV sum over all N queries
 
 
 @pytest.mark.parametrize("B,H,W,C_", [(2, 16, 16, 128), (2, 8, 8, 256), (1, 4, 4, 640), (2, 2, 2, 1024), (1, 7, 5, 128)])
