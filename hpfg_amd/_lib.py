@@ -152,7 +152,7 @@ PROTOTYPES = {
     "hpfg_gemm_f32": (_i, [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _p, _i, _i, _p]),
     "hpfg_gemm_bf16x3": (_i, [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _p, _i, _i, _p]),
     "hpfg_gemm_bf16x3_ok": (_i, [_p, _l, _l, _p, _l, _l, _i, _i, _i]),
-    "hpfg_gemm_tn_bf16x3": (_i, [_p, _p, _p, _p, _l, _i, _i, _p]),
+    "hpfg_gemm_tn_bf16x3": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _p]),
     "hpfg_gemm_tn_splits": (_i, [_l, _i, _i]),
     "hpfg_col_sum2": (_i, [_p, _l, _i, _l, _p, _p, _p]),
     "hpfg_col_sum_splits": (_i, [_l]),

@@ -374,7 +374,8 @@ __device__ __forceinline__ void tn_store(unsigned char* lds, int tid, const f32x
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void gemm_tn_bf16x3_kernel(const float* __restrict__ dy, long ldy, const float* __restrict__ x, long ldx,
-                                                             float* __restrict__ part, long R, int N, int K, int rows_per_split) {
+                                                             float* __restrict__ part, long R, int N, int K, int rows_per_split, int with_db,
+                                                             long part_stride) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * TPLANE];      // dY hi | dY lo | X hi | X lo
   unsigned char* ldsA = lds;
   unsigned char* ldsB = lds + 2 * TPLANE;
@@ -391,10 +392,13 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16x3_kernel(const float* __rest
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
   const int fr = (8 * g + q) * TRS + 8 * pp;
   f32x4 va[2], vb[2];
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};          // with_db: column sums of this thread's dY column quad (the bias gradient), blockIdx.y == 0 only
+  const bool do_db = with_db && blockIdx.y == 0;
   tn_load<ALIGNED>(dy, ldy, r0, r1, n0, N, tid, va);
   tn_load<ALIGNED>(x, ldx, r0, r1, k0, K, tid, vb);
   for (long rb = r0; rb < r1; rb += TR) {
     __syncthreads();
+    if (do_db) csum += va[0] + va[1];
     tn_store(ldsA, tid, va);
     tn_store(ldsB, tid, vb);
     __syncthreads();
@@ -419,7 +423,20 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16x3_kernel(const float* __rest
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
       }
   }
-  float* o = part + (long)blockIdx.z * N * K;
+  float* o = part + (long)blockIdx.z * part_stride;
+  if (do_db) {          // 16 row-threads share a column quad: fixed-order sum through LDS; db partial sits behind the N*K weight entries
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(lds);
+    red[tid] = csum;
+    __syncthreads();
+    if (tid < 16) {
+      f32x4 t = red[tid];
+      for (int k = 1; k < 16; ++k) t += red[tid + 16 * k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n0 + 4 * tid + j < N) o[(long)N * K + n0 + 4 * tid + j] = t[j];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int n = n0 + wn + 16 * i + (lane & 15);
@@ -489,21 +506,20 @@ inline int tn_splits(long R, int N, int K) {
 
 extern "C" int hpfg_gemm_tn_splits(long R, int N, int K) { return tn_splits(R, N, K); }
 
-/* dW[N][K] = dY^T X over R rows (dY [R][N], X [R][K], contiguous); partials: hpfg_gemm_tn_splits(R, N, K) * N * K floats of scratch */
-extern "C" int hpfg_gemm_tn_bf16x3(const float* dy, const float* x, float* dw, float* partials, long R, int N, int K, void* stream) {
-  HPFG_ARG_CHECK(dy && x && dw && partials && R > 0 && N > 0 && K > 0, "gemm_tn_bf16x3: bad args");
+/* dW[N][K] = dY^T X over R rows (dY [R][N], X [R][K], contiguous) and, with_db, db[N] = column sums of dY written right behind dW
+ * (dw_db holds N*K (+ N) floats); partials: hpfg_gemm_tn_splits(R, N, K) * (N*K + N) floats of scratch */
+extern "C" int hpfg_gemm_tn_bf16x3(const float* dy, const float* x, float* dw_db, float* partials, long R, int N, int K, int with_db, void* stream) {
+  HPFG_ARG_CHECK(dy && x && dw_db && partials && R > 0 && N > 0 && K > 0, "gemm_tn_bf16x3: bad args");
   const int S = tn_splits(R, N, K);
   int per = (int)((R + S - 1) / S);
   per = (per + TR - 1) / TR * TR;
   dim3 grid((N + TT - 1) / TT, (K + TT - 1) / TT, S);
-  const bool aligned = (N & 3) == 0 && (K & 3) == 0 && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)partials) & 15) == 0;
-  float* dst = S == 1 ? dw : partials;
-  if (aligned && (((uintptr_t)dw & 15) == 0)) hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, (long)N, x, (long)K, dst, R, N, K, per);
-  else hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, (long)N, x, (long)K, dst, R, N, K, per);
-  if (S > 1) {
-    const long NK = (long)N * K;
-    hipLaunchKernelGGL(gemm_rows_sum_kernel, dim3((unsigned)((NK + 63) / 64)), dim3(256), 0, (hipStream_t)stream, partials, S, NK, dw);
-  }
+  const long stride = (long)N * K + (with_db ? N : 0);
+  float* dst = S == 1 ? dw_db : partials;
+  const bool aligned = (N & 3) == 0 && (K & 3) == 0 && (stride & 3) == 0 && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dst) & 15) == 0;
+  if (aligned) hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, (long)N, x, (long)K, dst, R, N, K, per, with_db, stride);
+  else hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, (long)N, x, (long)K, dst, R, N, K, per, with_db, stride);
+  if (S > 1) hipLaunchKernelGGL(gemm_rows_sum_kernel, dim3((unsigned)((stride + 63) / 64)), dim3(256), 0, (hipStream_t)stream, partials, S, stride, dw_db);
   return hpfg_launch_status("gemm_tn_bf16x3_kernel");
 }
 

@@ -260,17 +260,21 @@ class _Linear(torch.autograd.Function):
         R = xc.shape[0]
         dyc = dy.reshape(-1, N).contiguous()
         dx = _gemm(dyc, N, 1, w, K, 1, R, K, N, None, ctx.math).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        if ctx.math == "bf16x3":
-            dw = torch.empty_like(w)
-            part = torch.empty(lib.hpfg_gemm_tn_splits(R, N, K) * N * K, dtype=torch.float32, device=w.device)
-            L.check(lib.hpfg_gemm_tn_bf16x3(L.ptr(dyc), L.ptr(xc), L.ptr(dw), L.ptr(part), R, N, K, _st(w)), "gemm_tn_bf16x3")      # dY^T X on MFMA
-        elif R >= TALL_ROWS and N % 4 == 0 and K % 4 == 0:
+        db = None
+        if ctx.math == "bf16x3":          # dY^T X on MFMA; the bias gradient (column sums of dY) comes out of the same pass
+            wb = torch.empty(N * K + (N if ctx.has_bias else 0), dtype=torch.float32, device=w.device)
+            part = torch.empty(lib.hpfg_gemm_tn_splits(R, N, K) * wb.numel(), dtype=torch.float32, device=w.device)
+            L.check(lib.hpfg_gemm_tn_bf16x3(L.ptr(dyc), L.ptr(xc), L.ptr(wb), L.ptr(part), R, N, K, 1 if ctx.has_bias else 0, _st(w)), "gemm_tn_bf16x3")
+            dw = wb[:N * K].view(N, K)
+            if ctx.has_bias:
+                db = wb[N * K:]
+            return dx, dw, db
+        if R >= TALL_ROWS and N % 4 == 0 and K % 4 == 0:
             dw = torch.empty_like(w)
             part = torch.empty(lib.hpfg_linear_wgrad_splits(R, N, K) * N * K, dtype=torch.float32, device=w.device)
             L.check(lib.hpfg_linear_wgrad(L.ptr(dyc), L.ptr(xc), L.ptr(dw), L.ptr(part), R, N, K, _st(w)), "linear_wgrad")
         else:
             dw = _gemm(dyc, 1, N, xc, K, 1, N, K, R, None, ctx.math)                   # dY^T X, exact fp32
-        db = None
         if ctx.has_bias:
             db = torch.empty(N, dtype=torch.float32, device=w.device)
             scratch = torch.empty(lib.hpfg_col_sum_splits(R) * N, dtype=torch.float32, device=w.device)

@@ -326,8 +326,9 @@ int hpfg_gemm_bf16x3(const float* A, long sam, long sak, const float* B, long sb
 int hpfg_gemm_bf16x3_ok(const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M, int N, int K);
 /* weight gradient dW[N][K] = dY^T X over R tokens (dY [R][N], X [R][K] contiguous) in split-bf16 arithmetic: operands staged as they lie in
  * memory, fragments through the transposing LDS read, rows split over workgroups, partials summed in a fixed order.
- * partials: hpfg_gemm_tn_splits(R, N, K) * N * K floats of scratch.  (autograd's mm for the weight of nn.Linear, segformer.py) */
-int hpfg_gemm_tn_bf16x3(const float* dy, const float* x, float* dw, float* partials, long R, int N, int K, void* stream);
+ * with_db: the bias gradient db[N] = column sums of dY comes out of the same pass, written right behind dW (dw_db: N*K + N floats).
+ * partials: hpfg_gemm_tn_splits(R, N, K) * (N*K + N) floats of scratch.  (autograd's mm / sum for the parameters of nn.Linear, segformer.py) */
+int hpfg_gemm_tn_bf16x3(const float* dy, const float* x, float* dw_db, float* partials, long R, int N, int K, int with_db, void* stream);
 int hpfg_gemm_tn_splits(long R, int N, int K);
 int hpfg_col_sum(const float* x, long R, int M, long ldx, float* out /* [M] = sum over rows */, void* stream);   /* bias gradients */
 int hpfg_col_sum2(const float* x, long R, int M, long ldx, float* out, float* scratch /* hpfg_col_sum_splits(R) * M floats */, void* stream);

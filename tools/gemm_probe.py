@@ -33,7 +33,7 @@ for R, N, K in shapes:
     part = torch.empty(lib.hpfg_gemm_tn_splits(R, N, K) * N * K, device=dev)
     t_f = timeit(lambda: L.check(lib.hpfg_gemm_bf16x3(L.ptr(x), K, 1, L.ptr(w), 1, K, L.ptr(y), N, R, N, K, None, 0, 0, st), "f"))
     t_d = timeit(lambda: L.check(lib.hpfg_gemm_bf16x3(L.ptr(dy), N, 1, L.ptr(w), K, 1, L.ptr(dx), K, R, K, N, None, 0, 0, st), "d"))
-    t_w = timeit(lambda: L.check(lib.hpfg_gemm_tn_bf16x3(L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(part), R, N, K, st), "w"))
+    t_w = timeit(lambda: L.check(lib.hpfg_gemm_tn_bf16x3(L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(part), R, N, K, 0, st), "w"))
     t_t = timeit(lambda: torch.matmul(x, w.t()))
     gf = 2.0 * R * N * K / 1e9
     print(f"R={R} N={N} K={K} ({gf:.1f} GFLOP): fwd {t_f:.0f} us ({gf / t_f * 1e3:.0f} TF)  dX {t_d:.0f} us ({gf / t_d * 1e3:.0f} TF)  dW {t_w:.0f} us ({gf / t_w * 1e3:.0f} TF) "
