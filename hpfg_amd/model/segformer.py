@@ -1,17 +1,18 @@
-"""SegFormer-B0 for the CTCT cross-teaching branch -- FIRST VERSION.
+"""SegFormer-B0 for the CTCT cross-teaching branch.
 
 Same module tree, parameter names and constructor order as the reference's ``model/segformer.py`` (MiT :213-272, SegFormerHead
 :298-320, SegFormer :397-411), so ``state_dict()`` interchanges and a seed gives the same initial weights.  Where the work runs:
 
-* hand-written HIP (``csrc/tokens.hip`` through ``hpfg_amd.ops_tokens``), forward and backward: every LayerNorm, the attention core
-  softmax(q k^T / sqrt(d)) v (at most 64 keys after the spatial reduction, head dim 32), depthwise 3x3 + GELU of the Mix-FFN, the
-  head's bilinear resizes and its BatchNorm(train) + ReLU + Dropout2d, im2col / col2im of the overlap patch embeddings;
-* library GEMMs (rocBLAS through ``F.linear`` / ``torch.matmul``): q / kv / proj / fc1 / fc2, the spatial-reduction conv (kernel ==
-  stride, so it is a GEMM over non-overlapping patches), the patch embeddings (after im2col), the head's per-stage projections, the
-  1x1 fuse and prediction convs, dK / dV of the attention backward -- except the weight gradients of the
-  Linear layers that see >= 8192 tokens (tall-skinny dY^T X), which run on a row-split HIP kernel with a fixed-order reduction;
-* still plain PyTorch-ROCm ops in this version (to be replaced): the channel concat of the head and the token <-> image reshapes
-  (residual adds with their drop-path factor are one HIP kernel, `residual_scale`).
+* hand-written HIP through ``hpfg_amd.ops_tokens``, forward and backward:
+  - every dense product on the matrix cores in split-bf16 arithmetic (``csrc/gemm.hip``: ``hpfg_gemm_bf16x3`` for Y = X W^T + b and
+    dX = dY W, ``hpfg_gemm_tn_bf16x3`` for dW = dY^T X together with db): q / kv / proj / fc1 / fc2, the spatial-reduction conv (kernel ==
+    stride, so it is a GEMM over non-overlapping patches), the patch embeddings (after a HIP im2col), the head's per-stage projections and
+    its 1x1 fuse / prediction convs.  No rocBLAS / hipBLASLt call is left (HPFG_MATH=f32 switches them to the exact-fp32 MFMA GEMM);
+  - the attention core softmax(q k^T / sqrt(d)) v on the matrix cores (``csrc/attn.hip``: at most 64 keys after the spatial reduction,
+    head dim 32 = one MFMA k-step; forward, dQ and dK / dV kernels without LDS transposes of the probabilities);
+  - every LayerNorm, depthwise 3x3 + GELU of the Mix-FFN, the head's bilinear resizes and its BatchNorm(train) + ReLU + Dropout2d,
+    im2col / col2im of the overlap patch embeddings, residual adds with their drop-path factor (``csrc/tokens.hip``);
+* still plain PyTorch-ROCm ops: the channel concat of the head and the token <-> image reshape copies (memory movement only).
 No MIOpen call is left in the module: with MIOpen convolutions / BatchNorm the forward was not bit-reproducible between identical runs
 (logits differing by ~4e-7), and one ReLU gate of the head flipping on such noise moves every gradient upstream by ~1e-3; without it the
 forward is bit-identical run to run.
@@ -23,7 +24,6 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ..ops_tokens import attention, bn_relu_dropout, dwconv_gelu, im2col, layer_norm, linear, residual_scale, resize_bilinear
 
@@ -200,10 +200,13 @@ class SegFormerHead(nn.Module):
         else:                      # eval: a per-channel affine map of the running statistics (elementwise torch ops)
             seg = torch.relu((z - bn.running_mean) * torch.rsqrt(bn.running_var + bn.eps) * bn.weight + bn.bias)
         pr = self.linear_pred
-        seg = linear(seg, pr.weight.reshape(pr.weight.shape[0], -1), pr.bias)
-        if seg.shape[-1] % 4 == 0:                                                 # HIP resize on NHWC; the result is viewed as NCHW
-            return resize_bilinear(seg.view(B, H, W, -1), self.image_size[0], self.image_size[1]).permute(0, 3, 1, 2)
-        return F.interpolate(seg.permute(0, 2, 1).reshape(B, -1, H, W), size=self.image_size, mode="bilinear", align_corners=False)
+        wp, bp, ncls = pr.weight.reshape(pr.weight.shape[0], -1), pr.bias, pr.weight.shape[0]
+        if ncls % 4:          # the HIP resize moves 4 channels per lane: pad the prediction layer with zero rows (2-class LIDC heads), slice them off after
+            pad = 4 - ncls % 4
+            wp, bp = torch.cat([wp, wp.new_zeros(pad, wp.shape[1])], 0), torch.cat([bp, bp.new_zeros(pad)], 0)
+        seg = linear(seg, wp, bp)
+        out = resize_bilinear(seg.view(B, H, W, -1), self.image_size[0], self.image_size[1])      # HIP resize on NHWC; the result is viewed as NCHW
+        return out[..., :ncls].permute(0, 3, 1, 2)
 
 
 class SegFormer(nn.Module):

@@ -158,3 +158,54 @@ def test_eval_path_runs_the_segformer():
     want = [losses_ref.binary_dice(pred == c, lab[0].numpy() == c) for c in range(1, 4)]
     assert np.abs(got[:, 0] - np.array(want)).max() < 2e-3, (got[:, 0], want)
     assert got.shape == (3, 2) and np.isfinite(got).all()
+
+
+def test_ctct_step_full_size_vs_oracle():
+    """BASELINE configs[4] at its real size: one CTCT iteration (2021_12_MIDL_CTCT_ACDC.py:117-134) of U-Net + SegFormer-B0 on 8 labelled +
+    24 unlabelled 224x224 images against oracle.steps_ref.ctct_step (pinned to the reference's own modules by tests/golden/trace_ctct.npz):
+    every loss term, both networks' logits, and the SGD / AdamW updates through the logits of a second iteration's forward."""
+    from hpfg_amd.datasets.synthetic import synth_batch
+    from hpfg_amd.model import UNet
+    from hpfg_amd.train import CTCTStep
+    from hpfg_amd.utils import AttrDict
+    from oracle import laws_ref, steps_ref
+    from tests.helpers import engine_masks, state_from_module
+    NL, NU, HW = 8, 24, 224
+    torch.manual_seed(1)
+    m1, m2 = UNet(1, 4).to(DEV), SegFormer(image_size=[HW, HW], in_channels=1, num_classes=4).to(DEV)
+    m1.train()
+    m2.train()
+    s1, s2 = state_from_module(m1), {k: v.detach().cpu().clone() for k, v in m2.state_dict().items()}
+    opt = dict(opt="sgd", lr=0.01, momentum=0.9, weight_decay=5e-4, sched="medical", total_itrs=30000, step_size=1500, warmup_epochs=1, warmup_lr=1e-4, min_lr=1e-6)
+    a = AttrDict(dict(model1=AttrDict(opt), model2=AttrDict(dict(opt, opt="adamW", lr=0.0008, weight_decay=0.05)), consistency=0.1, consistency_rampup=200.0))
+    st = CTCTStep(m1, m2, a)
+    xl, yl = synth_batch(31, NL, HW, HW, 1, 4, 32)
+    xu, _ = synth_batch(32, NU, HW, HW, 1, 4, 32)
+    torch.manual_seed(77)
+    draws = S.draw_randomness(NL + NU)
+    m2.external_draws = draws
+    w = 0.05
+    r = st.step(xl.to(DEV), yl.to(DEV), xu.to(DEV), 1, cons_w=w)
+    eng = next(iter(m1._engines.values()))[0]
+    masks = engine_masks(eng, m1._seed_counter, NL + NU, HW, HW)
+    bufs1, adam2 = {}, {}
+    ro = steps_ref.ctct_step(s1, s2, bufs1, adam2, xl, yl.long(), xu, laws_ref.medical_lr(1, 0.01, 30000), laws_ref.medical_lr(1, 0.0008, 30000), w, 0.9, 5e-4, 0.05,
+                             masks, draws)
+    p1, p2 = r["parts1"].cpu(), r["parts2"].cpu()
+    got = [float(r["loss"]), 0.5 * float(p1[1]) + 0.5 * float(p1[2]), 0.5 * float(p2[1]) + 0.5 * float(p2[2]), float(p1[4]), float(p2[4])]
+    ref = [ro["loss"], ro["sup1"], ro["sup2"], ro["ps1"], ro["ps2"]]
+    assert max(abs(x - y) for x, y in zip(got, ref)) < 1e-3, (got, ref)
+    assert maxerr(r["logits1"].cpu(), ro["logits1"]) < 1e-3
+    assert maxerr(r["logits2"].cpu(), ro["logits2"]) < 1e-3
+    # the updates: the U-Net after one SGD step agrees to 1e-3 in its next (eval) forward; the SegFormer after one AdamW step -- lr * sign(g)
+    # for every element, so gradients at rounding level move by a full +-8e-4 either way (see test_ctct_step_trace) -- to a few such steps
+    m1.eval()
+    m2.eval()
+    with torch.no_grad():
+        e1 = m1(xl.to(DEV)).cpu()
+        e2 = m2(xl.to(DEV)).cpu()
+        from oracle import unet_ref
+        f1 = unet_ref.unet_forward(s1, xl, train=False)
+        f2 = S.segformer_forward(s2, xl, False)
+    assert maxerr(e1, f1) < 1e-3
+    assert maxerr(e2, f2) < 2e-2
