@@ -157,6 +157,8 @@ def main():
     xl, yl = synth_batch(1234 + rank, a.lab, a.size, a.size, 1, 4, 32)
     xu, _ = synth_batch(91234 + rank, a.unlab, a.size, a.size, 1, 4, 32)
     xl, yl, xu = xl.to(dev), yl.to(dev), xu.to(dev)
+    from hpfg_amd.train import batch_pair
+    xl, xu = batch_pair(xl, xu)          # labelled and unlabelled images back to back in HBM: the step's batch is a view, not a concat copy
 
     # N > 1, default mode: two graphs around the gradient all-reduce (no RCCL node inside a hipGraph).  --sync-bn (collectives
     # between the kernels of forward and backward) runs eager unless HPFG_DP_GRAPH=1 asks for a capture with RCCL nodes.

@@ -175,7 +175,7 @@ class UNetEngine:
         return a
 
     def is_deep(self, s: ConvSpec) -> bool:
-        return (self.use_planes and self.math == L.MATH_BF16X3 and not self.wgrad_overlap and s.taps == 9 and s.cin >= 64 and s.cout >= 64
+        return (self.use_planes and self.math == L.MATH_BF16X3 and self.wgrad_overlap in (0, 3) and s.taps == 9 and s.cin >= 64 and s.cout >= 64
                 and s.h <= 56 and s.w <= 56 and s.cin % 8 == 0 and s.cout % 8 == 0)
 
     def _act_planes(self, t: torch.Tensor, C_: int, h: int, w: int) -> L.Act:
@@ -444,7 +444,8 @@ class UNetEngine:
         """Weight gradient of layer s.  It is off the critical chain of backward (nothing downstream consumes it before the final
         slab reduction), so it is issued on a second HIP stream forked behind the kernels recorded so far and joined at the end."""
         main = torch.cuda.current_stream(self.dev)
-        if self.wgrad_overlap:
+        # 3: only the layers whose grids do not fill the chip (<= 56 x 56: a few hundred workgroups each for dgrad and wgrad) share it
+        if self.wgrad_overlap in (1, 2) or (self.wgrad_overlap == 3 and s.taps == 9 and s.h <= 56):
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.dev)
             self._side.wait_stream(main)

@@ -67,6 +67,21 @@ class StepScalars:
         return self.dev[off:off + n]
 
 
+def cat_batch(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torch.cat([a, b], 0) -- without the copy when the two batches already sit back to back in one buffer (loaders and bench.py hand the
+    labelled and unlabelled images over as adjacent views): the result is then a view over both."""
+    if (a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.shape[1:] == b.shape[1:] and a.device == b.device
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and b.storage_offset() == a.storage_offset() + a.numel()):
+        return a.as_strided((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+    return torch.cat([a, b], 0)
+
+
+def batch_pair(a: torch.Tensor, b: torch.Tensor):
+    """Copies of (a, b) laid out back to back in one buffer, so that cat_batch(a', b') is free (call once, outside the step loop)."""
+    buf = torch.cat([a, b], 0)
+    return buf[:a.shape[0]], buf[a.shape[0]:]
+
+
 def argmax_labels(logits: torch.Tensor, mix_labels: Optional[torch.Tensor] = None, mix_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """uint8 [N,H,W] arg-max over classes of logits [N,C,H,W]; with (mix_labels, mix_mask): labels*(1-M) + argmax*M."""
     x = _nhwc(logits.detach())
@@ -229,7 +244,7 @@ class MeanTeacherStep(_StepBase):
     def device_fwd_bwd(self, label_img, target_label, unlabel_img):
         """Everything up to (not including) the gradient exchange."""
         nl = label_img.shape[0]
-        x = torch.cat([label_img, unlabel_img], 0)
+        x = cat_batch(label_img, unlabel_img)
         self._mark(0)
         t_out = self._teacher_forward(self.ema_model, x)
         self._mark(1)
@@ -420,7 +435,7 @@ class UAMTStep(_StepBase):
 
     def device_step(self, label_img, target_label, unlabel_img, noise0, noises):
         nl, nu = label_img.shape[0], unlabel_img.shape[0]
-        out = self.model(torch.cat([label_img, unlabel_img], 0))
+        out = self.model(cat_batch(label_img, unlabel_img))
         with torch.no_grad():
             ema_out = self.ema_model(noise_add(unlabel_img, noise0))
             preds = [self.ema_model(noise_add(unlabel_img, nz)) for nz in noises]
@@ -469,7 +484,7 @@ class CPSStep(_StepBase):
 
     def device_step(self, label_img, target_label, unlabel_img):
         nl = label_img.shape[0]
-        x = torch.cat([label_img, unlabel_img], 0)
+        x = cat_batch(label_img, unlabel_img)
         o1 = self.model1(x)
         o2 = self.model2(x)
         p1 = argmax_labels(o1[nl:])
@@ -542,7 +557,7 @@ class HPFGStep(_StepBase):
         mix_un = cutmix_blend(label_img1, img_unlabel, cutmix_mask)
         batch_mix = torch.cat([label_img, mix_un], 0)
         o1, _, _ = self.model1(batch_mix)
-        volume = torch.cat([label_img, img_unlabel], 0)
+        volume = cat_batch(label_img, img_unlabel)
         volume_t = volume
         ot, th1, th2 = self._teacher_forward(self.ema_model, volume_t)
         o2, h1, h2 = self.model2(volume)
@@ -609,7 +624,7 @@ class S4CVNetStep(_StepBase):
 
     def device_step(self, label_img, target_label, unlabel_img, noise):
         nl = label_img.shape[0]
-        x = torch.cat([label_img, unlabel_img], 0)
+        x = cat_batch(label_img, unlabel_img)
         ot = self._teacher_forward(self.ema_model, noise_add(unlabel_img, noise))
         o1 = self.model1(x)
         o2 = self.model2(x)
