@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round evidence on the GPU box (run through gpurun from the repo root): bench line, rocprofv3 kernel trace of the same command,
+# the two PMC passes of the HBM traffic (separate runs, counters only with --kernel-trace, as MI355X_MICROARCH.md prescribes),
+# the CTCT and HPFG step profiles.  Everything lands under gpurun_out/$1/ ; tools/rocpd_stats.py / step_traffic.py summarise it afterwards.
+set -o pipefail
+TAG=${1:-r02}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+python tools/time_other_configs.py > $OUT/other_configs.txt 2>&1
+python tools/bench_ctct.py > $OUT/ctct.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o mt -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f32-line > $OUT/trace.log 2>&1 || exit 2
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-f32-line > $OUT/pmc_fetch.log 2>&1 || exit 3
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-f32-line > $OUT/pmc_write.log 2>&1 || exit 4
+STEPS=5 GRAPH=0 rocprofv3 --kernel-trace --stats -d $OUT/trace_ctct -o c -- python3 $GRAFT_REPO_ROOT/tools/bench_ctct.py > $OUT/trace_ctct.log 2>&1 || exit 5
+rocprofv3 --kernel-trace --stats -d $OUT/trace_hpfg -o h -- python3 $GRAFT_REPO_ROOT/tools/hpfg_step_probe.py > $OUT/trace_hpfg.log 2>&1 || exit 6
+echo profile_round done
