@@ -150,6 +150,8 @@ PROTOTYPES = {
     "hpfg_attn_mfma_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "hpfg_attn_mfma_blocks": (_i, [_i]),
     "hpfg_gemm_f32": (_i, [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _p, _i, _i, _p]),
+    "hpfg_gemm_f32_splitk": (_i, [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _p, _i, _i, _p, _p]),
+    "hpfg_gemm_f32_splits": (_i, [_i, _i, _i]),
     "hpfg_gemm_bf16x3": (_i, [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _p, _i, _i, _p]),
     "hpfg_gemm_bf16x3_ok": (_i, [_p, _l, _l, _p, _l, _l, _i, _i, _i]),
     "hpfg_gemm_tn_bf16x3": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _p]),

@@ -23,11 +23,15 @@ struct GemmArgs {
   int M, N, K, relu, accumulate;
 };
 
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+// blockIdx.z = K split: split z covers k in [z * kper, (z + 1) * kper) and, when there are several splits, writes its partial product
+// (no bias / activation) to C + z * M * ldc; gemm_splitk_finish_kernel adds them in a fixed order.
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int kper) {
   __shared__ float As[TK * LDT], Bs[TK * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
   const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+  const int kbeg = blockIdx.z * kper, kend = kbeg + kper < p.K ? kbeg + kper : p.K;
+  const bool split = gridDim.z > 1;
   f32x4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -35,31 +39,43 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // staging map: consecutive threads walk the operand's unit-stride index (coalesced for either orientation)
   const bool a_k_fast = p.sak == 1, b_n_fast = p.sbn == 1;
-  for (int k0 = 0; k0 < p.K; k0 += TK) {
+  int am[4], ak[4], bn_[4], bk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (a_k_fast) {
+      ak[i] = tid & 15;
+      am[i] = (tid >> 4) + 16 * i;
+    } else {
+      am[i] = tid & 63;
+      ak[i] = (tid >> 6) + 4 * i;
+    }
+    if (b_n_fast) {
+      bn_[i] = tid & 63;
+      bk[i] = (tid >> 6) + 4 * i;
+    } else {
+      bk[i] = tid & 15;
+      bn_[i] = (tid >> 4) + 16 * i;
+    }
+  }
+  float ra[4], rb[4];
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int m, k;
-      if (a_k_fast) {
-        k = tid & 15;
-        m = (tid >> 4) + 16 * i;
-      } else {
-        m = tid & 63;
-        k = (tid >> 6) + 4 * i;
-      }
-      const int gm = m0 + m, gk = k0 + k;
-      As[k * LDT + m] = (gm < p.M && gk < p.K) ? p.A[(long)gm * p.sam + (long)gk * p.sak] : 0.f;
-      int n, kb;
-      if (b_n_fast) {
-        n = tid & 63;
-        kb = (tid >> 6) + 4 * i;
-      } else {
-        kb = tid & 15;
-        n = (tid >> 4) + 16 * i;
-      }
-      const int gn = n0 + n, gkb = k0 + kb;
-      Bs[kb * LDT + n] = (gn < p.N && gkb < p.K) ? p.B[(long)gkb * p.sbk + (long)gn * p.sbn] : 0.f;
+      const int gm = m0 + am[i], gk = k0 + ak[i], gn = n0 + bn_[i], gkb = k0 + bk[i];
+      ra[i] = (gm < p.M && gk < kend) ? p.A[(long)gm * p.sam + (long)gk * p.sak] : 0.f;
+      rb[i] = (gn < p.N && gkb < kend) ? p.B[(long)gkb * p.sbk + (long)gn * p.sbn] : 0.f;
+    }
+  };
+  fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += TK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      As[ak[i] * LDT + am[i]] = ra[i];
+      Bs[bk[i] * LDT + bn_[i]] = rb[i];
     }
     __syncthreads();
+    if (k0 + TK < kend) fetch(k0 + TK);          // the next chunk's loads fly across the MFMA phase
 #pragma unroll
     for (int ks = 0; ks < TK / 4; ++ks) {
       const int kk = ks * 4 + (lane >> 4);
@@ -73,27 +89,52 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
   }
   // D layout: row = (lane >> 4) * 4 + r, col = lane & 15
+  float* Cz = p.C + (split ? (long)blockIdx.z * p.M * p.ldc : 0);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int gn = n0 + wn + j * 16 + (lane & 15);
       if (gn >= p.N) continue;
-      const float bv = p.bias ? p.bias[gn] : 0.f;
+      const float bv = (p.bias && !split) ? p.bias[gn] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gm = m0 + wm + i * 16 + (lane >> 4) * 4 + r;
         if (gm >= p.M) continue;
         float v = acc[i][j][r] + bv;
-        float* c = p.C + (long)gm * p.ldc + gn;
-        if (p.accumulate) v += *c;
-        if (p.relu) v = fmaxf(v, 0.f);
+        float* c = Cz + (long)gm * p.ldc + gn;
+        if (!split) {
+          if (p.accumulate) v += *c;
+          if (p.relu) v = fmaxf(v, 0.f);
+        }
         *c = v;
       }
     }
+}
+
+// out[m][n] = act(sum_s part[s][m][n] + bias[n] (+ out[m][n])): the K splits of gemm_f32_kernel in a fixed order
+__global__ __launch_bounds__(256) void gemm_splitk_finish_kernel(const float* __restrict__ part, int S, int M, int N, long ldp, float* __restrict__ out, long ldc,
+                                                                 const float* __restrict__ bias, int relu, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)M * N) return;
+  const int m = (int)(i / N), n = (int)(i % N);
+  float v = bias ? bias[n] : 0.f;
+  for (int s = 0; s < S; ++s) v += part[((long)s * M + m) * ldp + n];
+  float* c = out + (long)m * ldc + n;
+  if (accumulate) v += *c;
+  if (relu) v = fmaxf(v, 0.f);
+  *c = v;
+}
+
+inline int f32_splits(int M, int N, int K) {
+  const long tiles = (long)((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+  if (tiles >= 128 || K < 256) return 1;          // enough workgroups already, or nothing to split
+  long s = 256 / tiles;
+  const long by_k = K / 128;                      // at least 128 of K per split
+  if (s > by_k) s = by_k;
+  return (int)(s < 1 ? 1 : (s > 32 ? 32 : s));
 }
 
 // out[c] = sum_r x[r, c]  (bias gradients of the neck layers): one thread per column, rows in a fixed order
@@ -118,8 +159,28 @@ extern "C" int hpfg_gemm_f32(const float* A, long sam, long sak, const float* B,
   HPFG_ARG_CHECK(A && B && Cm && M > 0 && N > 0 && K > 0 && ldc >= N, "gemm_f32: bad args (M=%d N=%d K=%d ldc=%ld)", M, N, K, ldc);
   GemmArgs p{A, B, Cm, bias, sam, sak, sbk, sbn, ldc, M, N, K, relu, accumulate};
   dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM);
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, K);
   return hpfg_launch_status("gemm_f32_kernel");
+}
+
+/* K splits for a product with few output tiles and a long contraction (the 2048-wide neck layers: 2 x 8 tiles, K = 2048) */
+extern "C" int hpfg_gemm_f32_splits(int M, int N, int K) { return f32_splits(M, N, K); }
+
+/* hpfg_gemm_f32 with the contraction split over workgroups; scratch: hpfg_gemm_f32_splits(M, N, K) * M * N floats (unused when 1 split) */
+extern "C" int hpfg_gemm_f32_splitk(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* Cm, long ldc, int M, int N, int K,
+                                    const float* bias, int relu, int accumulate, float* scratch, void* stream) {
+  const int S = f32_splits(M, N, K);
+  if (S <= 1) return hpfg_gemm_f32(A, sam, sak, B, sbk, sbn, Cm, ldc, M, N, K, bias, relu, accumulate, stream);
+  HPFG_ARG_CHECK(A && B && Cm && scratch && M > 0 && N > 0 && K > 0 && ldc >= N, "gemm_f32_splitk: bad args");
+  int kper = (K + S - 1) / S;
+  kper = (kper + TK - 1) / TK * TK;
+  GemmArgs p{A, B, scratch, nullptr, sam, sak, sbk, sbn, (long)N, M, N, K, 0, 0};
+  dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM, (K + kper - 1) / kper);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, kper);
+  const long total = (long)M * N;
+  hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scratch, (int)grid.z, M, N, (long)N, Cm,
+                     ldc, bias, relu, accumulate);
+  return hpfg_launch_status("gemm_f32_splitk");
 }
 
 extern "C" int hpfg_col_sum(const float* x, long R, int M, long ldx, float* out, void* stream) {

@@ -26,11 +26,22 @@ __global__ __launch_bounds__(256) void neck_pool_fwd_kernel(const float* __restr
   const int c = tid % C, slot = tid / C;
   const int bw = x1 - x0, npix = (y1 - y0) * bw;
   float s = 0.f;
-  if (slot < slots) {
-    for (int i = slot; i < npix; i += slots) {
-      const int yy = y0 + i / bw, xx = x0 + i % bw;
-      s += x[(((long)n * H + yy) * W + xx) * ps + c];
+  if (slot < slots) {          // four independent loads in flight per thread (a bin of the 224 x 224 logits is 49 pixels per slot: latency, not bytes)
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = slot;
+    for (; i + 3 * slots < npix; i += 4 * slots) {
+      const int i1 = i + slots, i2 = i + 2 * slots, i3 = i + 3 * slots;
+      const float v0 = x[(((long)n * H + y0 + i / bw) * W + x0 + i % bw) * ps + c];
+      const float v1 = x[(((long)n * H + y0 + i1 / bw) * W + x0 + i1 % bw) * ps + c];
+      const float v2 = x[(((long)n * H + y0 + i2 / bw) * W + x0 + i2 % bw) * ps + c];
+      const float v3 = x[(((long)n * H + y0 + i3 / bw) * W + x0 + i3 % bw) * ps + c];
+      s += v0;
+      s1 += v1;
+      s2 += v2;
+      s3 += v3;
     }
+    for (; i < npix; i += slots) s += x[(((long)n * H + y0 + i / bw) * W + x0 + i % bw) * ps + c];
+    s = (s + s1) + (s2 + s3);
   }
   sh[tid] = s;
   __syncthreads();

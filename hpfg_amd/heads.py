@@ -25,7 +25,11 @@ def gemm(a: torch.Tensor, sam: int, sak: int, b: torch.Tensor, sbk: int, sbn: in
         raise RuntimeError("hpfg_amd necks run on the HIP library only (no CPU fallback)")
     if out is None:
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
-    L.check(L.load().hpfg_gemm_f32(L.ptr(a), sam, sak, L.ptr(b), sbk, sbn, L.ptr(out), n, m, n, k, L.ptr(bias), 1 if relu else 0, 0, _st(a)), "gemm_f32")
+    lib = L.load()
+    splits = lib.hpfg_gemm_f32_splits(m, n, k)          # few output tiles, long contraction (the 2048-wide layers): split K over workgroups
+    scratch = torch.empty(splits * m * n, dtype=torch.float32, device=a.device) if splits > 1 else None
+    L.check(lib.hpfg_gemm_f32_splitk(L.ptr(a), sam, sak, L.ptr(b), sbk, sbn, L.ptr(out), n, m, n, k, L.ptr(bias), 1 if relu else 0, 0, L.ptr(scratch), _st(a)),
+            "gemm_f32")
     return out
 
 
@@ -55,7 +59,8 @@ class _Linear(torch.autograd.Function):
         dx = gemm(dy, M, 1, w, K, 1, R, K, M) if ctx.needs_input_grad[0] else None              # dY W
         dw = gemm(dy, 1, M, x, K, 1, M, K, R)                                                    # dY^T X
         db = torch.empty(M, dtype=torch.float32, device=dy.device)
-        L.check(lib.hpfg_col_sum(L.ptr(dy), R, M, M, L.ptr(db), _st(dy)), "col_sum")
+        scratch = torch.empty(lib.hpfg_col_sum_splits(R) * M, dtype=torch.float32, device=dy.device)
+        L.check(lib.hpfg_col_sum2(L.ptr(dy), R, M, M, L.ptr(db), L.ptr(scratch), _st(dy)), "col_sum2")
         return dx, dw, db, None
 
 

@@ -317,6 +317,11 @@ int hpfg_attn_mfma_blocks(int N);
  * products of the necks (unet.py:125-138) and torch.mm of dense_loss.py:24.  Deterministic: no split-K, no atomics. */
 int hpfg_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N, int K,
                   const float* bias, int relu, int accumulate, void* stream);
+/* the same with the contraction split over workgroups when the product has few output tiles and a long K (fixed-order sum of the partials);
+ * scratch: hpfg_gemm_f32_splits(M, N, K) * M * N floats */
+int hpfg_gemm_f32_splitk(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N, int K,
+                         const float* bias, int relu, int accumulate, float* scratch, void* stream);
+int hpfg_gemm_f32_splits(int M, int N, int K);
 /* the same contract in split-bf16 arithmetic (hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate; 128 x 128 tiles): every
  * nn.Linear / kernel==stride conv / 1x1 conv of the SegFormer branch (reference model/segformer.py:92-177, 298-320), forward and input
  * gradient, and the weight gradient of layers with few tokens.  Operands need a unit stride along one index and 4-element alignment:
