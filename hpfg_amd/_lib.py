@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ, ACT_PLANES = range(8)
 LOSS_NSUM = 32
-VERSION = 119
+VERSION = 120
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -35,7 +35,7 @@ class ConvArgs(C.Structure):
     _fields_ = [("a0", Act), ("a1", Act), ("wpk", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
                 ("stat_partials", C.c_void_p), ("out_pstride", C.c_int32), ("Cout", C.c_int32), ("CoutPad", C.c_int32),
                 ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("taps", C.c_int32), ("math", C.c_int32),
-                ("bwd_stats", C.c_int32), ("bwd_of", Act)]
+                ("bwd_stats", C.c_int32), ("bwd_of", Act), ("out2", C.c_void_p), ("out_split", C.c_int32), ("out2_pstride", C.c_int32)]
 
 
 class WgradArgs(C.Structure):

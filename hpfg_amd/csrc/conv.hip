@@ -134,7 +134,10 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
   HPFG_ARG_CHECK(a->N > 0 && a->H > 0 && a->W > 0 && a->N < 65536, "conv_fwd: bad N/H/W");
   HPFG_ARG_CHECK(a->a0.mode != HPFG_ACT_NONE && a->a0.C > 0, "conv_fwd: a0 empty");
   HPFG_ARG_CHECK(a->a1.mode == HPFG_ACT_NONE || a->a0.C % 16 == 0, "conv_fwd: concat needs a0.C %% 16 == 0");
-  HPFG_ARG_CHECK(a->out_pstride >= a->Cout, "conv_fwd: out_pstride < Cout");
+  HPFG_ARG_CHECK(a->out_split ? (a->out_pstride >= a->out_split) : (a->out_pstride >= a->Cout), "conv_fwd: out_pstride too small");
+  HPFG_ARG_CHECK(a->out_split == 0 || (a->out2 && a->out_split % 16 == 0 && a->out_split < a->Cout && a->out2_pstride >= a->Cout - a->out_split &&
+                                       !a->bwd_stats),
+                 "conv_fwd: out_split needs out2, a multiple of 16 below Cout, and no bwd_stats");
   hipStream_t st = (hipStream_t)stream;
   if (a->bwd_stats) {
     const int kind = hpfg_kind_of(a->a0, a->a1);

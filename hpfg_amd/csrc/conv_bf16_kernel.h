@@ -102,7 +102,7 @@ __device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (
                                                   const f32x4 (&bias)[C::NI], int lane, int wm, int nt0, int n, int ty0, int tx0,
                                                   bool reload_bias = false) {
   const int H = p.H, W = p.W;
-  const bool vec = (p.Cout & 3) == 0 && (p.out_pstride & 3) == 0;
+  const bool vec = (p.Cout & 3) == 0 && (p.out_pstride & 3) == 0 && (p.out2_pstride & 3) == 0;
   const bool bwd = BWD_OK && p.bwd_stats;
   ActCtx bcx;
   if (bwd) bcx = make_ctx(p.bwd_of);
@@ -137,7 +137,8 @@ __device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (
       const int gy = ty0 + pxl / C::TW, gx = tx0 + pxl % C::TW;
       if (gy < H && gx < W && co < p.Cout) {
         f32x4 v = acc[m][j] + b;
-        float* o = p.out + ((n * H + gy) * W + gx) * p.out_pstride + co;
+        float* o = (p.out_split && co >= p.out_split) ? p.out2 + ((n * H + gy) * W + gx) * p.out2_pstride + (co - p.out_split)
+                                                       : p.out + ((n * H + gy) * W + gx) * p.out_pstride + co;
         if (p.math & 0x100) {
         } else if (vec) {
           *reinterpret_cast<f32x4*>(o) = v;

@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(HpfgConvArgs p, int tile
         int gy = ty0 + pxl / C::TW, gx = tx0 + pxl % C::TW;
         float v = acc[m][j][r] + b;
         if (gy < H && gx < W && co < p.Cout) {
-          p.out[((long)(n * H + gy) * W + gx) * p.out_pstride + co] = v;
+          if (p.out_split && co >= p.out_split) p.out2[((long)(n * H + gy) * W + gx) * p.out2_pstride + (co - p.out_split)] = v;
+          else p.out[((long)(n * H + gy) * W + gx) * p.out_pstride + co] = v;
           s1[j] += v;
           s2[j] += v * v;
         }

@@ -354,10 +354,16 @@ class UNetEngine:
         self.dA_ps: Dict[str, int] = {}
         # gradient w.r.t. each BN'd conv's activated output.  Skip features alias the first half of the decoder's dCat.
         self.dcat: Dict[int, torch.Tensor] = {}
+        self.dup: Dict[int, torch.Tensor] = {}
         for k in range(1, 5):
             s = self.specs[f"decoder.up{k}.conv.conv_conv.0"]
-            self.dcat[k] = torch.empty(N, s.h, s.w, s.cin, **f32)
             skip = enc_prefix(4 - k) + ".4"
+            if s.cin // 2 * 4 < 128:              # a half of the concat gradient is less than a 128-byte line per pixel (up4: 16 channels): interleaved,
+                self.dcat[k] = torch.empty(N, s.h, s.w, s.cin // 2, **f32)     # every reader of one half would fetch both -> two buffers (HpfgConvArgs.out2)
+                self.dup[k] = torch.empty(N, s.h, s.w, s.cin // 2, **f32)
+                self.dA[skip], self.dA_ps[skip] = self.dcat[k], s.cin // 2
+                continue
+            self.dcat[k] = torch.empty(N, s.h, s.w, s.cin, **f32)
             self.dA[skip] = self.dcat[k]          # channels [0, C2) with pixel stride 2*C2
             self.dA_ps[skip] = s.cin
         for s in self.order:
@@ -430,15 +436,15 @@ class UNetEngine:
                                                   s.cout, 1.0, st), "bn_bwd_finalize")
         return g
 
-    def _wgrad_dgrad(self, s: ConvSpec, g: L.Act, dgrad_out: torch.Tensor, stats_for: Optional[str] = None):
+    def _wgrad_dgrad(self, s: ConvSpec, g: L.Act, dgrad_out: torch.Tensor, stats_for: Optional[str] = None, out2: Optional[torch.Tensor] = None):
         """Both gradients of layer s from the same dZ source (they only read it, so their order is free)."""
         g = self.staged_dz(s, g)
         if self.wgrad_overlap == 2:
-            self._dgrad(s, g, dgrad_out, stats_for)
+            self._dgrad(s, g, dgrad_out, stats_for, out2)
             self._wgrad(s, g)
         else:
             self._wgrad(s, g)
-            self._dgrad(s, g, dgrad_out, stats_for)
+            self._dgrad(s, g, dgrad_out, stats_for, out2)
 
     def _wgrad(self, s: ConvSpec, g: L.Act):
         """Weight gradient of layer s.  It is off the critical chain of backward (nothing downstream consumes it before the final
@@ -463,7 +469,7 @@ class UNetEngine:
         wa.math = self.math
         L.check(self.lib.hpfg_wgrad(C.byref(wa), stream), f"wgrad[{s.name}]")
 
-    def _dgrad(self, s: ConvSpec, g: L.Act, out: torch.Tensor, stats_for: Optional[str] = None):
+    def _dgrad(self, s: ConvSpec, g: L.Act, out: torch.Tensor, stats_for: Optional[str] = None, out2: Optional[torch.Tensor] = None):
         """out [N,h,w,cin] = conv-transpose of dZ with this layer's weights.
         stats_for: name of the BatchNorm layer whose activated output `out` is the COMPLETE gradient of (this conv is its only
         consumer): the bf16x3 kernel's epilogue then also leaves that layer's backward sums in self.partials, and the following
@@ -474,6 +480,8 @@ class UNetEngine:
         ca.wpk = L.ptr(self.wpk16_d[s.name]) if self.math == L.MATH_BF16X3 else L.ptr(self.wpk_d[s.name])
         ca.bias, ca.out, ca.stat_partials = None, L.ptr(out), None
         ca.out_pstride, ca.Cout, ca.CoutPad = s.cin, s.cin, s.cin_pad
+        if out2 is not None:          # [d(skip) | d(upsampled)] into two buffers
+            ca.out2, ca.out_split, ca.out_pstride, ca.out2_pstride = L.ptr(out2), s.cin // 2, s.cin // 2, s.cin // 2
         ca.N, ca.H, ca.W, ca.taps = self.N, s.h, s.w, s.taps
         # (not for the 32-channel slices of 16x16-pixel tiles: that instantiation is out of registers and the extra epilogue spills)
         spills = s.taps == 9 and s.cin_pad % 32 == 0 and s.h % 16 == 0 and s.w % 16 == 0
@@ -518,10 +526,14 @@ class UNetEngine:
             g2 = self._bn_backward(s2)
             self._wgrad_dgrad(s2, g2, self.dA[s1.name], s1.name)
             g1 = self._bn_backward(s1)
-            self._wgrad_dgrad(s1, g1, self.dcat[k])                # [dSkip | dUp]
             c2 = su.cout
-            dup = self.dcat[k].view(-1)[c2:]                        # channel offset c2, pixel stride 2*c2
-            L.check(self.lib.hpfg_upsample2x_bwd_sums(L.ptr(dup), 2 * c2, L.ptr(self.dU[k]), N, su.h, su.w, c2, L.ptr(self.csum_part[su.name]), st),
+            if k in self.dup:
+                self._wgrad_dgrad(s1, g1, self.dcat[k], out2=self.dup[k])      # dSkip and dUp in buffers of their own
+                dup, dup_ps = self.dup[k], c2
+            else:
+                self._wgrad_dgrad(s1, g1, self.dcat[k])            # [dSkip | dUp]
+                dup, dup_ps = self.dcat[k].view(-1)[c2:], 2 * c2   # channel offset c2, pixel stride 2*c2
+            L.check(self.lib.hpfg_upsample2x_bwd_sums(L.ptr(dup), dup_ps, L.ptr(self.dU[k]), N, su.h, su.w, c2, L.ptr(self.csum_part[su.name]), st),
                     "upsample2x_bwd")                            # + per-workgroup channel sums of dU: the 1x1 conv's bias gradient
             gu = self._act_plain(self.dU[k], c2, su.h, su.w)
             prev = enc_prefix(4) + ".4" if k == 1 else f"decoder.up{k - 1}.conv.conv_conv.4"

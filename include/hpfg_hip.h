@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 119
+#define HPFG_VERSION 120
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -80,6 +80,11 @@ typedef struct HpfgConvArgs {
                            sum(g), sum(g*xhat)  (g = out * LeakyReLU' * dropout) instead of sum(z), sum(z*z) -- what hpfg_bn_bwd_reduce
                            would compute in a pass of its own; feed the rows to hpfg_bn_bwd_finalize */
   HpfgAct bwd_of;       /* that layer: z, its table (mean, rstd, scale, shift rows), dropout fields; C == Cout, Hs x Ws == H x W */
+  float* out2;          /* optional second destination: output channels >= out_split go to out2[pixel * out2_pstride + (co - out_split)]
+                           instead of `out`.  The dgrad of a decoder block's first conv writes d(skip) and d(upsampled) -- the two halves of the
+                           concat gradient, unet.py:57 -- into buffers of their own, so that neither is read through a half-used pixel stride */
+  int32_t out_split;    /* multiple of 16; 0 = everything to `out` */
+  int32_t out2_pstride;
 } HpfgConvArgs;
 
 typedef struct HpfgWgradArgs {
