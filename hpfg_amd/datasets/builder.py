@@ -2,13 +2,13 @@
 
 Adds the keys "synthetic" -> (label_loader, unlabel_loader, test_loader) and "sup_synthetic" -> (train_loader, test_loader),
 which honour the same batch contract as "acdc"/"sup_acdc", and "device_synthetic": the slices live in HBM and every batch is
-augmented (the reference's RandomGenerator) and assembled by one kernel.  The reference's real-data keys need h5py / albumentations and the
-ACDC/LIDC files, none of which exist on the build or GPU boxes; they raise NotImplementedError like an unknown key
-(builder.py:76-77) with a pointer to the synthetic equivalents.
+augmented (the reference's RandomGenerator) and assembled by one kernel.  "acdc" / "sup_acdc" read an ACDC-format tree (h5 slices, the reference's list files) through the dependency-free reader
+``h5lite`` into the same HBM pool.  The reference's other real-data keys (LIDC, Synapse, ISIC, Building: png / npz trees with albumentations
+pipelines) are outside the hot-path build and raise NotImplementedError like an unknown key (builder.py:76-77).
 """
 from .synthetic import get_ssl_synthetic_loader, get_synthetic_loader, synth_batch
 
-_REAL = {"acdc", "lidc", "synapse", "isic", "sup_lidc", "sup_acdc", "sup_synapse", "sup_isic", "sup_building"}
+_REAL = {"lidc", "synapse", "isic", "sup_lidc", "sup_synapse", "sup_isic", "sup_building"}
 
 
 def _device_synthetic(args, rank):
@@ -38,6 +38,13 @@ def build_loader(args, rank: int = 0):
         return get_synthetic_loader(args, rank)
     if args.datasets == "device_synthetic":
         return _device_synthetic(args, rank)
+    if args.datasets == "acdc":          # builder.py:10-17: ACDC h5 slices from disk, resident in HBM, augmented on the device
+        from .acdc import get_ssl_acdc_loader
+        return get_ssl_acdc_loader(root=args.data_path, train_crop_size=args.train_crop_size, batch_size=args.batch_size,
+                                   unlabel_batch_size=args.unlabel_batch_size, label_num=args.label_num, device=getattr(args, "device", "cuda"))
+    if args.datasets == "sup_acdc":      # builder.py:45-50
+        from .acdc import get_acdc_loader
+        return get_acdc_loader(root=args.data_path, train_crop_size=args.train_crop_size, batch_size=args.batch_size, device=getattr(args, "device", "cuda"))
     if args.datasets in _REAL:
         raise NotImplementedError(f"dataset '{args.datasets}' (real-data I/O) is outside the MI355X hot-path build; "
                                   f"use 'synthetic' / 'sup_synthetic' (same batch contract)")
