@@ -119,7 +119,9 @@ def test_synthetic_loaders_keep_the_batch_contract():
     tr, te = build_loader(a2)
     assert next(iter(tr))[0].shape == (8, 1, 32, 32)
     with pytest.raises(NotImplementedError):
-        build_loader(AttrDict(datasets="acdc"))
+        build_loader(AttrDict(datasets="lidc"))          # real-data keys outside the hot-path build raise like an unknown key (builder.py:76-77)
+    with pytest.raises(NotImplementedError):
+        build_loader(AttrDict(datasets="no-such-dataset"))
     x1, y1 = synth_batch(5, 2, 32, 32, 3, 2, 8)
     x2, y2 = synth_batch(5, 2, 32, 32, 3, 2, 8)
     assert torch.equal(x1, x2) and torch.equal(y1, y2) and x1.shape == (2, 3, 32, 32) and int(y1.max()) <= 1
