@@ -117,6 +117,10 @@ class UNetEngine:
         # BatchNorm-backward sums of the layer below from the dgrad epilogue (bf16x3 kernels) instead of a streaming pass of their own
         self.fuse_bwd_stats = int(os.environ.get("HPFG_FUSE_BWD_STATS", "1"))      # 2: also the register-starved 32-channel instantiation
         self._fused_rows: Dict[str, int] = {}
+        # thin 3x3 layers (16-pixel-aligned, <= 64 input / 32 output channels, split-bf16 math): ONE kernel produces the input gradient, the
+        # weight-gradient slabs and the backward sums of the layer below from a single staging of dZ (hpfg_fused_bwd)
+        self.fused_bwd = os.environ.get("HPFG_FUSED_BWD", "1") == "1"
+        self.fused_grid: Dict[str, int] = {}
         self._side, self._side_used = None, False
         self.force_sync = False  # run the data-parallel code path (reduce -> all-reduce -> finalize) even with one rank (tests)
         self.math = L.MATH_F32      # L.MATH_BF16X3 selects the split-bf16 matrix-core kernels for conv forward / dgrad
@@ -346,8 +350,10 @@ class UNetEngine:
 
     # ---------------------------------------------------------------------------------------------------------
     def _alloc_bwd(self):
-        if self._bwd_alloc:
+        key = (self.math, self.fused_bwd, self.wgrad_overlap)      # what the slab layout depends on
+        if self._bwd_alloc and self._bwd_alloc_key == key:
             return
+        self._bwd_alloc_key = key
         f32 = dict(dtype=torch.float32, device=self.dev)
         N = self.N
         self.dA: Dict[str, torch.Tensor] = {}
@@ -376,6 +382,20 @@ class UNetEngine:
                                     self.specs[enc_prefix(lvl) + ".0"].cin, **f32) for lvl in range(1, 5)}
         # one slab region per layer; all of them are summed by ONE launch at the end of backward()
         sizes = [self.lib.hpfg_wgrad_slab_floats(N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps) for s in self.order]
+        self.fused_grid = {}
+        if self.fused_bwd and self.math == L.MATH_BF16X3 and self.wgrad_overlap == 0:
+            for i, s in enumerate(self.order):
+                if s.taps != 9 or s.idx == 0:
+                    continue
+                fa = L.FusedBwdArgs()
+                fa.xa0, fa.xa1 = self.input_acts(s.name)
+                fa.d.a0.mode = L.ACT_DZ if s.bn else L.ACT_PLAIN
+                fa.d.N, fa.d.H, fa.d.W, fa.d.taps, fa.d.math = N, s.h, s.w, 9, self.math
+                fa.Cin, fa.CinPad, fa.Cout, fa.CoutPad = s.cin, s.cin_pad, s.cout, s.cout_pad
+                grid = self.lib.hpfg_fused_bwd_grid(C.byref(fa))
+                if grid > 0:
+                    self.fused_grid[s.name] = grid
+                    sizes[i] = max(sizes[i], grid * 9 * s.cin_pad * s.cout_pad)
         self.slab_all = torch.empty(sum(sizes), **f32)
         self.slab_of, off = {}, 0
         # bias gradients of the convs without BatchNorm (1x1 convs, out_conv): their per-block channel sums are summed by the same
@@ -389,7 +409,7 @@ class UNetEngine:
             self.slab_of[s.name] = self.slab_all[off:off + sz]
             off += sz
             d.slab, d.dw_oihw = L.ptr(self.slab_of[s.name]), L.ptr(self.grads[f"{s.name}.weight"])
-            d.S = self.lib.hpfg_wgrad_splits(N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps)
+            d.S = self.fused_grid.get(s.name) or self.lib.hpfg_wgrad_splits(N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps)
             d.taps, d.Cin, d.CinPad, d.Cout, d.CoutPad = s.taps, s.cin, s.cin_pad, s.cout, s.cout_pad
         for j, s in enumerate(self.bias_layers):
             d = descs[len(self.order) + j]
@@ -438,6 +458,8 @@ class UNetEngine:
 
     def _wgrad_dgrad(self, s: ConvSpec, g: L.Act, dgrad_out: torch.Tensor, stats_for: Optional[str] = None, out2: Optional[torch.Tensor] = None):
         """Both gradients of layer s from the same dZ source (they only read it, so their order is free)."""
+        if s.name in self.fused_grid:
+            return self._fused_bwd(s, g, dgrad_out, stats_for, out2)
         g = self.staged_dz(s, g)
         if self.wgrad_overlap == 2:
             self._dgrad(s, g, dgrad_out, stats_for, out2)
@@ -445,6 +467,27 @@ class UNetEngine:
         else:
             self._wgrad(s, g)
             self._dgrad(s, g, dgrad_out, stats_for, out2)
+
+    def _fused_bwd(self, s: ConvSpec, g: L.Act, out: torch.Tensor, stats_for: Optional[str], out2: Optional[torch.Tensor]):
+        """hpfg_fused_bwd: dX into `out` (/ `out2`), the weight-gradient slabs of layer s and -- with stats_for -- the BatchNorm-backward
+        sums of the layer below, from one read of (dA, z) and one read of the layer input."""
+        fa = L.FusedBwdArgs()
+        fa.xa0, fa.xa1 = self.input_acts(s.name)
+        fa.slab = L.ptr(self.slab_of[s.name])
+        fa.Cin, fa.CinPad, fa.Cout, fa.CoutPad = s.cin, s.cin_pad, s.cout, s.cout_pad
+        ca = fa.d
+        ca.a0, ca.math, ca.wpk, ca.out = g, self.math, L.ptr(self.wpk16_d[s.name]), L.ptr(out)
+        ca.out_pstride, ca.Cout, ca.CoutPad = s.cin, s.cin, s.cin_pad
+        if out2 is not None:
+            ca.out2, ca.out_split, ca.out_pstride, ca.out2_pstride = L.ptr(out2), s.cin // 2, s.cin // 2, s.cin // 2
+        ca.N, ca.H, ca.W, ca.taps = self.N, s.h, s.w, 9
+        rows = self.fused_grid[s.name]
+        if stats_for is not None and self.fuse_bwd_stats and s.cin == s.cin_pad and out2 is None:
+            if rows * 2 * s.cin > self.partials.numel():
+                raise RuntimeError(f"fused_bwd[{s.name}]: {rows} rows of backward sums do not fit the partials workspace")
+            ca.bwd_stats, ca.bwd_of, ca.stat_partials = 1, self._act_dz(stats_for, out, s.cin), L.ptr(self.partials)
+            self._fused_rows[stats_for] = rows
+        L.check(self.lib.hpfg_fused_bwd(C.byref(fa), self._stream()), f"fused_bwd[{s.name}]")
 
     def _wgrad(self, s: ConvSpec, g: L.Act):
         """Weight gradient of layer s.  It is off the critical chain of backward (nothing downstream consumes it before the final

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 120
+#define HPFG_VERSION 121
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -99,6 +99,14 @@ typedef struct HpfgWgradArgs {
   int32_t defer_reduce; /* 1: leave the slabs in `slab`; the caller sums them later with hpfg_slab_reduce_multi (one launch per backward) */
 } HpfgWgradArgs;
 
+typedef struct HpfgFusedBwdArgs {   /* hpfg_fused_bwd: both gradients of a thin 3x3 layer from ONE staging of dZ (see below) */
+  HpfgConvArgs d;       /* the dgrad side exactly as hpfg_conv_fwd takes it: a0 = dZ (DZ or PLAIN), wpk = wpk16_dgrad, out / out2 = dX,
+                           Cout / CoutPad = the layer's Cin / CinPad, bwd_stats / bwd_of / stat_partials; math = HPFG_MATH_BF16X3 */
+  HpfgAct xa0, xa1;     /* the layer's input as in forward (BNACT | BNACT_POOL | [BNACT | UP2X]) */
+  float* slab;          /* [hpfg_fused_bwd_grid()][9][CinPad][CoutPad]: per-workgroup weight-gradient sums (hpfg_slab_reduce_multi) */
+  int32_t Cin, CinPad, Cout, CoutPad;   /* of the layer: dW is [Cout][Cin][3][3] */
+} HpfgFusedBwdArgs;
+
 typedef struct HpfgSlabDesc {   /* one layer of hpfg_slab_reduce_multi: dw_oihw[co][ci][tap] = sum_s slab[s][tap][ci][co] */
   const float* slab;
   float* dw_oihw;
@@ -165,6 +173,13 @@ int hpfg_bn_bwd_pool_blocks(int N, int Hp, int Wp, int C);
 int hpfg_bn_bwd_finalize(const float* partials, int nblk, const double* sums, double count, const float* gamma,
                          float* bn, float* dgamma, float* dbeta, int C, float param_grad_scale, void* stream);
 int hpfg_wgrad(const HpfgWgradArgs* args, void* stream);
+/* Fused backward of a thin 3x3 layer (bf16x3; H, W multiples of 16; CinPad <= 64, CoutPad <= 32): dX (as hpfg_conv_fwd with a dZ source,
+ * including the bwd_stats epilogue and out2) AND the weight-gradient slabs (as hpfg_wgrad with defer_reduce) from one read of (dA, z) and
+ * one read of the layer input -- replaces reference loss.backward()'s separate conv-transpose and weight-gradient kernels of one Conv2d
+ * (model/unet.py:18,22).  hpfg_fused_bwd_grid: workgroups of the launch = slabs = rows of d.stat_partials; 0 = shape not instantiated
+ * (the caller then uses hpfg_wgrad + hpfg_conv_fwd). */
+int hpfg_fused_bwd(const HpfgFusedBwdArgs* args, void* stream);
+int hpfg_fused_bwd_grid(const HpfgFusedBwdArgs* args);
 int hpfg_slab_reduce_multi(const HpfgSlabDesc* table_dev, const HpfgSlabDesc* table_host, int nlayers, void* stream);
 int hpfg_wgrad_splits(int N, int H, int W, int CinPad, int CoutPad, int taps);
 long hpfg_wgrad_slab_floats(int N, int H, int W, int CinPad, int CoutPad, int taps);

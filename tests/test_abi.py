@@ -29,7 +29,7 @@ def test_struct_layouts_match_header_field_order():
     src = open(os.path.join(ROOT, "include", "hpfg_hip.h")).read()
     for cname, pyt in (("HpfgAct", L.Act), ("HpfgConvArgs", L.ConvArgs), ("HpfgWgradArgs", L.WgradArgs), ("HpfgPackDesc", L.PackDesc),
                        ("HpfgLossArgs", L.LossArgs), ("HpfgAugSample", L.AugSample), ("HpfgSlabDesc", L.SlabDesc),
-                       ("HpfgPredBlocks", L.PredBlocks)):
+                       ("HpfgPredBlocks", L.PredBlocks), ("HpfgFusedBwdArgs", L.FusedBwdArgs)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []
@@ -50,6 +50,7 @@ def test_argument_errors_are_reported_not_crashed():
     assert lib.hpfg_conv_fwd(None, None) == -1
     assert b"null" in lib.hpfg_last_error()
     assert lib.hpfg_wgrad(None, None) == -1
+    assert lib.hpfg_fused_bwd(None, None) == -1 and lib.hpfg_fused_bwd_grid(None) == -1
     assert lib.hpfg_conv_stat_blocks(2, 32, 32) == 2 * 4 and lib.hpfg_conv_stat_blocks(1, 24, 24) == 12
     assert lib.hpfg_wgrad_splits(16, 224, 224, 16, 16, 9) >= 1
     assert ctypes.sizeof(L.Act) % 8 == 0

@@ -1,0 +1,137 @@
+"""GPU: hpfg_fused_bwd (one kernel: dgrad + BatchNorm-backward sums + weight-gradient slabs of a thin 3x3 layer) against the separate
+hpfg_conv_fwd (dgrad) and hpfg_wgrad launches on the same virtual sources, and against plain PyTorch fp32 autograd on the CPU."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hpfg_amd import _lib as L
+from tests.helpers import AdHocConv, maxerr, nchw, plain_act, stream
+from tests.test_gpu_kernels import _bn_table, _materialize
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _bnact(z, tab, C_, H, W, mode=L.ACT_BNACT, p=0.0, seed=0):
+    a = L.Act()
+    a.z, a.bn, a.mode, a.C, a.Hs, a.Ws, a.pstride, a.bn_stride = L.ptr(z), L.ptr(tab), mode, C_, H, W, C_, C_
+    a.drop_p, a.drop_seed = p, seed
+    return a
+
+
+def _dz(z, tab, dA, C_, H, W, p=0.0, seed=0):
+    d = L.Act()
+    d.z, d.bn, d.mode, d.C, d.Hs, d.Ws, d.pstride, d.aux_pstride, d.bn_stride = L.ptr(z), L.ptr(tab), L.ACT_DZ, C_, H, W, C_, C_, C_
+    if dA is not None:
+        d.aux = L.ptr(dA)
+    d.drop_p, d.drop_seed = p, seed
+    return d
+
+
+def _fused(layer, xa0, xa1, g, N, H, W, bwd_of=None, split=0):
+    """-> dX [N,H,W,cin] (or the two halves), dW [cout,cin,3,3], backward-sum rows or None"""
+    lib = L.load()
+    fa = L.FusedBwdArgs()
+    fa.xa0, fa.xa1 = xa0, (xa1 if xa1 is not None else L.Act())
+    fa.Cin, fa.CinPad, fa.Cout, fa.CoutPad = layer.cin, layer.cin_pad, layer.cout, layer.cout_pad
+    d = fa.d
+    d.a0, d.a1, d.math, d.wpk = g, L.Act(), L.MATH_BF16X3, L.ptr(layer.wpk16_d)
+    d.Cout, d.CoutPad, d.N, d.H, d.W, d.taps = layer.cin, layer.cin_pad, N, H, W, 9
+    if split:
+        out = torch.full((N, H, W, split), float("nan"), device=DEV)
+        out2 = torch.full((N, H, W, layer.cin - split), float("nan"), device=DEV)
+        d.out, d.out2, d.out_split, d.out_pstride, d.out2_pstride = L.ptr(out), L.ptr(out2), split, split, layer.cin - split
+    else:
+        out = torch.full((N, H, W, layer.cin), float("nan"), device=DEV)
+        out2 = None
+        d.out, d.out_pstride = L.ptr(out), layer.cin
+    grid = lib.hpfg_fused_bwd_grid(C.byref(fa))
+    assert grid > 0, lib.hpfg_last_error()
+    part = None
+    if bwd_of is not None:
+        part = torch.full((grid, 2, layer.cin_pad), float("nan"), device=DEV)
+        d.bwd_stats, d.bwd_of, d.stat_partials = 1, bwd_of, L.ptr(part)
+    slab = torch.full((grid, 9, layer.cin_pad, layer.cout_pad), float("nan"), device=DEV)
+    fa.slab = L.ptr(slab)
+    L.check(lib.hpfg_fused_bwd(C.byref(fa), stream(DEV)), "fused_bwd")
+    torch.cuda.synchronize()
+    dw = slab.double().sum(0)[:, :layer.cin, :layer.cout].permute(2, 1, 0).reshape(layer.cout, layer.cin, 3, 3).float()
+    return (out if out2 is None else (out, out2)), dw, part
+
+
+CASES = [  # N, H, W, cin, cout, input kind, dZ kind, p_in, p_out
+    (2, 32, 48, 16, 16, "bnact", "dz", 0.05, 0.0),     # in_conv.c2 / up4.c2
+    (3, 32, 32, 16, 16, "bnact", "dz", 0.0, 0.3),
+    (2, 32, 32, 16, 4, "bnact", "plain", 0.0, 0.0),    # out_conv
+    (2, 32, 32, 16, 2, "bnact", "plain", 0.0, 0.0),
+    (2, 32, 16, 16, 32, "pool", "dz", 0.0, 0.1),       # down1.c1
+    (2, 16, 48, 32, 32, "bnact", "dz", 0.1, 0.0),      # down1.c2 / up3.c2
+    (2, 32, 32, 32, 16, "cat", "dz", 0.0, 0.0),        # up4.c1
+    (2, 32, 32, 32, 16, "cat", "dz", 0.0, 0.0),        # (up3.c1, 64 -> 32, is not instantiated: its weight fragments do not fit LDS)
+    (7, 64, 64, 16, 16, "bnact", "dz", 0.0, 0.0),      # more tiles than one round of workgroups x several tiles each
+]
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,ak,gk,p_in,p_out", CASES)
+def test_fused_bwd_equals_separate_kernels_and_autograd(N, H, W, cin, cout, ak, gk, p_in, p_out):
+    g = torch.Generator().manual_seed(H * 7 + cin * 3 + cout)
+    layer = AdHocConv(cin, cout, 9, DEV, seed=cin + cout, hw=(H, W))
+    # ---- layer input
+    xa1 = None
+    if ak == "bnact":
+        zi = torch.randn(N, H, W, cin, generator=g).to(DEV)
+        tabi = _bn_table(cin, 3).to(DEV)
+        xa0 = _bnact(zi, tabi, cin, H, W, p=p_in, seed=77)
+    elif ak == "pool":
+        zi = torch.randn(N, 2 * H, 2 * W, cin, generator=g).to(DEV)
+        tabi = _bn_table(cin, 3).to(DEV)
+        xa0 = _bnact(zi, tabi, cin, 2 * H, 2 * W, mode=L.ACT_BNACT_POOL)
+    else:
+        c2 = cin // 2
+        zi = torch.randn(N, H, W, c2, generator=g).to(DEV)
+        tabi = _bn_table(c2, 3).to(DEV)
+        xa0 = _bnact(zi, tabi, c2, H, W)
+        ud = torch.randn(N, H // 2, W // 2, c2, generator=g).to(DEV)
+        xa1 = L.Act()
+        xa1.z, xa1.mode, xa1.C, xa1.Hs, xa1.Ws, xa1.pstride = L.ptr(ud), L.ACT_UP2X, c2, H // 2, W // 2, c2
+    # ---- dZ source
+    if gk == "dz":
+        zo = torch.randn(N, H, W, cout, generator=g).to(DEV)
+        dA = torch.randn(N, H, W, cout, generator=g).to(DEV)
+        tabo = _bn_table(cout, 11).to(DEV)
+        gsrc = _dz(zo, tabo, dA, cout, H, W, p=p_out, seed=99)
+    else:
+        dl = torch.randn(N, H, W, cout, generator=g).to(DEV)
+        gsrc = plain_act(dl, cout, H, W)
+    # ---- the layer below (whose backward sums the dgrad epilogue produces): only for un-split, un-padded outputs
+    bwd_of = None
+    if ak == "bnact":
+        bwd_of = _dz(zi, tabi, None, cin, H, W, p=p_in, seed=77)
+    split = cin // 2 if (ak == "cat" and cin == 32) else 0
+    dx, dw, part = _fused(layer, xa0, xa1, gsrc, N, H, W, bwd_of=bwd_of, split=split)
+    # ---- the separate launches on the same sources
+    dx_ref, _ = layer.conv(gsrc, None, N, H, W, dgrad=True, math=L.MATH_BF16X3)
+    dw_ref = layer.wgrad(xa0, xa1, gsrc, N, H, W, math=L.MATH_BF16X3)
+    if split:
+        dx = torch.cat([dx[0], dx[1]], -1)
+    assert torch.equal(dx, dx_ref), f"dgrad differs: {maxerr(dx.cpu(), dx_ref.cpu())}"      # same fragments, same order of MFMAs
+    assert maxerr(dw.cpu(), dw_ref.cpu()) < 1e-5 * max(1.0, float(dw_ref.abs().max()))      # other summation order over pixels
+    # ---- plain PyTorch fp32 on the CPU
+    a_in = _materialize(xa0, xa1, N, H, W, cin)
+    dz = _materialize(gsrc, None, N, H, W, cout)
+    xr = nchw(a_in).requires_grad_(True)
+    wr = layer.w.cpu().clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, padding=1).backward(nchw(dz))
+    assert maxerr(nchw(dx.cpu()), xr.grad) < 3e-4 * max(1.0, float(xr.grad.abs().max()))
+    assert maxerr(dw.cpu(), wr.grad) < 5e-4 * max(1.0, float(wr.grad.abs().max()))
+    if part is not None:
+        # sum(g), sum(g * xhat) of the layer below with g = dX * dropout * LeakyReLU'
+        lib = L.load()
+        bo = _dz(zi, tabi, dx_ref, cin, H, W, p=p_in, seed=77)
+        nblk = lib.hpfg_bn_bwd_blocks(N, H, W, cin)
+        ref = torch.empty(nblk, 2, cin, device=DEV)
+        L.check(lib.hpfg_bn_bwd_reduce(C.byref(bo), N, H, W, L.ptr(ref), stream(DEV)), "bn_bwd_reduce")
+        ps, rs = part.double().sum(0).cpu(), ref.double().sum(0).cpu()
+        assert maxerr(ps[:, :cin], rs) < 1e-4 * max(1.0, float(rs.abs().max()))
