@@ -69,11 +69,20 @@ __device__ inline void sum_partials(const float* __restrict__ partials, int nblk
 }
 
 // grid = C blocks; partials [nblk][2][C]
-__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __restrict__ partials, int nblk, const double* __restrict__ sums,
-                                                              double count, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              float* running_mean, float* running_var, float momentum, float eps,
-                                                              float* __restrict__ bn, int C) {
+struct FinalizePair {
+  HpfgBnFinalizeArgs g[2];
+};
+template <bool PAIR>
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(FinalizePair pp, int nblk, const double* __restrict__ sums, double count, float momentum,
+                                                              float eps, int C) {
   __shared__ double sh[8];
+  const HpfgBnFinalizeArgs& q = pp.g[PAIR ? blockIdx.y : 0];      // blockIdx.y: which of the two layers sharing the launch
+  const float* __restrict__ partials = q.partials;
+  const float* __restrict__ gamma = q.gamma;
+  const float* __restrict__ beta = q.beta;
+  float* running_mean = q.running_mean;
+  float* running_var = q.running_var;
+  float* __restrict__ bn = q.bn;
   const int c = blockIdx.x;
   const float ga = gamma[c], be = beta[c];                       // requested up front: off the dependent chain below
   const float rm = running_mean ? running_mean[c] : 0.f, rv = running_mean ? running_var[c] : 0.f;
@@ -288,8 +297,21 @@ extern "C" int hpfg_bn_fwd_finalize(const float* partials, int nblk, const doubl
                                     float* running_mean, float* running_var, float momentum, float eps, float* bn, int C, void* stream) {
   HPFG_ARG_CHECK((partials && nblk > 0) || sums, "bn_fwd_finalize: need partials or sums");
   HPFG_ARG_CHECK(gamma && beta && bn && C > 0 && count > 0, "bn_fwd_finalize: bad args");
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nblk, sums, count, gamma, beta, running_mean,
-                     running_var, momentum, eps, bn, C);
+  FinalizePair pp;
+  pp.g[0] = HpfgBnFinalizeArgs{partials, gamma, beta, running_mean, running_var, bn};
+  pp.g[1] = pp.g[0];
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel<false>, dim3(C), dim3(256), 0, (hipStream_t)stream, pp, nblk, sums, count, momentum, eps, C);
+  return hpfg_launch_status("bn_fwd_finalize_kernel");
+}
+
+extern "C" int hpfg_bn_fwd_finalize_pair(const HpfgBnFinalizeArgs* a, const HpfgBnFinalizeArgs* b, int nblk, double count, float momentum, float eps,
+                                         int C, void* stream) {
+  HPFG_ARG_CHECK(a && b && a->partials && b->partials && nblk > 0, "bn_fwd_finalize_pair: need the partial sums of both layers");
+  HPFG_ARG_CHECK(a->gamma && a->beta && a->bn && b->gamma && b->beta && b->bn && a->bn != b->bn && C > 0 && count > 0, "bn_fwd_finalize_pair: bad args");
+  FinalizePair pp;
+  pp.g[0] = *a;
+  pp.g[1] = *b;
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel<true>, dim3(C, 2), dim3(256), 0, (hipStream_t)stream, pp, nblk, nullptr, count, momentum, eps, C);
   return hpfg_launch_status("bn_fwd_finalize_kernel");
 }
 

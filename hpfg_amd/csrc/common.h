@@ -215,6 +215,12 @@ __device__ static inline f32x4 cat_load4(const HpfgAct& a0, const ActCtx& c0, co
 
 
 // ---- single-mode loaders (compile-time mode): keep the conv kernels' staging code small and register-light -------------
+// Kernel argument of the bf16x3 conv kernels: up to two independent layers of identical geometry (the same conv of the student and the
+// teacher network, hpfg_conv_fwd_pair) share one launch; blockIdx.z (3x3) / blockIdx.y / N (1x1) selects the set.
+struct HpfgConvPair {
+  HpfgConvArgs g[2];
+};
+
 enum { HPFG_KIND_PLAIN = 0, HPFG_KIND_BNACT = 1, HPFG_KIND_POOL = 2, HPFG_KIND_CAT = 3, HPFG_KIND_DZ = 4, HPFG_KIND_PLANES = 5 };
 
 template <int MODE>

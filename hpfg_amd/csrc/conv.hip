@@ -23,10 +23,18 @@ inline bool tile_is_big(int H, int W) { return (H % 16 == 0) && (W % 16 == 0); }
 // Persistent: a workgroup walks tiles w = blockIdx.x, + gridDim.x, ...; the BatchNorm partial sums stay in registers across its
 // tiles and are reduced once (the per-tile wave butterfly of 32 values used to cost more than the 144 FMAs of the convolution),
 // so the layer also hands only gridDim.x rows to the finalize instead of one per tile.
-__global__ __launch_bounds__(256) void conv_first_kernel(HpfgAct x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                         float* __restrict__ out, float* __restrict__ stat, int N, int H, int W,
-                                                         int Cin, int tiles_x, int tiles_y) {
+struct FirstPair {
+  HpfgFirstConvArgs g[2];
+};
+template <bool PAIR>
+__global__ __launch_bounds__(256) void conv_first_kernel(FirstPair pp, int N, int H, int W, int Cin, int tiles_x, int tiles_y) {
   constexpr int T = 16, TP = T + 2, CO = 16;
+  const HpfgFirstConvArgs& q = pp.g[PAIR ? blockIdx.y : 0];      // blockIdx.y: which of the two networks sharing the launch
+  const HpfgAct& x = q.x;
+  const float* __restrict__ w = q.w_oihw;
+  const float* __restrict__ bias = q.bias;
+  float* __restrict__ out = q.out;
+  float* __restrict__ stat = q.stat_partials;
   __shared__ float tin[4][TP * TP];
   __shared__ __attribute__((aligned(16))) float wl[9 * 4 * CO];
   __shared__ float red[2][4][CO];
@@ -116,9 +124,24 @@ extern "C" int hpfg_conv_stat_blocks(int N, int H, int W) {
 
 extern "C" int hpfg_conv_first_rows(int N, int H, int W) { return conv_first_grid(N, H, W); }
 
-static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only);
+static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only, const HpfgConvArgs* b = nullptr);
 
 extern "C" int hpfg_conv_fwd(const HpfgConvArgs* a, void* stream) { return conv_fwd_impl(a, stream, nullptr); }
+
+// Two layers of identical geometry (the same conv of two networks) in one launch: b goes through a's checks, then the geometry is compared.
+extern "C" int hpfg_conv_fwd_pair(const HpfgConvArgs* a, const HpfgConvArgs* b, void* stream) {
+  HPFG_ARG_CHECK(a && b, "conv_fwd_pair: null pointer");
+  HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && b->math == a->math, "conv_fwd_pair: split-bf16 math mode only, the same for both");
+  HPFG_ARG_CHECK(!a->bwd_stats && !b->bwd_stats && !a->out_split && !b->out_split, "conv_fwd_pair: forward convolutions only");
+  HPFG_ARG_CHECK(a->taps == b->taps && a->N == b->N && a->H == b->H && a->W == b->W && a->Cout == b->Cout && a->CoutPad == b->CoutPad &&
+                     a->a0.C == b->a0.C && a->a1.C == b->a1.C && hpfg_kind_of(a->a0, a->a1) == hpfg_kind_of(b->a0, b->a1) &&
+                     a->a0.mode == b->a0.mode && (a->stat_partials != nullptr) == (b->stat_partials != nullptr) && (a->bias != nullptr) == (b->bias != nullptr),
+                 "conv_fwd_pair: the two layers must have the same geometry, source kinds and outputs");
+  HPFG_ARG_CHECK(a->out != b->out && (!a->stat_partials || a->stat_partials != b->stat_partials), "conv_fwd_pair: the two layers must write different buffers");
+  int rows = 0;
+  if (conv_fwd_impl(b, nullptr, &rows)) return -1;      // b's own argument checks
+  return conv_fwd_impl(a, stream, nullptr, b);
+}
 
 // rows of stat_partials ([rows][2][CoutPad]) that hpfg_conv_fwd(args) fills; <0 on argument errors
 extern "C" int hpfg_conv_stat_rows(const HpfgConvArgs* a) {
@@ -127,7 +150,7 @@ extern "C" int hpfg_conv_stat_rows(const HpfgConvArgs* a) {
   return rc ? -1 : rows;
 }
 
-static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
+static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only, const HpfgConvArgs* b) {
   HPFG_ARG_CHECK(a && a->wpk && a->out, "conv_fwd: null pointer");
   HPFG_ARG_CHECK(a->taps == 9 || a->taps == 1, "conv_fwd: taps must be 1 or 9 (got %d)", a->taps);
   HPFG_ARG_CHECK(a->CoutPad % 16 == 0 && a->Cout <= a->CoutPad && a->Cout > 0, "conv_fwd: bad Cout %d / pad %d", a->Cout, a->CoutPad);
@@ -149,14 +172,14 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
   }
   if ((a->math & 0xff) == HPFG_MATH_BF16X3) {
     switch (hpfg_kind_of(a->a0, a->a1)) {
-      case HPFG_KIND_PLAIN: return hpfg_conv16_launch_plain(*a, st, rows_only);
-      case HPFG_KIND_BNACT: return hpfg_conv16_launch_bnact(*a, st, rows_only);
-      case HPFG_KIND_POOL: return hpfg_conv16_launch_pool(*a, st, rows_only);
-      case HPFG_KIND_CAT: return hpfg_conv16_launch_cat(*a, st, rows_only);
-      case HPFG_KIND_DZ: return hpfg_conv16_launch_dz(*a, st, rows_only);
+      case HPFG_KIND_PLAIN: return hpfg_conv16_launch_plain(*a, st, rows_only, b);
+      case HPFG_KIND_BNACT: return hpfg_conv16_launch_bnact(*a, st, rows_only, b);
+      case HPFG_KIND_POOL: return hpfg_conv16_launch_pool(*a, st, rows_only, b);
+      case HPFG_KIND_CAT: return hpfg_conv16_launch_cat(*a, st, rows_only, b);
+      case HPFG_KIND_DZ: return hpfg_conv16_launch_dz(*a, st, rows_only, b);
       case HPFG_KIND_PLANES:
         HPFG_ARG_CHECK(a->a0.C % 8 == 0 && a->a0.pstride % 8 == 0, "conv_fwd: a PLANES source needs C %% 8 == 0 (got %d)", a->a0.C);
-        return hpfg_conv16_launch_planes(*a, st, rows_only);
+        return hpfg_conv16_launch_planes(*a, st, rows_only, b);
       default: break;
     }
     hpfg_set_error("conv_fwd(bf16x3): unsupported source combination (a0.mode=%d, a1.mode=%d)", a->a0.mode, a->a1.mode);
@@ -179,15 +202,33 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
   return -1;
 }
 
+static int conv_first_impl(const HpfgFirstConvArgs* a, const HpfgFirstConvArgs* b, int N, int H, int W, int Cin, int Cout, void* stream) {
+  HPFG_ARG_CHECK(Cin >= 1 && Cin <= 4 && Cout == 16, "conv_first: needs Cin<=4, Cout==16 (got %d,%d)", Cin, Cout);
+  for (const HpfgFirstConvArgs* q : {a, b}) {
+    if (!q) continue;
+    HPFG_ARG_CHECK(q->x.z && q->w_oihw && q->bias && q->out, "conv_first: null pointer");
+    HPFG_ARG_CHECK(q->x.mode == HPFG_ACT_STRIDED, "conv_first: input must be a STRIDED source");
+    // stat partial layout must match hpfg_conv_stat_blocks(): 16x16 tiles only when H,W are multiples of 16
+    HPFG_ARG_CHECK(q->stat_partials == nullptr || tile_is_big(H, W), "conv_first: BN partials need H,W multiples of 16 (got %dx%d)", H, W);
+  }
+  HPFG_ARG_CHECK(!b || (a->out != b->out && (a->stat_partials != nullptr) == (b->stat_partials != nullptr)), "conv_first_pair: outputs must differ");
+  int tx = (W + 15) / 16, ty = (H + 15) / 16;
+  FirstPair pp;
+  pp.g[0] = *a;
+  pp.g[1] = b ? *b : *a;
+  if (b) hipLaunchKernelGGL(conv_first_kernel<true>, dim3(conv_first_grid(N, H, W), 2), dim3(256), 0, (hipStream_t)stream, pp, N, H, W, Cin, tx, ty);
+  else hipLaunchKernelGGL(conv_first_kernel<false>, dim3(conv_first_grid(N, H, W)), dim3(256), 0, (hipStream_t)stream, pp, N, H, W, Cin, tx, ty);
+  return hpfg_launch_status("conv_first_kernel");
+}
+
 extern "C" int hpfg_conv3x3_first_fwd(const HpfgAct* x, const float* w_oihw, const float* bias, float* out, float* stat_partials,
                                       int N, int H, int W, int Cin, int Cout, void* stream) {
-  HPFG_ARG_CHECK(x && w_oihw && bias && out, "conv_first: null pointer");
-  HPFG_ARG_CHECK(Cin >= 1 && Cin <= 4 && Cout == 16, "conv_first: needs Cin<=4, Cout==16 (got %d,%d)", Cin, Cout);
-  HPFG_ARG_CHECK(x->mode == HPFG_ACT_STRIDED, "conv_first: input must be a STRIDED source");
-  int tx = (W + 15) / 16, ty = (H + 15) / 16;
-  // stat partial layout must match hpfg_conv_stat_blocks(): 16x16 tiles only when H,W are multiples of 16
-  HPFG_ARG_CHECK(stat_partials == nullptr || tile_is_big(H, W), "conv_first: BN partials need H,W multiples of 16 (got %dx%d)", H, W);
-  hipLaunchKernelGGL(conv_first_kernel, dim3(conv_first_grid(N, H, W)), dim3(256), 0, (hipStream_t)stream, *x, w_oihw, bias, out, stat_partials,
-                     N, H, W, Cin, tx, ty);
-  return hpfg_launch_status("conv_first_kernel");
+  HPFG_ARG_CHECK(x, "conv_first: null pointer");
+  HpfgFirstConvArgs a = {*x, w_oihw, bias, out, stat_partials};
+  return conv_first_impl(&a, nullptr, N, H, W, Cin, Cout, stream);
+}
+
+extern "C" int hpfg_conv3x3_first_fwd_pair(const HpfgFirstConvArgs* a, const HpfgFirstConvArgs* b, int N, int H, int W, int Cin, int Cout, void* stream) {
+  HPFG_ARG_CHECK(a && b, "conv_first_pair: null pointer");
+  return conv_first_impl(a, b, N, H, W, Cin, Cout, stream);
 }

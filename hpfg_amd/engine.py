@@ -280,37 +280,44 @@ class UNetEngine:
             L.check(self.lib.hpfg_bn_fwd_finalize(L.ptr(self.partials), nblk, None, count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), BN_MOMENTUM,
                                                   BN_EPS, L.ptr(self.bn[s.name]), s.cout, st), "bn_fwd_finalize")
 
-    def forward(self, x: torch.Tensor, train: bool = True, dropout: Optional[bool] = None, track_running: bool = True,
-                seed_step: Optional[int] = None, needs_grad: bool = True) -> torch.Tensor:
-        """x: [N,C,H,W] fp32 on the device (any strides).  Returns logits as an [N,H,W,ncls] tensor (fresh allocation)."""
+    def _fwd_begin(self, x: torch.Tensor, train: bool, dropout: Optional[bool], seed_step: Optional[int], needs_grad: bool) -> torch.Tensor:
         assert x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (self.N, self.in_ch, self.H, self.W), (x.shape, x.dtype, x.device)
-        st = self._stream()
         self.x = x
         self.train_mode = train
         self.dropout_on = train if dropout is None else dropout
         if seed_step is not None:
             self.seed_dev.fill_(int(seed_step) & 0x7FFFFFFF)
         self.pack(with_dgrad=bool(train and needs_grad))
-        logits = torch.empty(self.N, self.H, self.W, self.ncls, dtype=torch.float32, device=self.dev)
+        return torch.empty(self.N, self.H, self.W, self.ncls, dtype=torch.float32, device=self.dev)
+
+    def _conv_args(self, s: ConvSpec, out: torch.Tensor, want_stats: bool) -> L.ConvArgs:
+        ca = L.ConvArgs()
+        ca.a0, ca.a1 = self.staged_inputs(s, fresh=True)
+        ca.math = self.math
+        ca.wpk = L.ptr(self.wpk16_f[s.name]) if self.math == L.MATH_BF16X3 else L.ptr(self.wpk_f[s.name])
+        ca.bias, ca.out = L.ptr(self.bias_pad[s.name]), L.ptr(out)
+        ca.stat_partials = L.ptr(self.partials) if want_stats else None
+        ca.out_pstride, ca.Cout, ca.CoutPad = s.cout, s.cout, s.cout_pad
+        ca.N, ca.H, ca.W, ca.taps = self.N, s.h, s.w, s.taps
+        return ca
+
+    def forward(self, x: torch.Tensor, train: bool = True, dropout: Optional[bool] = None, track_running: bool = True,
+                seed_step: Optional[int] = None, needs_grad: bool = True) -> torch.Tensor:
+        """x: [N,C,H,W] fp32 on the device (any strides).  Returns logits as an [N,H,W,ncls] tensor (fresh allocation)."""
+        st = self._stream()
+        logits = self._fwd_begin(x, train, dropout, seed_step, needs_grad)
         for s in self.order:
-            a0, a1 = self.staged_inputs(s, fresh=True)
             out = logits if s.name == "decoder.out_conv" else self.z[s.name]
             want_stats = bool(s.bn) and train
             nblk = self.lib.hpfg_conv_stat_blocks(self.N, s.h, s.w)
             if s.idx == 0:
+                a0, _ = self.staged_inputs(s, fresh=True)
                 L.check(self.lib.hpfg_conv3x3_first_fwd(C.byref(a0), L.ptr(self.params[f"{s.name}.weight"]), L.ptr(self.params[f"{s.name}.bias"]),
                                                         L.ptr(out), L.ptr(self.partials) if want_stats else None, self.N, s.h, s.w, s.cin, s.cout, st),
                         "conv3x3_first_fwd")
                 nblk = self.lib.hpfg_conv_first_rows(self.N, s.h, s.w)
             else:
-                ca = L.ConvArgs()
-                ca.a0, ca.a1 = a0, a1
-                ca.math = self.math
-                ca.wpk = L.ptr(self.wpk16_f[s.name]) if self.math == L.MATH_BF16X3 else L.ptr(self.wpk_f[s.name])
-                ca.bias, ca.out = L.ptr(self.bias_pad[s.name]), L.ptr(out)
-                ca.stat_partials = L.ptr(self.partials) if want_stats else None
-                ca.out_pstride, ca.Cout, ca.CoutPad = s.cout, s.cout, s.cout_pad
-                ca.N, ca.H, ca.W, ca.taps = self.N, s.h, s.w, s.taps
+                ca = self._conv_args(s, out, want_stats)
                 probe = self.probe is not None and self.probe[0] == s.name
                 if probe:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -330,6 +337,50 @@ class UNetEngine:
                                                         L.ptr(self.bn[s.name]), s.cout, st), "bn_eval_table")
         self.bwd_ready = bool(train and needs_grad)
         return logits
+
+    def pairable(self, other: "UNetEngine") -> bool:
+        """Can forward_pair() run this engine and `other` layer by layer in shared launches?"""
+        return (other is not self and (self.N, self.H, self.W, self.in_ch, self.ncls) == (other.N, other.H, other.W, other.in_ch, other.ncls)
+                and self.dev == other.dev and self.math == L.MATH_BF16X3 and other.math == L.MATH_BF16X3
+                and self.world == 1 and other.world == 1 and not self.force_sync and not other.force_sync
+                and not self.use_planes and not other.use_planes and self.probe is None and other.probe is None)
+
+    @staticmethod
+    def forward_pair(ea: "UNetEngine", eb: "UNetEngine", xa: torch.Tensor, xb: torch.Tensor, track_running=(True, True), seed_steps=(None, None),
+                     needs_grad=(True, False)):
+        """Train-mode forward of two networks of identical geometry (student + teacher of Mean-Teacher, 2017_03_NIPS_Mean-Teacher_ACDC.py:94-101;
+        the two students of CPS), every layer of both in ONE launch (hpfg_conv_fwd_pair, hpfg_bn_fwd_finalize_pair).  Results are bit-identical
+        to ea.forward(xa), eb.forward(xb); the step has half the forward launches and no second stream competing for the chip."""
+        assert ea.pairable(eb)
+        lib, st = ea.lib, ea._stream()
+        la = ea._fwd_begin(xa, True, None, seed_steps[0], needs_grad[0])
+        lb = eb._fwd_begin(xb, True, None, seed_steps[1], needs_grad[1])
+        for s in ea.order:
+            oa = la if s.name == "decoder.out_conv" else ea.z[s.name]
+            ob = lb if s.name == "decoder.out_conv" else eb.z[s.name]
+            want_stats = bool(s.bn)
+            if s.idx == 0:
+                fa, fb = L.FirstConvArgs(), L.FirstConvArgs()
+                for f, e, o in ((fa, ea, oa), (fb, eb, ob)):
+                    f.x, _ = e.staged_inputs(s, fresh=True)
+                    f.w_oihw, f.bias, f.out = L.ptr(e.params[f"{s.name}.weight"]), L.ptr(e.params[f"{s.name}.bias"]), L.ptr(o)
+                    f.stat_partials = L.ptr(e.partials) if want_stats else None
+                L.check(lib.hpfg_conv3x3_first_fwd_pair(C.byref(fa), C.byref(fb), ea.N, s.h, s.w, s.cin, s.cout, st), "conv3x3_first_fwd_pair")
+                nblk = lib.hpfg_conv_first_rows(ea.N, s.h, s.w)
+            else:
+                ca, cb = ea._conv_args(s, oa, want_stats), eb._conv_args(s, ob, want_stats)
+                L.check(lib.hpfg_conv_fwd_pair(C.byref(ca), C.byref(cb), st), f"conv_fwd_pair[{s.name}]")
+                nblk = lib.hpfg_conv_stat_rows(C.byref(ca)) if want_stats else 0
+            if s.bn:
+                qa, qb = L.BnFinalizeArgs(), L.BnFinalizeArgs()
+                for q, e, track in ((qa, ea, track_running[0]), (qb, eb, track_running[1])):
+                    q.partials, q.gamma, q.beta, q.bn = L.ptr(e.partials), L.ptr(e.params[f"{s.bn}.weight"]), L.ptr(e.params[f"{s.bn}.bias"]), L.ptr(e.bn[s.name])
+                    q.running_mean = L.ptr(e.buffers[f"{s.bn}.running_mean"]) if track else None
+                    q.running_var = L.ptr(e.buffers[f"{s.bn}.running_var"]) if track else None
+                L.check(lib.hpfg_bn_fwd_finalize_pair(C.byref(qa), C.byref(qb), nblk, float(ea.N * s.h * s.w), BN_MOMENTUM, BN_EPS, s.cout, st),
+                        "bn_fwd_finalize_pair")
+        ea.bwd_ready, eb.bwd_ready = bool(needs_grad[0]), bool(needs_grad[1])
+        return la, lb
 
     def materialize(self, name: str, mode=L.ACT_BNACT) -> torch.Tensor:
         """Activated output of conv `name` as a real [N,h,w,C] tensor (projection-neck input, tests)."""

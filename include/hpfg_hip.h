@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 121
+#define HPFG_VERSION 122
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -99,6 +99,23 @@ typedef struct HpfgWgradArgs {
   int32_t defer_reduce; /* 1: leave the slabs in `slab`; the caller sums them later with hpfg_slab_reduce_multi (one launch per backward) */
 } HpfgWgradArgs;
 
+typedef struct HpfgFirstConvArgs {   /* one network's side of hpfg_conv3x3_first_fwd_pair */
+  HpfgAct x;            /* STRIDED source: the network input */
+  const float* w_oihw;
+  const float* bias;
+  float* out;
+  float* stat_partials; /* or NULL */
+} HpfgFirstConvArgs;
+
+typedef struct HpfgBnFinalizeArgs {  /* one layer's side of hpfg_bn_fwd_finalize_pair (fields as in hpfg_bn_fwd_finalize) */
+  const float* partials;
+  const float* gamma;
+  const float* beta;
+  float* running_mean;  /* or NULL: statistics not tracked */
+  float* running_var;
+  float* bn;
+} HpfgBnFinalizeArgs;
+
 typedef struct HpfgFusedBwdArgs {   /* hpfg_fused_bwd: both gradients of a thin 3x3 layer from ONE staging of dZ (see below) */
   HpfgConvArgs d;       /* the dgrad side exactly as hpfg_conv_fwd takes it: a0 = dZ (DZ or PLAIN), wpk = wpk16_dgrad, out / out2 = dX,
                            Cout / CoutPad = the layer's Cin / CinPad, bwd_stats / bwd_of / stat_partials; math = HPFG_MATH_BF16X3 */
@@ -137,6 +154,14 @@ int hpfg_conv_first_rows(int N, int H, int W);            /* rows of stat_partia
 /* nn.Conv2d k3/k1 (+ fused producer BN/LeakyReLU/Dropout/MaxPool/Upsample/cat on load) + BN partial sums.
  * Also serves dgrad: a0 = dZ (mode DZ/PLAIN), wpk = wpk_dgrad. */
 int hpfg_conv_fwd(const HpfgConvArgs* args, void* stream);
+/* The SAME layer of two independent networks of identical geometry in ONE launch -- student and teacher of the Mean-Teacher step
+ * (2017_03_NIPS_Mean-Teacher_ACDC.py:94-101: model(x), then ema_model(x) under no_grad), the two students of CPS.  Every result is bit-identical
+ * to two separate launches (same tile -> workgroup mapping per network); what changes is that each launch carries twice the tiles instead of the
+ * two networks' launches competing from two streams, and the step has half the forward launches.  bf16x3 math, forward convolutions only. */
+int hpfg_conv_fwd_pair(const HpfgConvArgs* a, const HpfgConvArgs* b, void* stream);
+int hpfg_conv3x3_first_fwd_pair(const HpfgFirstConvArgs* a, const HpfgFirstConvArgs* b, int N, int H, int W, int Cin, int Cout, void* stream);
+int hpfg_bn_fwd_finalize_pair(const HpfgBnFinalizeArgs* a, const HpfgBnFinalizeArgs* b, int nblk, double count, float momentum, float eps, int C,
+                              void* stream);
 int hpfg_conv_stat_blocks(int N, int H, int W);          /* rows written by the fp32 kernels / upper bound for workspace sizing */
 int hpfg_conv_stat_rows(const HpfgConvArgs* args);         /* rows hpfg_conv_fwd(args) writes (depends on args->math) */
 /* BatchNorm2d train-mode statistics -> table rows mean/rstd/scale/shift, running stats (momentum .1, unbiased var)

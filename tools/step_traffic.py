@@ -20,6 +20,8 @@ def load(d, name):
 
 
 def fam(n):
+    if "fused_bwd" in n:
+        return "fused dgrad + wgrad (thin layers)"
     if "wgrad_bf16x3" in n:
         return "wgrad"
     if "conv1x1" in n:
