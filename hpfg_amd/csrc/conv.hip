@@ -117,7 +117,7 @@ inline int conv_first_grid(int N, int H, int W) {
 }  // namespace
 
 extern "C" int hpfg_conv_stat_blocks(int N, int H, int W) {
-  if (tile_is_big(H, W)) return N * (H / 16) * (W / 16);
+  if (tile_is_big(H, W)) return (N * (H / 16) * (W / 16) + 7) / 8 * 8;      // (conv_thin_kernel launches a multiple of 8 workgroups, one row each)
   const int a = N * ((H + 7) / 8) * ((W + 7) / 8), b = N * ((H + 3) / 4) * ((W + 15) / 16);   // 8x8 (fp32 path) / 4x16 (bf16x3 3x3 path)
   return a > b ? a : b;
 }
@@ -171,6 +171,10 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only, co
                    "conv_fwd: bwd_of must describe a layer with C == Cout == CoutPad (%d/%d/%d) at the output size", a->bwd_of.C, a->Cout, a->CoutPad);
   }
   if ((a->math & 0xff) == HPFG_MATH_BF16X3) {
+    if (!b) {      // the thin 16-pixel-aligned layers have a kernel of their own
+      const int r = hpfg_conv_thin_try(*a, st, rows_only);
+      if (r != HPFG_THIN_NONE) return r;
+    }
     switch (hpfg_kind_of(a->a0, a->a1)) {
       case HPFG_KIND_PLAIN: return hpfg_conv16_launch_plain(*a, st, rows_only, b);
       case HPFG_KIND_BNACT: return hpfg_conv16_launch_bnact(*a, st, rows_only, b);

@@ -769,6 +769,8 @@ int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st, int* rows_only, co
 
 }  // namespace hpfg_conv16
 
+constexpr int HPFG_THIN_NONE = -100;
+int hpfg_conv_thin_try(const HpfgConvArgs& a, hipStream_t st, int* rows_only);      // conv_thin.hip
 int hpfg_conv16_launch_plain(const HpfgConvArgs& a, hipStream_t st, int* rows_only, const HpfgConvArgs* b = nullptr);
 int hpfg_conv16_launch_bnact(const HpfgConvArgs& a, hipStream_t st, int* rows_only, const HpfgConvArgs* b = nullptr);
 int hpfg_conv16_launch_pool(const HpfgConvArgs& a, hipStream_t st, int* rows_only, const HpfgConvArgs* b = nullptr);

@@ -29,6 +29,7 @@ def _models(seed):
 @pytest.mark.parametrize("N,H", [(3, 64), (2, 48)])
 def test_pair_forward_equals_two_forwards_bitwise(N, H, monkeypatch):
     monkeypatch.setenv("HPFG_PAIR_FWD", "1")      # (off by default: measured slower than the two-stream overlap it replaces)
+    monkeypatch.setenv("HPFG_CONV_THIN", "0")     # the paired launches run conv_bf16x3_kernel: compare like with like (BatchNorm sum rows differ otherwise)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(N, 1, H, H, generator=g).to(DEV)
     dy = torch.randn(N, 4, H, H, generator=g).to(DEV)
@@ -92,6 +93,7 @@ def test_mean_teacher_step_with_paired_forward_equals_the_two_stream_step(monkey
         losses = [float(st.step(xl, yl, xu, k, cons_w=0.05)["loss"]) for k in range(1, 4)]
         return losses, m.flat_params.clone(), ema.flat_params.clone()
 
+    monkeypatch.setenv("HPFG_CONV_THIN", "0")
     monkeypatch.setenv("HPFG_PAIR_FWD", "0")
     l0, p0, e0 = run()
     monkeypatch.setenv("HPFG_PAIR_FWD", "1")
