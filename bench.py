@@ -266,7 +266,7 @@ def dominant_kernel_roofline(model, step, inputs, it, dev, eager_ok=True):
             traffic = int(tj["hbm_bytes_per_launch"])
     except Exception:
         traffic = None
-    kname = "conv_bf16x3_kernel" if eng.math == L.MATH_BF16X3 else "conv_mfma_kernel"
+    kname = "conv_thin_kernel" if eng.math == L.MATH_BF16X3 else "conv_mfma_kernel"
     return {"kernel": kname + "<16x16 tile, 16 output channels, 3x3, CAT loader> @ decoder.up4.conv.conv_conv.0 (32->16ch, 224x224, skip concat + "
                       "bilinear upsample + BN + LeakyReLU fused on load, BN partial sums in the epilogue)",
             "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,

@@ -26,6 +26,8 @@ def fam(n):
         return "wgrad"
     if "conv1x1" in n:
         return "conv 1x1 (fwd + dgrad)"
+    if "conv_thin" in n:
+        return "conv 3x3 forward"
     if "conv_bf16x3" in n:
         return "conv 3x3 dgrad" if re.search(r">, (0|4), ", n) else "conv 3x3 forward"
     if "conv_first" in n:
