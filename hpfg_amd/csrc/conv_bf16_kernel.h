@@ -423,7 +423,10 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
       // Prefetch depth: kinds with few raw loads per piece (PLAIN/BNACT) put ALL pieces of the next item in flight before the
       // first MFMA and finish them after the last one (a whole item of latency cover); DZ (4 raw float4 + 10 table registers) and
       // POOL/CAT (8 raw float4 per piece) keep the two-k-step ring to stay inside the register budget.
-      constexpr bool DEEP = NR <= 2 || C::NLD <= 2;
+      // The channel-rich layers (KC = 32; not the concat loader, whose upsampled chunks take the LDS-patch path) interleave instead: one wave
+      // per SIMD there, and issue -> k-loop -> convert in sequence left the MFMA pipe idle for half of every chunk (in-kernel timeline:
+      // 2957 cycles of k-loop + 2249 of conversion per chunk against 1728 cycles of MFMAs).
+      constexpr bool DEEP = (NR <= 2 || C::NLD <= 2) && (C::KC != 32 || CATK);
       // concat: a chunk is entirely skip half (BN + LeakyReLU pieces, like BNACT) or entirely upsampled half (a0.C % KC == 0)
       constexpr int SK = CATK ? HPFG_KIND_BNACT : KIND;        // loader kind of the per-pixel pieces held in `raw`
       RawPiece<SK> raw[DEEP ? C::NLD : 2];
