@@ -8,8 +8,8 @@ CE+Dice+MSE loss, SGD, EMA -- every step of 2017_03_NIPS_Mean-Teacher_ACDC.py:82
 `python bench.py --gpus N` with N > 1 and no launcher environment starts `python -m torch.distributed.run --nproc-per-node N`
 on this file as a CHILD process (before anything here touches the GPU) and relays its JSON line; under a launcher (RANK /
 WORLD_SIZE set) it is one rank of the job.  One rank per GPU over RCCL, weak scaling (per-GPU batch fixed).
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (the heaviest-traffic conv launch, timed with HIP events
-both alone and inside eager steps), `step_roofline`, `f32_math` (the same step with exact-fp32 MFMA products, N=1 only) and
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (the longest launch of the step -- the fused backward kernel of
+decoder.up4's first conv; its forward conv under `forward_conv_of_the_same_layer` -- timed with HIP events both alone and inside eager steps), `step_roofline`, `f32_math` (the same step with exact-fp32 MFMA products, N=1 only) and
 `cpu_baseline` (the CPU oracle timed on this host's cores on a bounded sample).
 """
 import argparse
@@ -171,7 +171,12 @@ def main():
 
     roof = f32 = cpu = None
     if rank == 0:
-        roof = dominant_kernel_roofline(model, step, (xl, yl, xu), it, dev, eager_ok=dp is None)
+        fwd = dominant_kernel_roofline(model, step, (xl, yl, xu), it, dev, eager_ok=dp is None)
+        roof = fused_bwd_roofline(model, step, (xl, yl, xu), it, dev, eager_ok=dp is None)
+        if roof is None:
+            roof = fwd
+        else:
+            roof["forward_conv_of_the_same_layer"] = fwd
     if world == 1 and dp is None and not a.no_f32_line and a.math != "f32":
         del step, model, ema
         torch.cuda.empty_cache()
@@ -206,6 +211,65 @@ def main():
         print(json.dumps(out))
     if dp is not None:
         dp.shutdown()
+
+
+def fused_bwd_roofline(model, step, inputs, it, dev, eager_ok=True):
+    """The longest launch of the step since round 2: the fused backward kernel of decoder.up4's first conv (32 -> 16 channels at 224x224):
+    input gradient + weight-gradient slabs from one staging of dZ.  Timed like dominant_kernel_roofline(): HIP events around the launch
+    inside eager steps (teacher stream idle during backward, so in-step == what the kernel trace shows), and 20 launches alone.
+    Algorithmic bytes per pixel: dA + z of the layer (2 x 16 ch), the skip tensor (16 ch), the low-res 1x1 output (16 ch at a quarter of
+    the pixels), dX written (32 ch) = 336 B.  None when the layer is not on the fused path (f32 math, HPFG_FUSED_BWD=0)."""
+    import ctypes as C
+    import torch
+    from hpfg_amd import _lib as L
+    eng = next(iter(model._engines.values()))[0]
+    name = "decoder.up4.conv.conv_conv.0"
+    if name not in eng.fused_grid or name not in eng._last_fused:
+        return None
+    s = eng.specs[name]
+    in_step_us = None
+    if eager_ok:
+        eng.probe = ("fused_bwd:" + name, [])
+        for k in range(6):
+            step.step(*inputs, it + 1 + k)
+        torch.cuda.synchronize(dev)
+        ts = [e0.elapsed_time(e1) * 1e3 for (e0, e1) in eng.probe[1][len(eng.probe[1]) // 3:]]
+        eng.probe = None
+        if ts:
+            in_step_us = sum(ts) / len(ts)
+    fa = eng._last_fused[name]
+    st = torch.cuda.current_stream(dev)
+    lib = L.load()
+    for _ in range(3):
+        L.check(lib.hpfg_fused_bwd(C.byref(fa), st.cuda_stream), "fused_bwd")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record(st)
+    for _ in range(reps):
+        L.check(lib.hpfg_fused_bwd(C.byref(fa), st.cuda_stream), "fused_bwd")
+    e1.record(st)
+    e1.synchronize()
+    solo_us = e0.elapsed_time(e1) / reps * 1e3
+    us = in_step_us if in_step_us is not None else solo_us
+    n = eng.N
+    bytes_alg = n * s.h * s.w * (2 * 16 + 16 + 32) * 4 + n * (s.h // 2) * (s.w // 2) * 16 * 4
+    flops = n * s.h * s.w * 9 * 32 * 16 * 2 * 2
+    ach = bytes_alg / (us * 1e-6) / 1e9
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_fused_bwd_kernel.json")))
+        if n == 16 and s.h == 224:
+            traffic = int(tj["hbm_bytes_per_launch"])
+    except Exception:
+        traffic = None
+    return {"kernel": "fused_bwd_kernel<2 input x 1 output channel tiles, concat input, dZ source, 8 waves> @ decoder.up4.conv.conv_conv.0 (32->16ch, "
+                      "224x224): input gradient + weight-gradient slabs from one staging of dZ = k1*g + k2*z + k3 (BatchNorm / LeakyReLU backward on load)",
+            "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
+            "avg_launch_us": round(us, 2), "timing": "in-step (events around the launch inside eager steps)" if in_step_us is not None else "solo",
+            "solo_launch_us": round(solo_us, 2), "frac_solo": round(bytes_alg / (solo_us * 1e-6) / 8e12, 4),
+            "algorithmic_bytes_per_launch": bytes_alg, "flops_per_launch": flops, "achieved_TFLOPs": round(flops / (us * 1e-6) / 1e12, 2),
+            "note": "the longest launch of the step (backward of the layer whose forward was round 1's roofline kernel); no single kernel dominates "
+                    "(largest family 19 % of kernel time): step_roofline is the figure that matters"}
 
 
 def dominant_kernel_roofline(model, step, inputs, it, dev, eager_ok=True):

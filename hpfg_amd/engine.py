@@ -121,6 +121,7 @@ class UNetEngine:
         # weight-gradient slabs and the backward sums of the layer below from a single staging of dZ (hpfg_fused_bwd)
         self.fused_bwd = os.environ.get("HPFG_FUSED_BWD", "1") == "1"
         self.fused_grid: Dict[str, int] = {}
+        self._last_fused: Dict[str, "L.FusedBwdArgs"] = {}
         self._side, self._side_used = None, False
         self.force_sync = False  # run the data-parallel code path (reduce -> all-reduce -> finalize) even with one rank (tests)
         self.math = L.MATH_F32      # L.MATH_BF16X3 selects the split-bf16 matrix-core kernels for conv forward / dgrad
@@ -538,7 +539,15 @@ class UNetEngine:
                 raise RuntimeError(f"fused_bwd[{s.name}]: {rows} rows of backward sums do not fit the partials workspace")
             ca.bwd_stats, ca.bwd_of, ca.stat_partials = 1, self._act_dz(stats_for, out, s.cin), L.ptr(self.partials)
             self._fused_rows[stats_for] = rows
+        self._last_fused[s.name] = fa      # (bench.py re-launches it alone)
+        probe = self.probe is not None and self.probe[0] == "fused_bwd:" + s.name
+        if probe:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.dev))
         L.check(self.lib.hpfg_fused_bwd(C.byref(fa), self._stream()), f"fused_bwd[{s.name}]")
+        if probe:
+            e1.record(torch.cuda.current_stream(self.dev))
+            self.probe[1].append((e0, e1))
 
     def _wgrad(self, s: ConvSpec, g: L.Act):
         """Weight gradient of layer s.  It is off the critical chain of backward (nothing downstream consumes it before the final
