@@ -5,18 +5,18 @@ namespace {
 
 using namespace hpfg_fused;
 
-template <int CI, int CO, int AK, int GK, int NW, int WGS, int PFA, int PFPOS>
+template <int CI, int CO, int AK, int GK, int NW, int WGS, int PFA, int PFPOS, int BMAX = 48>
 int launch(const HpfgFusedBwdArgs& a, hipStream_t st, bool grid_only) {
-  const int grid = fused_grid<CI, CO, AK, GK, NW, WGS>(a);
+  const int grid = fused_grid<CI, CO, AK, GK, NW, WGS, BMAX>(a);
   if (grid_only) return grid;
   const int tx = a.d.W / T, ty = a.d.H / T;
   if (a.d.bwd_stats) {
     if constexpr (AK == HPFG_KIND_BNACT)
-      hipLaunchKernelGGL((fused_bwd_kernel<CI, CO, AK, GK, true, NW, WGS, PFA, PFPOS>), dim3(grid), dim3(64 * NW), 0, st, a, tx, ty);
+      hipLaunchKernelGGL((fused_bwd_kernel<CI, CO, AK, GK, true, NW, WGS, PFA, PFPOS, BMAX>), dim3(grid), dim3(64 * NW), 0, st, a, tx, ty);
     else
       return -3;
   } else {
-    hipLaunchKernelGGL((fused_bwd_kernel<CI, CO, AK, GK, false, NW, WGS, PFA, PFPOS>), dim3(grid), dim3(64 * NW), 0, st, a, tx, ty);
+    hipLaunchKernelGGL((fused_bwd_kernel<CI, CO, AK, GK, false, NW, WGS, PFA, PFPOS, BMAX>), dim3(grid), dim3(64 * NW), 0, st, a, tx, ty);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

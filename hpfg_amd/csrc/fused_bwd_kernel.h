@@ -48,6 +48,8 @@ constexpr int DSLOT = (HP * HP + 15) / 16 * 16;         // 336
 constexpr int DPL = DSLOT * 32;                         // bytes per hi / lo plane of one 16-channel chunk of the dZ tile: 32 bytes per pixel slot
 constexpr int APL = T * T * 32;                         // ... of the A tile
 constexpr int DCH = 2 * DPL, ACH = 2 * APL;             // one 16-channel chunk = (hi, lo)
+constexpr int USH = T / 2 + 3, USW = T / 2 + 3;         // low-resolution source patch of an upsampled chunk of the (interior) input tile
+constexpr int UBYTES = USH * USW * 16 * 4;              // fp32, [pixel][16 ch]
 
 // NW waves per workgroup: staging pieces (8 channels of one pixel) per thread and 16-channel chunk, pixel tiles per wave in dgrad
 template <int NW>
@@ -57,7 +59,7 @@ struct Split {
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
 };
 
-template <int CI, int CO, int AK, int GK, int NW, bool BWD>
+template <int CI, int CO, int AK, int GK, int NW, bool BWD, int BMAX = 48>
 struct Geo {
   static constexpr bool CATK = AK == HPFG_KIND_CAT;
   static constexpr int AK0 = CATK ? HPFG_KIND_BNACT : AK;          // loader kind of the chunks read through xa0 (concat: the skip half)
@@ -66,14 +68,14 @@ struct Geo {
   static constexpr int TABA = 2 * 16 * NA0 * 4;                              // sc, sh rows of the input's producer
   static constexpr int STAT = 2 * NW * 16 * CI * 4;
   static constexpr int KS = 5 * CO;                                          // dgrad k-steps (2 taps x 16 channels each)
-  static constexpr bool BREG = KS * CI * 8 <= 48;                            // dgrad weight fragments: registers (few) or LDS
+  static constexpr bool BREG = KS * CI * 8 <= BMAX;                            // dgrad weight fragments: registers (few) or LDS
   static constexpr int BFR = BREG ? 0 : KS * CI * 2 * 1024;
   static constexpr bool ZLDS = BWD && AK == HPFG_KIND_BNACT;                 // raw z of the input tile for the epilogue of the layer below
   static constexpr int ZPS = 64 * CI + 32;                                   // bytes per pixel of that tile
   static constexpr int ZL = ZLDS ? T * T * ZPS : 0;
   static constexpr int OFF_STAT = CO * DCH + CI * ACH, OFF_TABD = OFF_STAT + STAT, OFF_TABA = OFF_TABD + TABD, OFF_B = OFF_TABA + TABA,
-                       OFF_Z = OFF_B + BFR;
-  static constexpr int LDS = OFF_Z + ZL;
+                       OFF_Z = OFF_B + BFR, OFF_U = OFF_Z + ZL;
+  static constexpr int LDS = OFF_U + NA1 * UBYTES;
 };
 
 __device__ __forceinline__ bf16x8 tr8(const unsigned char* p0, const unsigned char* p1) {
@@ -86,10 +88,10 @@ __device__ __forceinline__ bf16x8 tr8(const unsigned char* p0, const unsigned ch
 // wider layers: per-thread staging registers and accumulators halve, which is what lets a whole tile be prefetched); WGS = workgroups per CU
 // to compile for; PFA = how many of the CI input chunks are prefetched a tile ahead together with dZ (the rest is requested when the tile
 // starts); PFPOS = where in the tile loop that prefetch is issued
-template <int CI, int CO, int AK, int GK, bool BWD, int NW, int WGS, int PFA, int PFPOS>
+template <int CI, int CO, int AK, int GK, bool BWD, int NW, int WGS, int PFA, int PFPOS, int BMAX = 48>
 __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArgs p, int tiles_x, int tiles_y) {
   using C = Cfg<16, 16, 4, 1, CI, 9, 16>;               // (weight-fragment indexing of the dgrad side: CI output-channel tiles, K = 2 taps x 16 channels)
-  using G = Geo<CI, CO, AK, GK, NW, BWD>;
+  using G = Geo<CI, CO, AK, GK, NW, BWD, BMAX>;
   static_assert(!BWD || AK == HPFG_KIND_BNACT, "the backward sums of the layer below need its raw output as this layer's input");
   using SP = Split<NW>;
   constexpr int AK0 = G::AK0, NA0 = G::NA0, NA1 = G::NA1, NTH = SP::NTH, ND = SP::ND, NA = SP::NA, MI = SP::MI;
@@ -101,6 +103,8 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
   float* tabA = reinterpret_cast<float*>(lds + G::OFF_TABA);
   const bf16x8* ldsB = reinterpret_cast<const bf16x8*>(lds + G::OFF_B);
   unsigned char* ldsZ = lds + G::OFF_Z;
+  float* ldsU = reinterpret_cast<float*>(lds + G::OFF_U);
+  static_assert(NA1 == 0 || USH * USW * 2 <= NTH, "one source piece of the upsampled half per thread");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.d.H, W = p.d.W;
   const int ntiles = tiles_x * tiles_y, nwork = ntiles * p.d.N;
@@ -108,8 +112,6 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
   const HpfgAct& aD = p.d.a0;
   HpfgAct aS = p.xa0;                                    // (the skip half of a concat carries no dropout: model/unet.py:57 concatenates block outputs)
   if (G::CATK) aS.drop_p = 0.f;
-  HpfgAct aU0 = {};                                      // stands in for "no channels before the upsampled tensor": issue / finish_piece<CAT> then
-  aU0.C = 0;                                             // take their upsampled-half branch at compile time
   const ActCtx cxg = make_ctx(aD), cxa = make_ctx(aS);
 #ifdef HPFG_TRACE      // diagnostics build (make TRACE=1, tools/trace_fused.py): thread 0 stamps s_memtime at the phase boundaries into d.bias
   const bool tr_on = (p.d.math & 0x2000) && tid == 0;
@@ -198,7 +200,8 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
 
   RawPiece<GK> rawD[CO][ND];
   RawPiece<AK0> rawA0[NA0][NA];
-  RawPiece<HPFG_KIND_CAT> rawA1[NA1 > 0 ? NA1 : 1][NA];
+  f32x4 rawU[NA1 > 0 ? NA1 : 1][2];      // concat: the low-res source patch of the tile (one 8-channel piece per thread and upsampled chunk),
+                                         // parked in LDS and blended from there (conv_bf16_kernel.h) -- 8 float4 loads per output piece otherwise
 
   // loads of one tile.  EARLY: dZ and the first PFA input chunks (a tile ahead); !EARLY: the remaining input chunks.  live == false: the
   // workgroup has no further tile -- every lane then reads pixel (0, 0, 0), one cache line, and nothing is made of it.
@@ -229,15 +232,17 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
         issue_piece<AK0>(rawA0[c][i], aS, none, cxa, n, live ? ty0 + pix / T : 0, live ? tx0 + pix % T : 0, chv ? c0 : 0, live && chv);
       }
     }
+    if (NA1 > 0) {
+      const int sy_base = hpfg_conv16::up_base(ty0, p.xa1.Hs), sx_base = hpfg_conv16::up_base(tx0, p.xa1.Ws);
+      const int pix = tid >> 1;
+      const int sy = live ? clampi(sy_base + pix / USW, 0, p.xa1.Hs - 1) : 0, sx = live ? clampi(sx_base + pix % USW, 0, p.xa1.Ws - 1) : 0;
 #pragma unroll
-    for (int c = 0; c < NA1; ++c) {
-      if ((NA0 + c < PFA) != EARLY) continue;
-      const int cu = c * 16 + gsel * 8;                  // channel inside the upsampled tensor
-      const bool chv = cu < p.xa1.C;
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const int pix = (tid + i * NTH) >> 1;
-        issue_piece<HPFG_KIND_CAT>(rawA1[c][i], aU0, p.xa1, cxa, n, live ? ty0 + pix / T : 0, live ? tx0 + pix % T : 0, chv ? cu : 0, live && chv);
+      for (int c = 0; c < NA1; ++c) {
+        if ((NA0 + c < PFA) != EARLY) continue;
+        const int cu = c * 16 + gsel * 8;                // channel inside the upsampled tensor
+        const int off = ((n * p.xa1.Hs + sy) * p.xa1.Ws + sx) * p.xa1.pstride + (cu < p.xa1.C ? cu : 0);
+        rawU[c][0] = ld4(p.xa1.z, off);
+        rawU[c][1] = ld4(p.xa1.z, off + 4);
       }
     }
   };
@@ -310,21 +315,48 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
         *reinterpret_cast<bf16x8*>(o + APL) = lo;
       }
     }
+    if (NA1 > 0) {
+      if (tid < USH * USW * 2) {
 #pragma unroll
-    for (int c = 0; c < NA1; ++c) {
-      const int cu = c * 16 + gsel * 8;
-      const bool chv = cu < p.xa1.C;
-      Tab ta;
+        for (int c = 0; c < NA1; ++c) {
+          float* d = ldsU + c * (UBYTES / 4) + (tid >> 1) * 16 + gsel * 8;
+          *reinterpret_cast<f32x4*>(d) = rawU[c][0];
+          *reinterpret_cast<f32x4*>(d + 4) = rawU[c][1];
+        }
+      }
+      __syncthreads();
+      const int sy_base = hpfg_conv16::up_base(ty0, p.xa1.Hs), sx_base = hpfg_conv16::up_base(tx0, p.xa1.Ws);
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int pix = (tid + i * NTH) >> 1;
-        f32x4 v0, v1;
-        finish_piece<HPFG_KIND_CAT>(v0, v1, rawA1[c][i], ta, aU0, p.xa1, cxa, n, ty0 + pix / T, tx0 + pix % T, chv ? cu : 0, chv);
-        bf16x8 hi, lo;
-        split8(v0, v1, hi, lo);
-        unsigned char* o = ldsA + (NA0 + c) * ACH + pix * 32 + gsel * 16;
-        *reinterpret_cast<bf16x8*>(o) = hi;
-        *reinterpret_cast<bf16x8*>(o + APL) = lo;
+        int y0, y1, x0, x1;
+        float wy1, wx1;
+        up_coord(ty0 + pix / T, p.xa1.Hs, y0, y1, wy1);
+        up_coord(tx0 + pix % T, p.xa1.Ws, x0, x1, wx1);
+        const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+        const int o0 = (x0 - sx_base) * 16, o1 = (x1 - sx_base) * 16;
+#pragma unroll
+        for (int c = 0; c < NA1; ++c) {
+          const bool chv = c * 16 + gsel * 8 < p.xa1.C;
+          const float* r0 = ldsU + c * (UBYTES / 4) + ((y0 - sy_base) * USW) * 16 + gsel * 8;
+          const float* r1 = ldsU + c * (UBYTES / 4) + ((y1 - sy_base) * USW) * 16 + gsel * 8;
+          const f32x4 a00 = *reinterpret_cast<const f32x4*>(r0 + o0), b00 = *reinterpret_cast<const f32x4*>(r0 + o0 + 4);
+          const f32x4 a01 = *reinterpret_cast<const f32x4*>(r0 + o1), b01 = *reinterpret_cast<const f32x4*>(r0 + o1 + 4);
+          const f32x4 a10 = *reinterpret_cast<const f32x4*>(r1 + o0), b10 = *reinterpret_cast<const f32x4*>(r1 + o0 + 4);
+          const f32x4 a11 = *reinterpret_cast<const f32x4*>(r1 + o1), b11 = *reinterpret_cast<const f32x4*>(r1 + o1 + 4);
+          f32x4 v0 = wy0 * (wx0 * a00 + wx1 * a01) + wy1 * (wx0 * a10 + wx1 * a11);     // same expression order as finish_piece<CAT>
+          f32x4 v1 = wy0 * (wx0 * b00 + wx1 * b01) + wy1 * (wx0 * b10 + wx1 * b11);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v0[j] = chv ? v0[j] : 0.f;
+            v1[j] = chv ? v1[j] : 0.f;
+          }
+          bf16x8 hi, lo;
+          split8(v0, v1, hi, lo);
+          unsigned char* o = ldsA + (NA0 + c) * ACH + pix * 32 + gsel * 16;
+          *reinterpret_cast<bf16x8*>(o) = hi;
+          *reinterpret_cast<bf16x8*>(o + APL) = lo;
+        }
       }
     }
     HPFG_TR(4)
@@ -499,10 +531,10 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
 }
 
 // workgroups of the launch = slabs = rows of the BatchNorm-backward partial sums
-template <int CI, int CO, int AK, int GK, int NW, int WGS>
+template <int CI, int CO, int AK, int GK, int NW, int WGS, int BMAX = 48>
 inline int fused_grid(const HpfgFusedBwdArgs& a) {
   const long nwork = (long)a.d.N * (a.d.H / T) * (a.d.W / T);
-  int per_cu = 160 * 1024 / Geo<CI, CO, AK, GK, NW, AK == HPFG_KIND_BNACT>::LDS;      // (the same grid with and without the backward sums)
+  int per_cu = 160 * 1024 / Geo<CI, CO, AK, GK, NW, AK == HPFG_KIND_BNACT, BMAX>::LDS;      // (the same grid with and without the backward sums)
   if (per_cu > WGS) per_cu = WGS;
   if (per_cu < 1) per_cu = 1;
   const long cap = 256L * per_cu;
