@@ -5,12 +5,14 @@ namespace {
 
 using namespace hpfg_fused;
 
-template <int CI, int CO, int AK, int GK, int NW, int WGS, int PFA, int PFPOS, int BMAX = 48>
+template <int CI, int CO, int AK, int GK, int NW, int WGS, int PFA, int PFPOS, int BMAX = 48, bool NODG = false>
 int launch(const HpfgFusedBwdArgs& a, hipStream_t st, bool grid_only) {
   const int grid = fused_grid<CI, CO, AK, GK, NW, WGS, BMAX>(a);
   if (grid_only) return grid;
   const int tx = a.d.W / T, ty = a.d.H / T;
-  if (a.d.bwd_stats) {
+  if constexpr (NODG) {
+    hipLaunchKernelGGL((fused_bwd_kernel<CI, CO, AK, GK, false, NW, WGS, PFA, PFPOS, BMAX, true>), dim3(grid), dim3(64 * NW), 0, st, a, tx, ty);
+  } else if (a.d.bwd_stats) {
     if constexpr (AK == HPFG_KIND_BNACT)
       hipLaunchKernelGGL((fused_bwd_kernel<CI, CO, AK, GK, true, NW, WGS, PFA, PFPOS, BMAX>), dim3(grid), dim3(64 * NW), 0, st, a, tx, ty);
     else
@@ -28,6 +30,10 @@ int dispatch(const HpfgFusedBwdArgs& a, hipStream_t st, bool grid_only) {
   const int ak = hpfg_kind_of(a.xa0, a.xa1), gk = hpfg_kind_of(a.d.a0, a.d.a1);
 #define HPFG_FUSED_CASE(CI, CO, AK, GK, NW, WGS, PFA, PFPOS) \
   if (ci == CI && co == CO && ak == AK && gk == GK) return launch<CI, CO, AK, GK, NW, WGS, PFA, PFPOS>(a, st, grid_only);
+  if (!a.d.out) {      // weight gradient only: the first layer (network input, <= 4 channels, read through its strides)
+    if (ci == 1 && co == 1 && ak == HPFG_KIND_PLAIN && gk == HPFG_KIND_DZ) return launch<1, 1, HPFG_KIND_PLAIN, HPFG_KIND_DZ, 4, 2, 1, 1, 48, true>(a, st, grid_only);
+    return grid_only ? 0 : -2;
+  }
   HPFG_FUSED_CASE(1, 1, HPFG_KIND_BNACT, HPFG_KIND_DZ, 4, 2, 1, 1)      // in_conv.c2, up4.c2
   HPFG_FUSED_CASE(1, 1, HPFG_KIND_BNACT, HPFG_KIND_PLAIN, 4, 2, 1, 1)   // out_conv
   HPFG_FUSED_CASE(1, 2, HPFG_KIND_POOL, HPFG_KIND_DZ, 8, 1, 1, 1)       // down1.c1
@@ -58,15 +64,16 @@ extern "C" int hpfg_fused_bwd(const HpfgFusedBwdArgs* a, void* stream) {
   if (c < 0) return -1;
   HPFG_ARG_CHECK(c == 0, "fused_bwd: 3x3 bf16x3 layers with H, W multiples of 16, CinPad <= 64 and CoutPad <= 32 only");
   const HpfgConvArgs& d = a->d;
-  HPFG_ARG_CHECK(d.wpk && d.out && a->slab && d.a0.z, "fused_bwd: wpk, out, slab and the dZ source are required");
+  const bool wonly = !d.out;      // no dX wanted: weight gradient only (first layer)
+  HPFG_ARG_CHECK(a->slab && d.a0.z && (wonly ? (!d.wpk && !d.bwd_stats && !d.out2) : d.wpk != nullptr), "fused_bwd: slab and the dZ source are required; wpk with out");
   HPFG_ARG_CHECK(d.Cout == a->Cin && d.CoutPad == a->CinPad && d.a0.C == a->Cout && a->xa0.C + a->xa1.C == a->Cin,
                  "fused_bwd: the dgrad side must describe the same layer (d.Cout == Cin, d.a0.C == Cout, input channels == Cin)");
-  HPFG_ARG_CHECK(a->Cin % 8 == 0 && (a->Cout % 8 == 0 || d.a0.mode == HPFG_ACT_PLAIN || d.a0.mode == HPFG_ACT_STRIDED), "fused_bwd: Cin (and Cout behind a DZ source) must be multiples of 8");
+  HPFG_ARG_CHECK((wonly || a->Cin % 8 == 0) && (a->Cout % 8 == 0 || d.a0.mode == HPFG_ACT_PLAIN || d.a0.mode == HPFG_ACT_STRIDED), "fused_bwd: Cin (and Cout behind a DZ source) must be multiples of 8");
 #ifndef HPFG_TRACE      // (the diagnostics build takes its stamp buffer through d.bias)
   HPFG_ARG_CHECK(!d.bias, "fused_bwd: the dgrad side takes no bias");
 #endif
   HPFG_ARG_CHECK(d.a1.mode == 0 && !d.a1.z, "fused_bwd: the dgrad side takes no second source");
-  HPFG_ARG_CHECK(d.Cout == d.CoutPad && d.out_pstride % 4 == 0 && d.out2_pstride % 4 == 0, "fused_bwd: Cin must be a multiple of 16 and the dX pixel strides of 4");
+  HPFG_ARG_CHECK(wonly || (d.Cout == d.CoutPad && d.out_pstride % 4 == 0 && d.out2_pstride % 4 == 0), "fused_bwd: Cin must be a multiple of 16 and the dX pixel strides of 4");
   if (hpfg_kind_of(a->xa0, a->xa1) == HPFG_KIND_CAT)
     HPFG_ARG_CHECK(a->xa0.C == a->xa1.C && a->xa0.C % 16 == 0, "fused_bwd: a concatenated input must be two halves of a multiple of 16 channels");
   HPFG_ARG_CHECK(!d.out_split || (d.out2 && d.out_split % 16 == 0 && d.out_split < d.Cout && !d.bwd_stats),

@@ -86,9 +86,9 @@ __device__ __forceinline__ bf16x8 tr8(const unsigned char* p0, const unsigned ch
 
 // CI = CinPad / 16, CO = CoutPad / 16 of the layer; AK / GK = loader kinds of the layer input and of dZ; NW = waves per workgroup (8 for the
 // wider layers: per-thread staging registers and accumulators halve, which is what lets a whole tile be prefetched); WGS = workgroups per CU
-// to compile for; PFA = how many of the CI input chunks are prefetched a tile ahead together with dZ (the rest is requested when the tile
+// to compile for; NODG = weight gradient only (the first layer: nothing to back-propagate into the network input); PFA = how many of the CI input chunks are prefetched a tile ahead together with dZ (the rest is requested when the tile
 // starts); PFPOS = where in the tile loop that prefetch is issued
-template <int CI, int CO, int AK, int GK, bool BWD, int NW, int WGS, int PFA, int PFPOS, int BMAX = 48>
+template <int CI, int CO, int AK, int GK, bool BWD, int NW, int WGS, int PFA, int PFPOS, int BMAX = 48, bool NODG = false>
 __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArgs p, int tiles_x, int tiles_y) {
   using C = Cfg<16, 16, 4, 1, CI, 9, 16>;               // (weight-fragment indexing of the dgrad side: CI output-channel tiles, K = 2 taps x 16 channels)
   using G = Geo<CI, CO, AK, GK, NW, BWD, BMAX>;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
       tabD[i] = ch < aD.C ? aD.bn[aD.bn_coff + row * aD.bn_stride + ch] : 0.f;
     }
   }
-  for (int i = tid; i < 2 * 16 * NA0; i += NTH) {
+  for (int i = tid; i < 2 * 16 * NA0 && AK0 != HPFG_KIND_PLAIN; i += NTH) {
     const int r = i / (16 * NA0), ch = i % (16 * NA0);
     tabA[i] = ch < aS.C ? aS.bn[aS.bn_coff + (r == 0 ? HPFG_BN_SCALE : HPFG_BN_SHIFT) * aS.bn_stride + ch] : 0.f;
   }
@@ -171,13 +171,13 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
   // tile in and out), otherwise in LDS -- streamed from L2 per tile they stalled every other k-step (8 waves x 40 KB per tile, each k-step
   // pair shorter than the L2 latency)
   constexpr int KS = G::KS;
-  constexpr int PB = G::BREG ? KS : 0;
+  constexpr int PB = G::BREG && !NODG ? KS : 0;
   const int ntn = p.d.CoutPad / 16;                      // dgrad output-channel tiles = CI
   const bf16x8* wpk = reinterpret_cast<const bf16x8*>(p.d.wpk);
   bf16x8 pbh[PB > 0 ? PB : 1][CI], pbl[PB > 0 ? PB : 1][CI];
 #pragma unroll
   for (int k = 0; k < PB; ++k) hpfg_conv16::load_b<C>(pbh[k], pbl[k], wpk, k, ntn, 0, lane);
-  if (!G::BREG) {
+  if (!G::BREG && !NODG) {
     bf16x8* dst = reinterpret_cast<bf16x8*>(lds + G::OFF_B);
     for (int i = tid; i < KS * CI * 2 * 64; i += NTH) dst[i] = wpk[i];
   }
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
       const bool chv = c0 < aS.C;
       Tab ta;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < 2 && AK0 != HPFG_KIND_PLAIN; ++h) {
         ta.sc[h] = ld4(tabA, 0 * 16 * NA0 + c0 + 4 * h);
         ta.sh[h] = ld4(tabA, 1 * 16 * NA0 + c0 + 4 * h);
       }
@@ -369,6 +369,7 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
     const bool live2 = w2 < wend;
     const int ws2 = live2 ? w2 : 0;
     if (PFPOS == 0) issue(std::true_type{}, ws2 / ntiles, ((ws2 % ntiles) / tiles_x) * T, ((ws2 % ntiles) % tiles_x) * T, live2);
+    if constexpr (!NODG) {
     // ---- dgrad: dX tile = dZ (*) Wd, K = (tap pair, 16 channels) per MFMA
     f32x4 acc[MI][CI];
 #pragma unroll
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
           }
         }
       }
+    }
     }
     HPFG_TR(7)
     if (PFPOS == 1) issue(std::true_type{}, ws2 / ntiles, ((ws2 % ntiles) / tiles_x) * T, ((ws2 % ntiles) % tiles_x) * T, live2);

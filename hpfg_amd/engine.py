@@ -437,11 +437,12 @@ class UNetEngine:
         self.fused_grid = {}
         if self.fused_bwd and self.math == L.MATH_BF16X3 and self.wgrad_overlap == 0:
             for i, s in enumerate(self.order):
-                if s.taps != 9 or s.idx == 0:
+                if s.taps != 9:
                     continue
                 fa = L.FusedBwdArgs()
                 fa.xa0, fa.xa1 = self.input_acts(s.name)
                 fa.d.a0.mode = L.ACT_DZ if s.bn else L.ACT_PLAIN
+                fa.d.out = None if s.idx == 0 else L.ptr(self.partials)      # (no dX for the first layer: weight gradient only; any non-null otherwise)
                 fa.d.N, fa.d.H, fa.d.W, fa.d.taps, fa.d.math = N, s.h, s.w, 9, self.math
                 fa.Cin, fa.CinPad, fa.Cout, fa.CoutPad = s.cin, s.cin_pad, s.cout, s.cout_pad
                 grid = self.lib.hpfg_fused_bwd_grid(C.byref(fa))
@@ -528,7 +529,8 @@ class UNetEngine:
         fa.slab = L.ptr(self.slab_of[s.name])
         fa.Cin, fa.CinPad, fa.Cout, fa.CoutPad = s.cin, s.cin_pad, s.cout, s.cout_pad
         ca = fa.d
-        ca.a0, ca.math, ca.wpk, ca.out = g, self.math, L.ptr(self.wpk16_d[s.name]), L.ptr(out)
+        ca.a0, ca.math, ca.out = g, self.math, L.ptr(out)
+        ca.wpk = L.ptr(self.wpk16_d[s.name]) if out is not None else None      # (out None: the first layer, weight gradient only)
         ca.out_pstride, ca.Cout, ca.CoutPad = s.cin, s.cin, s.cin_pad
         if out2 is not None:
             ca.out2, ca.out_split, ca.out_pstride, ca.out2_pstride = L.ptr(out2), s.cin // 2, s.cin // 2, s.cin // 2
@@ -659,7 +661,10 @@ class UNetEngine:
             self._wgrad_dgrad(s2, g2, self.dA[s1.name], s1.name)
             g1 = self._bn_backward(s1)
             if lvl == 0:
-                self._wgrad(s1, g1)
+                if s1.name in self.fused_grid:
+                    self._fused_bwd(s1, g1, None, None, None)
+                else:
+                    self._wgrad(s1, g1)
             if lvl > 0:
                 self._wgrad_dgrad(s1, g1, self.dP[lvl])
         if self._side_used:

@@ -135,3 +135,38 @@ def test_fused_bwd_equals_separate_kernels_and_autograd(N, H, W, cin, cout, ak, 
         L.check(lib.hpfg_bn_bwd_reduce(C.byref(bo), N, H, W, L.ptr(ref), stream(DEV)), "bn_bwd_reduce")
         ps, rs = part.double().sum(0).cpu(), ref.double().sum(0).cpu()
         assert maxerr(ps[:, :cin], rs) < 1e-4 * max(1.0, float(rs.abs().max()))
+
+
+@pytest.mark.parametrize("N,H,W,cin", [(2, 32, 48, 1), (3, 32, 32, 3)])
+def test_fused_bwd_weight_gradient_only_first_layer(N, H, W, cin):
+    """The first layer (network input read through its strides, <= 4 channels, nothing to back-propagate): hpfg_fused_bwd without `out`
+    = the weight-gradient slabs only, against hpfg_wgrad and PyTorch autograd."""
+    g = torch.Generator().manual_seed(cin + H)
+    layer = AdHocConv(cin, 16, 9, DEV, seed=9, hw=(H, W))
+    x = torch.randn(N, cin, H, W, generator=g).to(DEV)
+    xa = L.Act()
+    xa.z, xa.mode, xa.C, xa.Hs, xa.Ws = L.ptr(x), L.ACT_STRIDED, cin, H, W
+    xa.sn, xa.sc, xa.sy, xa.sx = cin * H * W, H * W, W, 1
+    zo = torch.randn(N, H, W, 16, generator=g).to(DEV)
+    dA = torch.randn(N, H, W, 16, generator=g).to(DEV)
+    tabo = _bn_table(16, 11).to(DEV)
+    gsrc = _dz(zo, tabo, dA, 16, H, W, p=0.05, seed=3)
+    lib = L.load()
+    fa = L.FusedBwdArgs()
+    fa.xa0, fa.xa1 = xa, L.Act()
+    fa.Cin, fa.CinPad, fa.Cout, fa.CoutPad = cin, 16, 16, 16
+    fa.d.a0, fa.d.math, fa.d.Cout, fa.d.CoutPad, fa.d.N, fa.d.H, fa.d.W, fa.d.taps = gsrc, L.MATH_BF16X3, cin, 16, N, H, W, 9
+    grid = lib.hpfg_fused_bwd_grid(C.byref(fa))
+    assert grid > 0, lib.hpfg_last_error()
+    slab = torch.full((grid, 9, 16, 16), float("nan"), device=DEV)
+    fa.slab = L.ptr(slab)
+    L.check(lib.hpfg_fused_bwd(C.byref(fa), stream(DEV)), "fused_bwd")
+    torch.cuda.synchronize()
+    dw = slab.double().sum(0)[:, :cin, :16].permute(2, 1, 0).reshape(16, cin, 3, 3).float()
+    dw_ref = layer.wgrad(xa, None, gsrc, N, H, W, math=L.MATH_BF16X3)
+    assert maxerr(dw.cpu(), dw_ref.cpu()) < 1e-5 * max(1.0, float(dw_ref.abs().max()))
+    dz = _materialize(gsrc, None, N, H, W, 16)
+    xr = x.cpu().clone()
+    wr = layer.w.cpu().clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, padding=1).backward(nchw(dz))
+    assert maxerr(dw.cpu(), wr.grad) < 5e-4 * max(1.0, float(wr.grad.abs().max()))
