@@ -36,7 +36,7 @@ int dispatch(const HpfgFusedBwdArgs& a, hipStream_t st, bool grid_only) {
   }
   HPFG_FUSED_CASE(1, 1, HPFG_KIND_BNACT, HPFG_KIND_DZ, 4, 2, 1, 1)      // in_conv.c2, up4.c2
   HPFG_FUSED_CASE(1, 1, HPFG_KIND_BNACT, HPFG_KIND_PLAIN, 4, 2, 1, 1)   // out_conv
-  HPFG_FUSED_CASE(1, 2, HPFG_KIND_POOL, HPFG_KIND_DZ, 8, 1, 1, 1)       // down1.c1
+  HPFG_FUSED_CASE(1, 2, HPFG_KIND_POOL, HPFG_KIND_DZ, 8, 1, 1, 0)       // down1.c1
   HPFG_FUSED_CASE(2, 2, HPFG_KIND_BNACT, HPFG_KIND_DZ, 8, 1, 2, 1)      // down1.c2, up3.c2
   HPFG_FUSED_CASE(2, 1, HPFG_KIND_CAT, HPFG_KIND_DZ, 8, 1, 2, 1)        // up4.c1
 #undef HPFG_FUSED_CASE
