@@ -435,7 +435,7 @@ class UNetEngine:
         # one slab region per layer; all of them are summed by ONE launch at the end of backward()
         sizes = [self.lib.hpfg_wgrad_slab_floats(N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps) for s in self.order]
         self.fused_grid = {}
-        if self.fused_bwd and self.math == L.MATH_BF16X3 and self.wgrad_overlap == 0:
+        if self.fused_bwd and self.math == L.MATH_BF16X3 and self.wgrad_overlap in (0, 3):
             for i, s in enumerate(self.order):
                 if s.taps != 9:
                     continue

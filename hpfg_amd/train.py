@@ -490,8 +490,19 @@ class CPSStep(_StepBase):
     def device_step(self, label_img, target_label, unlabel_img):
         nl = label_img.shape[0]
         x = cat_batch(label_img, unlabel_img)
-        o1 = self.model1(x)
-        o2 = self.model2(x)
+        if self.overlap and os.environ.get("HPFG_STUDENT_OVERLAP", "1") == "1":
+            # the two students are independent until the losses: the second one's forward runs on the side stream, and autograd runs its
+            # backward there too (a backward node executes on the stream of its forward), so both chains of small kernels overlap
+            cur = torch.cuda.current_stream(self.dev)
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                o2 = self.model2(x)
+            o1 = self.model1(x)
+            cur.wait_stream(self.side)
+            o2.record_stream(cur)
+        else:
+            o1 = self.model1(x)
+            o2 = self.model2(x)
         p1 = argmax_labels(o1[nl:])
         p2 = argmax_labels(o2[nl:])
         coef = self.sc.view(S_COEF_A, 8)
@@ -561,12 +572,26 @@ class HPFGStep(_StepBase):
         nl = label_img.shape[0]
         mix_un = cutmix_blend(label_img1, img_unlabel, cutmix_mask)
         batch_mix = torch.cat([label_img, mix_un], 0)
-        o1, _, _ = self.model1(batch_mix)
+        split = self.overlap and os.environ.get("HPFG_STUDENT_OVERLAP", "1") == "1"
+        if split:      # student 1 (fed the CutMix batch) is independent of student 2 and the teacher until the losses: a stream of its own,
+            # forward and -- through autograd, which runs a backward node on the stream of its forward -- backward (see CPSStep)
+            cur = torch.cuda.current_stream(self.dev)
+            if getattr(self, "side2", None) is None:
+                self.side2 = torch.cuda.Stream(device=self.dev)
+            self.side2.wait_stream(cur)
+            with torch.cuda.stream(self.side2):
+                o1, _, _ = self.model1(batch_mix)
+        else:
+            o1, _, _ = self.model1(batch_mix)
         volume = cat_batch(label_img, img_unlabel)
         volume_t = volume
         ot, th1, th2 = self._teacher_forward(self.ema_model, volume_t)
         o2, h1, h2 = self.model2(volume)
         self._join_teacher(ot, th1, th2)
+        if split:
+            cur.wait_stream(self.side2)
+            o1.record_stream(cur)
+            batch_mix.record_stream(self.side2)
         pseudo = argmax_labels(ot[nl:], target_label1, cutmix_mask[:, 0])
         r1 = seg_loss(o1, target_label, nl, coef=self.sc.view(S_COEF_A, 8), pseudo=pseudo, dp=self.dp)
         r2 = seg_loss(o2, target_label, nl, coef=self.sc.view(S_COEF_B, 8), teacher_logits=ot, dp=self.dp)
@@ -631,8 +656,19 @@ class S4CVNetStep(_StepBase):
         nl = label_img.shape[0]
         x = cat_batch(label_img, unlabel_img)
         ot = self._teacher_forward(self.ema_model, noise_add(unlabel_img, noise))
-        o1 = self.model1(x)
-        o2 = self.model2(x)
+        if self.overlap and os.environ.get("HPFG_STUDENT_OVERLAP", "1") == "1":      # the U-Net on a stream of its own, forward and backward (see CPSStep)
+            cur = torch.cuda.current_stream(self.dev)
+            if getattr(self, "side2", None) is None:
+                self.side2 = torch.cuda.Stream(device=self.dev)
+            self.side2.wait_stream(cur)
+            with torch.cuda.stream(self.side2):
+                o1 = self.model1(x)
+            o2 = self.model2(x)
+            cur.wait_stream(self.side2)
+            o1.record_stream(cur)
+        else:
+            o1 = self.model1(x)
+            o2 = self.model2(x)
         self._join_teacher(ot)
         p1 = argmax_labels(o1[nl:])
         p2 = argmax_labels(o2[nl:])
