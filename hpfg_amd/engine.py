@@ -120,6 +120,8 @@ class UNetEngine:
         # thin 3x3 layers (16-pixel-aligned, <= 64 input / 32 output channels, split-bf16 math): ONE kernel produces the input gradient, the
         # weight-gradient slabs and the backward sums of the layer below from a single staging of dZ (hpfg_fused_bwd)
         self.fused_bwd = os.environ.get("HPFG_FUSED_BWD", "1") == "1"
+        self.defer_wgrad = os.environ.get("HPFG_DEFER_WGRAD", "1") == "1"
+        self._deferred = None
         self.fused_grid: Dict[str, int] = {}
         self._last_fused: Dict[str, "L.FusedBwdArgs"] = {}
         self._side, self._side_used = None, False
@@ -514,7 +516,10 @@ class UNetEngine:
         if s.name in self.fused_grid:
             return self._fused_bwd(s, g, dgrad_out, stats_for, out2)
         g = self.staged_dz(s, g)
-        if self.wgrad_overlap == 2:
+        if self._deferred is not None:      # decoder half: the weight gradient is queued for the side stream (see backward())
+            self._dgrad(s, g, dgrad_out, stats_for, out2)
+            self._deferred.append((s, g))
+        elif self.wgrad_overlap == 2:
             self._dgrad(s, g, dgrad_out, stats_for, out2)
             self._wgrad(s, g)
         else:
@@ -551,12 +556,14 @@ class UNetEngine:
             e1.record(torch.cuda.current_stream(self.dev))
             self.probe[1].append((e0, e1))
 
-    def _wgrad(self, s: ConvSpec, g: L.Act):
+    def _wgrad(self, s: ConvSpec, g: L.Act, on_side: bool = False):
         """Weight gradient of layer s.  It is off the critical chain of backward (nothing downstream consumes it before the final
         slab reduction), so it is issued on a second HIP stream forked behind the kernels recorded so far and joined at the end."""
         main = torch.cuda.current_stream(self.dev)
         # 3: only the layers whose grids do not fill the chip (<= 56 x 56: a few hundred workgroups each for dgrad and wgrad) share it
-        if self.wgrad_overlap in (1, 2) or (self.wgrad_overlap == 3 and s.taps == 9 and s.h <= 56):
+        if on_side:
+            stream = self._side.cuda_stream      # (the caller forked it)
+        elif self.wgrad_overlap in (1, 2) or (self.wgrad_overlap == 3 and s.taps == 9 and s.h <= 56):
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.dev)
             self._side.wait_stream(main)
@@ -618,6 +625,12 @@ class UNetEngine:
         st = self._stream()
         N = self.N
         sp = self.specs
+        # ONE fork for the decoder's separate weight gradients (the channel-rich layers and the 1x1 convs; the thin layers' are fused with their
+        # dgrad): they are queued while the decoder half back-propagates and run on the side stream beside the encoder half -- everything they
+        # read (dA, z, the BatchNorm tables of their layers) stays in place until the next forward.  A fork / join per layer cost more than it
+        # returned (HPFG_WGRAD_OVERLAP); this is one of each.  Not with the data-parallel buckets: the decoder's gradients must be final at the
+        # bucket boundary.
+        self._deferred = [] if (self.defer_wgrad and bucket_cb is None and self.wgrad_overlap == 0) else None
         # ---- out_conv
         s = sp["decoder.out_conv"]
         g = self._act_plain(dlogits, self.ncls, s.h, s.w)
@@ -646,6 +659,15 @@ class UNetEngine:
             self._wgrad_dgrad(su, gu, self.dA[prev], prev if (k > 1 or dfeat4 is None) else None)
         if dfeat4 is not None:
             self.dA[enc_prefix(4) + ".4"].add_(dfeat4)
+        if self._deferred:
+            main = torch.cuda.current_stream(self.dev)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.dev)
+            self._side.wait_stream(main)
+            for s_, g_ in self._deferred:
+                self._wgrad(s_, g_, on_side=True)
+            self._side_used = True
+        self._deferred = None
         if bucket_cb is not None:
             if self._side_used:
                 torch.cuda.current_stream(self.dev).wait_stream(self._side)
