@@ -659,15 +659,20 @@ class UNetEngine:
             self._wgrad_dgrad(su, gu, self.dA[prev], prev if (k > 1 or dfeat4 is None) else None)
         if dfeat4 is not None:
             self.dA[enc_prefix(4) + ".4"].add_(dfeat4)
-        if self._deferred:
-            main = torch.cuda.current_stream(self.dev)
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.dev)
-            self._side.wait_stream(main)
-            for s_, g_ in self._deferred:
-                self._wgrad(s_, g_, on_side=True)
-            self._side_used = True
-        self._deferred = None
+        defer = self._deferred is not None
+
+        def flush():
+            if self._deferred:
+                main = torch.cuda.current_stream(self.dev)
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.dev)
+                self._side.wait_stream(main)
+                for s_, g_ in self._deferred:
+                    self._wgrad(s_, g_, on_side=True)
+                self._side_used = True
+
+        flush()
+        self._deferred = [] if defer else None      # second batch: the channel-rich encoder layers, beside the thin layers' fused kernels
         if bucket_cb is not None:
             if self._side_used:
                 torch.cuda.current_stream(self.dev).wait_stream(self._side)
@@ -689,6 +694,9 @@ class UNetEngine:
                     self._wgrad(s1, g1)
             if lvl > 0:
                 self._wgrad_dgrad(s1, g1, self.dP[lvl])
+            if lvl == 2 and self._deferred is not None:
+                flush()
+                self._deferred = None
         if self._side_used:
             torch.cuda.current_stream(self.dev).wait_stream(self._side)
             self._side_used = False
