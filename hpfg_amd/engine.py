@@ -476,6 +476,8 @@ class UNetEngine:
         # descriptor order = encoder convs | decoder convs | bias pseudo layers (all decoder): two contiguous ranges, so the decoder's
         # weight gradients can be finished (and handed to the data-parallel all-reduce) while the encoder half still back-propagates
         self._n_enc_desc = sum(1 for s in self.order if s.name.startswith("encoder."))
+        # encoder levels 0 and 1 (in_conv, down1) come first: their slabs are written last (by the main stream's final kernels)
+        self._n_thin_enc_desc = sum(1 for s in self.order if s.name.startswith("encoder.in_conv") or s.name.startswith("encoder.down1"))
         self._bwd_alloc = True
 
     def _bn_backward(self, s: ConvSpec, pooled_grad: Optional[torch.Tensor] = None):
@@ -605,11 +607,14 @@ class UNetEngine:
             self._fused_rows[stats_for] = rows
         L.check(self.lib.hpfg_conv_fwd(C.byref(ca), self._stream()), f"dgrad[{s.name}]")
 
-    def _slab_reduce(self, lo: int, hi: int):
+    def _slab_reduce(self, lo: int, hi: int, stream=None):
         """Sum the weight-gradient slabs of descriptors [lo, hi) into the gradient buffer (one launch)."""
+        if hi <= lo:
+            return
         sz = C.sizeof(L.SlabDesc)
         host = (L.SlabDesc * (hi - lo)).from_buffer(self._slab_host, lo * sz)
-        L.check(self.lib.hpfg_slab_reduce_multi(self._slab_dev.data_ptr() + lo * sz, host, hi - lo, self._stream()), "slab_reduce_multi")
+        L.check(self.lib.hpfg_slab_reduce_multi(self._slab_dev.data_ptr() + lo * sz, host, hi - lo, stream if stream is not None else self._stream()),
+                "slab_reduce_multi")
 
     def backward(self, dlogits: torch.Tensor, dfeat4: Optional[torch.Tensor] = None, bucket_cb=None):
         """dlogits: [N,H,W,ncls] contiguous.  dfeat4: optional gradient w.r.t. the activated bottleneck [N,h,w,256].
@@ -661,17 +666,20 @@ class UNetEngine:
             self.dA[enc_prefix(4) + ".4"].add_(dfeat4)
         defer = self._deferred is not None
 
-        def flush():
-            if self._deferred:
+        def flush(lo, hi):
+            """queued weight gradients -> side stream, followed there by the slab reduction of descriptors [lo, hi) (all their producers -- these
+            launches and fused kernels already queued on the main stream -- are ordered before it by the fork)"""
+            if self._deferred is not None:
                 main = torch.cuda.current_stream(self.dev)
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=self.dev)
                 self._side.wait_stream(main)
                 for s_, g_ in self._deferred:
                     self._wgrad(s_, g_, on_side=True)
+                self._slab_reduce(lo, hi, self._side.cuda_stream)
                 self._side_used = True
 
-        flush()
+        flush(self._n_enc_desc, len(self._slab_host))
         self._deferred = [] if defer else None      # second batch: the channel-rich encoder layers, beside the thin layers' fused kernels
         if bucket_cb is not None:
             if self._side_used:
@@ -695,7 +703,7 @@ class UNetEngine:
             if lvl > 0:
                 self._wgrad_dgrad(s1, g1, self.dP[lvl])
             if lvl == 2 and self._deferred is not None:
-                flush()
+                flush(self._n_thin_enc_desc, self._n_enc_desc)
                 self._deferred = None
         if self._side_used:
             torch.cuda.current_stream(self.dev).wait_stream(self._side)
@@ -703,6 +711,8 @@ class UNetEngine:
         if bucket_cb is not None:
             self._slab_reduce(0, self._n_enc_desc)
             bucket_cb(1)
+        elif defer:
+            self._slab_reduce(0, self._n_thin_enc_desc)      # the rest was reduced on the side stream
         else:
             self._slab_reduce(0, len(self._slab_host))
         self.bwd_ready = False
