@@ -145,8 +145,12 @@ class _StepBase:
                             u.record_stream(cur)
             self._pending_join = False
 
-    def _attach(self, model):
+    def _attach(self, model, alone: bool = False):
+        """alone: the only trainable network of the step -- its backward may fork its off-chain weight gradients onto a side stream
+        (UNetEngine.backward); with two networks training on two streams that extra fork is not taken (see engine.py)."""
         model.dp = self.dp
+        if alone:
+            model.defer_wgrad = True
         if any(p.requires_grad for p in model.parameters()):
             model.direct_grads = True          # one zero_grad + one backward per step: write gradients in place (no memset, no add)
 
@@ -192,7 +196,7 @@ class SupervisedStep(_StepBase):
     def __init__(self, model, args, dp=None):
         super().__init__(next(model.parameters()).device, dp)
         self.model, self.args = model, args
-        self._attach(model)
+        self._attach(model, alone=True)
         self.optimizer = build_optimizer(args=args, model=model)
         self.lr_scheduler = build_lr_scheduler(args=args, optimizer=self.optimizer)
         self.optimizer._lr_dev = self.sc.view(S_LR1)
@@ -226,7 +230,7 @@ class MeanTeacherStep(_StepBase):
     def __init__(self, model, ema_model, args, dp=None):
         super().__init__(next(model.parameters()).device, dp)
         self.model, self.ema_model, self.args = model, ema_model, args
-        self._attach(model)
+        self._attach(model, alone=True)
         self._attach(ema_model)
         self.optimizer = build_optimizer(args=args, model=model)
         self.lr_scheduler = build_lr_scheduler(args=args, optimizer=self.optimizer)
@@ -318,7 +322,7 @@ class ICTStep(_StepBase):
     def __init__(self, model, ema_model, args, dp=None):
         super().__init__(next(model.parameters()).device, dp)
         self.model, self.ema_model, self.args = model, ema_model, args
-        self._attach(model)
+        self._attach(model, alone=True)
         self._attach(ema_model)
         self.optimizer = build_optimizer(args=args, model=model)
         self.lr_scheduler = build_lr_scheduler(args=args, optimizer=self.optimizer)
@@ -414,7 +418,7 @@ class UAMTStep(_StepBase):
     def __init__(self, model, ema_model, args, dp=None):
         super().__init__(next(model.parameters()).device, dp)
         self.model, self.ema_model, self.args = model, ema_model, args
-        self._attach(model)
+        self._attach(model, alone=True)
         self._attach(ema_model)
         self.optimizer = build_optimizer(args=args, model=model)
         self.lr_scheduler = build_lr_scheduler(args=args, optimizer=self.optimizer)
