@@ -1,4 +1,4 @@
-// Forward 3x3 convolution of the thin layers (16 / 32 input channels, or a 32-channel concat; 16 / 32 output channels; H and W multiples
+// 3x3 convolution of the thin layers -- forward, and the dgrad of a 32-channel layer into a 64-channel input (dZ source) -- (16 / 32 input channels, or a 32-channel concat; 16 / 32 output channels; H and W multiples
 // of 16) on the bf16 matrix cores with split-precision operands -- the forward twin of fused_bwd_kernel.h, built on what that kernel's
 // timelines and counters showed:
 //   * the WHOLE 18 x 18 halo tile of the (virtual) input -- all input channels -- is staged at once as [chunk][hi|lo][pixel slot][16 ch]
@@ -41,7 +41,8 @@ struct Geo {
   static constexpr int MI = 16 / NW;                               // 16-pixel MFMA tiles per wave
   static constexpr int KS = 5 * CI;                                // k-steps: 2 taps x 16 channels each
   static constexpr bool BREG = KS * CO * 8 <= 80;                  // weight fragments: registers or LDS
-  static constexpr int TAB = 2 * 16 * NA0 * 4;                     // scale / shift rows of the input's producer
+  static constexpr int TROWS = AK == HPFG_KIND_DZ ? 5 : 2;         // table rows of the loader: scale, shift [, k1, k2, k3 of a dZ source]
+  static constexpr int TAB = TROWS * 16 * NA0 * 4;
   static constexpr int STAT = 2 * NW * 16 * CO * 4;
   static constexpr int BFR = BREG ? 0 : KS * CO * 2 * 1024;
   static constexpr int OFF_TAB = CI * CH, OFF_STAT = OFF_TAB + TAB, OFF_U = OFF_STAT + STAT, OFF_B = OFF_U + NA1 * UBYTES;
@@ -69,9 +70,10 @@ __global__ __launch_bounds__(64 * NW, WGS) void conv_thin_kernel(HpfgConvArgs p,
   const ActCtx cxa = make_ctx(aS);
   const int gsel = tid & 1;                              // this thread's 8-channel group inside a 16-channel chunk
 
-  for (int i = tid; i < 2 * 16 * NA0; i += NTH) {
+  for (int i = tid; i < G::TROWS * 16 * NA0; i += NTH) {
     const int r = i / (16 * NA0), ch = i % (16 * NA0);
-    tabA[i] = ch < aS.C ? aS.bn[aS.bn_coff + (r == 0 ? HPFG_BN_SCALE : HPFG_BN_SHIFT) * aS.bn_stride + ch] : 0.f;
+    const int row = r == 0 ? HPFG_BN_SCALE : r == 1 ? HPFG_BN_SHIFT : r == 2 ? HPFG_BN_K1 : r == 3 ? HPFG_BN_K2 : HPFG_BN_K3;
+    tabA[i] = ch < aS.C ? aS.bn[aS.bn_coff + row * aS.bn_stride + ch] : 0.f;
   }
   const int ntn = p.CoutPad / 16;
   const bf16x8* wpk = reinterpret_cast<const bf16x8*>(p.wpk);
@@ -162,6 +164,11 @@ __global__ __launch_bounds__(64 * NW, WGS) void conv_thin_kernel(HpfgConvArgs p,
       for (int h = 0; h < 2; ++h) {
         ta.sc[h] = ld4(tabA, 0 * 16 * NA0 + c0 + 4 * h);
         ta.sh[h] = ld4(tabA, 1 * 16 * NA0 + c0 + 4 * h);
+        if (AK0 == HPFG_KIND_DZ) {
+          ta.k1[h] = ld4(tabA, 2 * 16 * NA0 + c0 + 4 * h);
+          ta.k2[h] = ld4(tabA, 3 * 16 * NA0 + c0 + 4 * h);
+          ta.k3[h] = ld4(tabA, 4 * 16 * NA0 + c0 + 4 * h);
+        }
       }
 #pragma unroll
       for (int i = 0; i < ND; ++i) {

@@ -76,3 +76,30 @@ def test_thin_conv_equals_the_chunked_kernel_bitwise(N, H, W, cin, cout, ak, p):
     a_in = _materialize(a0, a1, N, H, W, cin)
     want = F.conv2d(nchw(a_in), layer.w.cpu(), layer.b.cpu(), padding=1)
     assert maxerr(nchw(out.cpu()), want) < 3e-4 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("N,H,W,p", [(2, 32, 48, 0.0), (5, 48, 32, 0.2)])
+def test_thin_dgrad_of_the_64_to_32_layer_equals_the_chunked_kernel(N, H, W, p):
+    """dgrad of a 64 -> 32 channel layer (decoder.up3's first conv at 112^2): dZ source of 32 channels, 64 output channels, weights in LDS."""
+    from tests.test_gpu_fused_bwd import _dz
+    g = torch.Generator().manual_seed(H + W)
+    layer = AdHocConv(64, 32, 9, DEV, seed=4, hw=(H, W))
+    zo = torch.randn(N, H, W, 32, generator=g).to(DEV)
+    dA = torch.randn(N, H, W, 32, generator=g).to(DEV)
+    tabo = _bn_table(32, 11).to(DEV)
+    d = _dz(zo, tabo, dA, 32, H, W, p=p, seed=21)
+    def dgrad(math):
+        ca = L.ConvArgs()
+        ca.a0, ca.a1, ca.math, ca.wpk = d, L.Act(), math, L.ptr(layer.wpk16_d)
+        out = torch.full((N, H, W, 64), float("nan"), device=DEV)
+        ca.out, ca.out_pstride, ca.Cout, ca.CoutPad, ca.N, ca.H, ca.W, ca.taps = L.ptr(out), 64, 64, 64, N, H, W, 9
+        L.check(L.load().hpfg_conv_fwd(C.byref(ca), stream(DEV)), "dgrad")
+        torch.cuda.synchronize()
+        return out
+
+    got, ref = dgrad(L.MATH_BF16X3), dgrad(L.MATH_BF16X3 | OLD)
+    assert torch.equal(got, ref), f"dgrad differs: {maxerr(got.cpu(), ref.cpu())}"
+    dz = _materialize(d, None, N, H, W, 32)
+    xr = torch.zeros(N, 64, H, W, requires_grad=True)
+    F.conv2d(xr, layer.w.cpu(), None, padding=1).backward(nchw(dz))
+    assert maxerr(nchw(got.cpu()), xr.grad) < 3e-4 * max(1.0, float(xr.grad.abs().max()))
