@@ -1,5 +1,5 @@
 import ctypes as C, sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hpfg_amd import _lib as L
 lib = L.load()
 dev = torch.device("cuda:0")
