@@ -52,7 +52,12 @@ def parse():
     ap.add_argument("--force-sync", action="store_true", help="diagnostics: run the data-parallel code path (RCCL collectives) on one rank")
     ap.add_argument("--sync-bn", action="store_true", help="N > 1: all-reduce every BatchNorm statistic and the loss sums (R ranks == one process on the "
                     "global batch) instead of the default per-rank BatchNorm + averaged gradients (DDP semantics)")
-    ap.add_argument("--no-overlap", action="store_true", help="N > 1: one blocking gradient all-reduce after backward instead of bucketed, overlapped ones")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N > 1: bucketed gradient all-reduce overlapped with the encoder half of backward (a chain of three hipGraphs around two eager "
+                         "RCCL calls).  Default is ONE all-reduce between two hipGraphs: measured on one rank (nccl, this flag vs none) the chain costs "
+                         "130-250 us per step -- it cannot queue the decoder's weight gradients onto the side stream and pays two more graph "
+                         "launches -- which is more than the 7.26 MB all-reduce it would hide takes over xGMI")
+    ap.add_argument("--no-overlap", action="store_true", help="(the default; kept for older command lines)")
     return ap.parse_args()
 
 
@@ -152,7 +157,7 @@ def main():
         dp = parallel.init_from_env(dev, backend=os.environ.get("HPFG_DP_BACKEND") or None)
         dp.force_sync = bool(a.force_sync)
         dp.sync_bn = bool(a.sync_bn or (a.force_sync and os.environ.get("HPFG_BENCH_LOCAL_BN", "0") != "1"))
-        dp.overlap = not a.no_overlap
+        dp.overlap = bool(a.overlap) and not a.no_overlap
     model, ema, step = build_step(dev, a, a.math, dp)
     xl, yl = synth_batch(1234 + rank, a.lab, a.size, a.size, 1, 4, 32)
     xu, _ = synth_batch(91234 + rank, a.unlab, a.size, a.size, 1, 4, 32)
@@ -193,7 +198,8 @@ def main():
         par = f"dp{world}"
         if world > 1:
             par += " (sync BatchNorm + loss sums: == one process on the global batch)" if (dp is not None and dp.sync_bn) else \
-                " (per-rank BatchNorm, gradients averaged by bucketed all-reduces overlapped with backward)"
+                (" (per-rank BatchNorm, gradients averaged by bucketed all-reduces overlapped with backward)" if dp is not None and dp.overlap else
+                 " (per-rank BatchNorm, gradients averaged by one all-reduce between two hipGraphs)")
         out = {
             "metric": "labeled+unlabeled images/sec/node, U-Net 224x224 ACDC-shaped (Mean-Teacher step)", "value": round(value, 2),
             "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4),
