@@ -167,7 +167,7 @@ __device__ inline void up_taps(int lo, int L, int* idx, float* wgt, int& cnt) {
 // produced the low-res tensor (model/unet.py:50) is sum_p dU, and the slab reduction adds the rows in a fixed order.
 constexpr int UPB_MAXDIM = 512, UPB_TAPS = 6;
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dUp, int dup_ps, float* __restrict__ dU, int N, int Hl, int Wl,
-                                                           int C, float* __restrict__ csum) {
+                                                           int C, float* __restrict__ csum, int xcd_aware) {
   __shared__ short t_idx[UPB_MAXDIM][UPB_TAPS];
   __shared__ float t_w[UPB_MAXDIM][UPB_TAPS];
   __shared__ unsigned char t_cnt[UPB_MAXDIM];
@@ -188,7 +188,16 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
   const int Q = C / 4, Ho = 2 * Hl, Wo = 2 * Wl;
   const long total = (long)N * Hl * Wl * Q;
   f32x4 csum4 = {0.f, 0.f, 0.f, 0.f};
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {      // 256 % Q == 0: a thread keeps its channel quad
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Every XCD owns a CONTIGUOUS eighth of the
+  // outputs and its workgroups sweep it side by side (grid-stride inside the eighth), so the high-res rows that neighbouring low-res rows
+  // both gather from are in flight on one XCD at one time and are fetched once (linear grid-stride over all XCDs fetched 2x the
+  // algorithmic bytes; PMC: 199 -> 137 MB per step for a contiguous run per workgroup).
+  const int nxcd = (xcd_aware && gridDim.x % 8 == 0) ? 8 : 1;
+  const long gx = gridDim.x / nxcd, xj = blockIdx.x / nxcd;
+  const long span = ((total + nxcd - 1) / nxcd + 255) / 256 * 256;      // outputs per XCD, whole 256-thread rows
+  const long x0 = (long)(blockIdx.x % nxcd) * span;
+  const long x1 = x0 + span < total ? x0 + span : total;
+  for (long i = x0 + xj * 256 + threadIdx.x; i < x1; i += gx * 256) {      // 256 % Q == 0: a thread keeps its channel quad
     int q = (int)(i % Q);
     long pp = i / Q;
     int xl = (int)(pp % Wl), yl = (int)((pp / Wl) % Hl), n = (int)(pp / ((long)Wl * Hl));
@@ -547,8 +556,9 @@ extern "C" int hpfg_upsample2x_bwd_sums(const float* dUp, int dup_pstride, float
                                         void* stream) {
   HPFG_ARG_CHECK(dUp && dU && C % 4 == 0 && C >= 4 && N > 0 && Hl > 0 && Wl > 0 && Hl + Wl <= UPB_MAXDIM, "upsample2x_bwd: bad args");
   HPFG_ARG_CHECK(!csum_partials || (C <= 256 && 256 % (C / 4) == 0), "upsample2x_bwd: channel sums need C/4 to divide 256 (C=%d)", C);
+  static const int xcd_aware = getenv("HPFG_UPB_XCD") ? atoi(getenv("HPFG_UPB_XCD")) : 1;      // 0: contiguous runs dealt to the XCDs round-robin (A/B)
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3(hpfg_upsample2x_bwd_blocks(N, Hl, Wl, C)), dim3(256), 0, (hipStream_t)stream, dUp, dup_pstride, dU, N,
-                     Hl, Wl, C, csum_partials);
+                     Hl, Wl, C, csum_partials, xcd_aware);
   return hpfg_launch_status("upsample_bwd_kernel");
 }
 

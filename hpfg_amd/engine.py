@@ -309,39 +309,62 @@ class UNetEngine:
     def forward(self, x: torch.Tensor, train: bool = True, dropout: Optional[bool] = None, track_running: bool = True,
                 seed_step: Optional[int] = None, needs_grad: bool = True) -> torch.Tensor:
         """x: [N,C,H,W] fp32 on the device (any strides).  Returns logits as an [N,H,W,ncls] tensor (fresh allocation)."""
-        st = self._stream()
         logits = self._fwd_begin(x, train, dropout, seed_step, needs_grad)
         for s in self.order:
-            out = logits if s.name == "decoder.out_conv" else self.z[s.name]
-            want_stats = bool(s.bn) and train
-            nblk = self.lib.hpfg_conv_stat_blocks(self.N, s.h, s.w)
-            if s.idx == 0:
-                a0, _ = self.staged_inputs(s, fresh=True)
-                L.check(self.lib.hpfg_conv3x3_first_fwd(C.byref(a0), L.ptr(self.params[f"{s.name}.weight"]), L.ptr(self.params[f"{s.name}.bias"]),
-                                                        L.ptr(out), L.ptr(self.partials) if want_stats else None, self.N, s.h, s.w, s.cin, s.cout, st),
-                        "conv3x3_first_fwd")
-                nblk = self.lib.hpfg_conv_first_rows(self.N, s.h, s.w)
-            else:
-                ca = self._conv_args(s, out, want_stats)
-                probe = self.probe is not None and self.probe[0] == s.name
-                if probe:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(torch.cuda.current_stream(self.dev))
-                L.check(self.lib.hpfg_conv_fwd(C.byref(ca), st), f"conv_fwd[{s.name}]")
-                if probe:
-                    e1.record(torch.cuda.current_stream(self.dev))
-                    self.probe[1].append((e0, e1))
-                if want_stats:
-                    nblk = self.lib.hpfg_conv_stat_rows(C.byref(ca))
-            if s.bn:
-                if train:
-                    self._finalize_bn(s, nblk, track_running)
-                else:
-                    L.check(self.lib.hpfg_bn_eval_table(L.ptr(self.params[f"{s.bn}.weight"]), L.ptr(self.params[f"{s.bn}.bias"]),
-                                                        L.ptr(self.buffers[f"{s.bn}.running_mean"]), L.ptr(self.buffers[f"{s.bn}.running_var"]), BN_EPS,
-                                                        L.ptr(self.bn[s.name]), s.cout, st), "bn_eval_table")
+            self._fwd_layer(s, logits, train, track_running)
         self.bwd_ready = bool(train and needs_grad)
         return logits
+
+    def _fwd_layer(self, s: ConvSpec, logits: torch.Tensor, train: bool, track_running: bool):
+        """One conv of the schedule (+ its BatchNorm table) on the current stream."""
+        st = self._stream()
+        out = logits if s.name == "decoder.out_conv" else self.z[s.name]
+        want_stats = bool(s.bn) and train
+        nblk = self.lib.hpfg_conv_stat_blocks(self.N, s.h, s.w)
+        if s.idx == 0:
+            a0, _ = self.staged_inputs(s, fresh=True)
+            L.check(self.lib.hpfg_conv3x3_first_fwd(C.byref(a0), L.ptr(self.params[f"{s.name}.weight"]), L.ptr(self.params[f"{s.name}.bias"]),
+                                                    L.ptr(out), L.ptr(self.partials) if want_stats else None, self.N, s.h, s.w, s.cin, s.cout, st),
+                    "conv3x3_first_fwd")
+            nblk = self.lib.hpfg_conv_first_rows(self.N, s.h, s.w)
+        else:
+            ca = self._conv_args(s, out, want_stats)
+            probe = self.probe is not None and self.probe[0] == s.name
+            if probe:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream(self.dev))
+            L.check(self.lib.hpfg_conv_fwd(C.byref(ca), st), f"conv_fwd[{s.name}]")
+            if probe:
+                e1.record(torch.cuda.current_stream(self.dev))
+                self.probe[1].append((e0, e1))
+            if want_stats:
+                nblk = self.lib.hpfg_conv_stat_rows(C.byref(ca))
+        if s.bn:
+            if train:
+                self._finalize_bn(s, nblk, track_running)
+            else:
+                L.check(self.lib.hpfg_bn_eval_table(L.ptr(self.params[f"{s.bn}.weight"]), L.ptr(self.params[f"{s.bn}.bias"]),
+                                                    L.ptr(self.buffers[f"{s.bn}.running_mean"]), L.ptr(self.buffers[f"{s.bn}.running_var"]), BN_EPS,
+                                                    L.ptr(self.bn[s.name]), s.cout, st), "bn_eval_table")
+
+    @staticmethod
+    def forward_interleaved(ea: "UNetEngine", eb: "UNetEngine", xa: torch.Tensor, xb: torch.Tensor, stream_b, track_running=(True, True),
+                            seed_steps=(None, None), needs_grad=(True, False)):
+        """Train-mode forward of two networks with the same schedule, `ea` on the current stream and `eb` on `stream_b` (already forked behind
+        the current one), their launches ISSUED ALTERNATELY, layer by layer.  Same kernels, same results as ea.forward / eb.forward on those two
+        streams; only the order in which the launches are queued (and captured into a hipGraph) differs: a graph's nodes reach the hardware
+        queues in creation order, one after the other, so a network whose whole forward is captured first keeps the other one's first kernel
+        waiting for its ~60 submissions (`tools/stream_timeline.py`: 108 us)."""
+        assert len(ea.order) == len(eb.order)
+        la = ea._fwd_begin(xa, True, None, seed_steps[0], needs_grad[0])
+        with torch.cuda.stream(stream_b):
+            lb = eb._fwd_begin(xb, True, None, seed_steps[1], needs_grad[1])
+        for sa, sb in zip(ea.order, eb.order):
+            ea._fwd_layer(sa, la, True, track_running[0])
+            with torch.cuda.stream(stream_b):
+                eb._fwd_layer(sb, lb, True, track_running[1])
+        ea.bwd_ready, eb.bwd_ready = bool(needs_grad[0]), bool(needs_grad[1])
+        return la, lb
 
     def pairable(self, other: "UNetEngine") -> bool:
         """Can forward_pair() run this engine and `other` layer by layer in shared launches?"""
@@ -677,7 +700,8 @@ class UNetEngine:
                     self._side = torch.cuda.Stream(device=self.dev)
                 self._side.wait_stream(main)
                 for s_, g_ in self._deferred:
-                    self._wgrad(s_, g_, on_side=True)
+                    if os.environ.get("HPFG_SKIP_WGRAD", "0") != "1":       # timing experiment only (stale gradients): what the queued launches cost
+                        self._wgrad(s_, g_, on_side=True)
                 self._slab_reduce(lo, hi, self._side.cuda_stream)
                 self._side_used = True
 

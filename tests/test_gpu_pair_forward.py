@@ -99,3 +99,41 @@ def test_mean_teacher_step_with_paired_forward_equals_the_two_stream_step(monkey
     monkeypatch.setenv("HPFG_PAIR_FWD", "1")
     l1, p1, e1 = run()
     assert l0 == l1 and torch.equal(p0, p1) and torch.equal(e0, e1)
+
+
+def test_mean_teacher_step_with_interleaved_launches_equals_the_default_step(monkeypatch):
+    """HPFG_INTERLEAVE_FWD=1 (student and teacher on two streams, launches issued layer by layer in turn; UNetEngine.forward_interleaved)
+    runs the same kernels as the default step: same trajectory bit for bit, eager and captured."""
+    from copy import deepcopy
+
+    from hpfg_amd.train import GraphedStep, MeanTeacherStep
+    from hpfg_amd.datasets.synthetic import synth_batch
+    from tests.test_gpu_dp_path import _args
+
+    def run(graph):
+        torch.manual_seed(7)
+        reset_dropout_streams()
+        m = UNet(1, 4).to(DEV)
+        ema = deepcopy(m)
+        for p in ema.parameters():
+            p.requires_grad = False
+        m.train()
+        ema.train()
+        st = MeanTeacherStep(m, ema, _args())
+        xl, yl = synth_batch(1, 2, 64, 64, 1, 4, 8)
+        xu, _ = synth_batch(2, 2, 64, 64, 1, 4, 8)
+        xl, yl, xu = xl.to(DEV), yl.to(DEV), xu.to(DEV)
+        if graph:
+            r = GraphedStep(st, [xl, yl, xu], warmup=2)
+            losses = [float(r.step([xl, yl, xu], k)["loss"]) for k in range(3, 6)]
+        else:
+            losses = [float(st.step(xl, yl, xu, k, cons_w=0.05)["loss"]) for k in range(1, 4)]
+        torch.cuda.synchronize()
+        return losses, m.flat_params.clone(), ema.flat_params.clone()
+
+    for graph in (False, True):
+        monkeypatch.setenv("HPFG_INTERLEAVE_FWD", "0")
+        l0, p0, e0 = run(graph)
+        monkeypatch.setenv("HPFG_INTERLEAVE_FWD", "1")
+        l1, p1, e1 = run(graph)
+        assert l0 == l1 and torch.equal(p0, p1) and torch.equal(e0, e1), graph
