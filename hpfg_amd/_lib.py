@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ, ACT_PLANES = range(8)
 LOSS_NSUM = 32
-VERSION = 122
+VERSION = 123
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -165,6 +165,7 @@ PROTOTYPES = {
     "hpfg_sgd_step": (_i, [_p, _p, _p, _l, _p, _f, _f, _f, _p]),
     "hpfg_adamw_step": (_i, [_p, _p, _p, _p, _l, _p, _p, _f, _f, _f, _f, _f, _p]),
     "hpfg_ema_update": (_i, [_p, _p, _l, _p, _p]),
+    "hpfg_sgd_ema_step": (_i, [_p, _p, _p, _l, _p, _f, _f, _f, _p, _l, _p, _p]),
     "hpfg_attn_mfma_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "hpfg_attn_mfma_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "hpfg_attn_mfma_blocks": (_i, [_i]),

@@ -419,6 +419,7 @@ __global__ __launch_bounds__(256) void confusion_kernel(const uint8_t* __restric
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom, long n,
                                                   const float* __restrict__ lr_dev, float momentum, float wd, float gscale) {
+#pragma clang fp contract(off)      // separately rounded products, as the reference's optimizer: the fused and the two-launch forms agree bit for bit
   const float lr = *lr_dev;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float w = p[i];
@@ -426,6 +427,25 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     float b = momentum * mom[i] + d;
     mom[i] = b;
     p[i] = w - lr * b;
+  }
+}
+
+// SGD step + EMA teacher update in one pass (the Mean-Teacher family ends every step with both: 2017_03_NIPS_Mean-Teacher_ACDC.py:108-113):
+// the fresh weight goes into the teacher's average from a register instead of being read back by a second launch.  Same expressions as
+// sgd_kernel / ema_kernel, so the results are bit-identical to the two launches.
+__global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom, long n,
+                                                      const float* __restrict__ lr_dev, float momentum, float wd, float gscale,
+                                                      float* __restrict__ t, long n_ema, const float* __restrict__ alpha_dev) {
+#pragma clang fp contract(off)      // separately rounded products, as the reference's optimizer: the fused and the two-launch forms agree bit for bit
+  const float lr = *lr_dev, a = *alpha_dev;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float w = p[i];
+    float d = g[i] * gscale + wd * w;
+    float b = momentum * mom[i] + d;
+    mom[i] = b;
+    const float s = w - lr * b;
+    p[i] = s;
+    if (i < n_ema) t[i] = t[i] * a + s * (1.f - a);
   }
 }
 
@@ -453,6 +473,7 @@ __global__ void step_inc_kernel(float* step_dev) {
 }
 
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const float* __restrict__ s, long n, const float* __restrict__ alpha_dev) {
+#pragma clang fp contract(off)      // separately rounded products, as the reference's optimizer: the fused and the two-launch forms agree bit for bit
   const float a = *alpha_dev;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) t[i] = t[i] * a + s[i] * (1.f - a);
 }
@@ -644,6 +665,14 @@ extern "C" int hpfg_sgd_step(float* p, const float* g, float* mom, long n, const
   HPFG_ARG_CHECK(p && g && mom && lr_dev && n > 0, "sgd_step: bad args");
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, mom, n, lr_dev, momentum, weight_decay, grad_scale);
   return hpfg_launch_status("sgd_kernel");
+}
+
+extern "C" int hpfg_sgd_ema_step(float* p, const float* g, float* mom, long n, const float* lr_dev, float momentum, float weight_decay, float grad_scale,
+                                 float* t, long n_ema, const float* alpha_dev, void* stream) {
+  HPFG_ARG_CHECK(p && g && mom && lr_dev && t && alpha_dev && n > 0 && n_ema >= 0 && n_ema <= n && t != p, "sgd_ema_step: bad args");
+  hipLaunchKernelGGL(sgd_ema_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, mom, n, lr_dev, momentum, weight_decay, grad_scale,
+                     t, n_ema, alpha_dev);
+  return hpfg_launch_status("sgd_ema_kernel");
 }
 
 extern "C" int hpfg_adamw_step(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float* step_dev, float beta1, float beta2,

@@ -29,6 +29,7 @@ from . import _lib as L
 from .utils import (BoxMaskGenerator, build_lr_scheduler, build_optimizer, ema_alpha, linear_rampup, seg_loss, sigmoid_rampup,
                     update_ema_variables, update_ema_variables_backbone)
 from .utils.loss import _nhwc
+from .utils.optim import FusedSGD
 from .model.unet import can_interleave, can_pair, forward_pair
 
 # layout of the per-step scalar block (device fp32 [32])
@@ -153,6 +154,17 @@ class _StepBase:
             model.defer_wgrad = True
         if any(p.requires_grad for p in model.parameters()):
             model.direct_grads = True          # one zero_grad + one backward per step: write gradients in place (no memset, no add)
+
+    def _sgd_ema_update(self):
+        """optimizer.step(); update_ema_variables(model, ema_model, ...) -- the tail of every Mean-Teacher-family iteration
+        (2017_03_NIPS_Mean-Teacher_ACDC.py:108-113) -- as ONE launch over the student's flat buffers where the optimizer offers it."""
+        fs, ft = getattr(self.model, "flat_params", None), getattr(self.ema_model, "flat_params", None)
+        if (os.environ.get("HPFG_FUSE_SGD_EMA", "1") == "1" and isinstance(self.optimizer, FusedSGD) and fs is not None and ft is not None
+                and fs.numel() == ft.numel() and fs.is_cuda):
+            self.optimizer.step(push_lr=False, ema=(ft, fs.numel(), self.sc.view(S_ALPHA)))
+        else:
+            self.optimizer.step(push_lr=False)
+            update_ema_variables(self.model, self.ema_model, self.args.ema_decay, 0, alpha_dev=self.sc.view(S_ALPHA))
 
     def _loss_backward(self, res):
         """backward() of the fused loss vector [total, parts...]: only element 0 carries gradient; a constant one-hot gradient
@@ -284,8 +296,7 @@ class MeanTeacherStep(_StepBase):
         self._reduce_grads(self.model)
 
     def device_update(self):
-        self.optimizer.step(push_lr=False)
-        update_ema_variables(self.model, self.ema_model, self.args.ema_decay, 0, alpha_dev=self.sc.view(S_ALPHA))
+        self._sgd_ema_update()
         self._mark(7)
 
     def device_step(self, label_img, target_label, unlabel_img):
@@ -368,8 +379,7 @@ class ICTStep(_StepBase):
         self.optimizer.zero_grad()
         self._loss_backward(res)
         self._reduce_grads(self.model)
-        self.optimizer.step(push_lr=False)
-        update_ema_variables(self.model, self.ema_model, self.args.ema_decay, 0, alpha_dev=self.sc.view(S_ALPHA))
+        self._sgd_ema_update()
         return {"loss": res[0].detach(), "parts": res.detach(), "logits": out.detach(), "t_prob": tp}
 
     def after(self):
@@ -463,8 +473,7 @@ class UAMTStep(_StepBase):
         self.optimizer.zero_grad()
         self._loss_backward(res)
         self._reduce_grads(self.model)
-        self.optimizer.step(push_lr=False)
-        update_ema_variables(self.model, self.ema_model, self.args.ema_decay, 0, alpha_dev=self.sc.view(S_ALPHA))
+        self._sgd_ema_update()
         return {"loss": res[0].detach(), "parts": res.detach(), "logits": out.detach(), "mask": mask, "t_logits": ema_out.detach()}
 
     def after(self):

@@ -34,7 +34,9 @@ class FusedSGD(torch.optim.Optimizer):
         self._lr_dev.copy_(self._lr_host, non_blocking=True)
 
     @torch.no_grad()
-    def step(self, closure=None, push_lr: bool = True):
+    def step(self, closure=None, push_lr: bool = True, ema=None):
+        """ema: optional (teacher_flat, numel, alpha_dev) -- the EMA teacher update of the same iteration rides along in the same launch
+        (hpfg_sgd_ema_step; bit-identical to step() followed by utils.update_ema_variables)."""
         g = self.param_groups[0]
         flat, grad = self.model.flat_params, self.model.flat_grads
         if self._mom.data_ptr() == 0 or self._mom.numel() != flat.numel() or self._mom.device != flat.device:
@@ -42,6 +44,13 @@ class FusedSGD(torch.optim.Optimizer):
         if push_lr:
             self.push_lr()
         st = torch.cuda.current_stream(flat.device).cuda_stream
+        if ema is not None:
+            t, n_ema, alpha_dev = ema
+            assert t.is_cuda and t.dtype == torch.float32 and t.numel() == flat.numel() and 0 <= n_ema <= flat.numel()
+            L.check(L.load().hpfg_sgd_ema_step(L.ptr(flat), L.ptr(grad), L.ptr(self._mom), flat.numel(), L.ptr(self._lr_dev), float(g["momentum"]),
+                                               float(g["weight_decay"]), float(self.grad_scale), L.ptr(t), int(n_ema), L.ptr(alpha_dev), st),
+                    "sgd_ema_step")
+            return
         L.check(L.load().hpfg_sgd_step(L.ptr(flat), L.ptr(grad), L.ptr(self._mom), flat.numel(), L.ptr(self._lr_dev), float(g["momentum"]),
                                        float(g["weight_decay"]), float(self.grad_scale), st), "sgd_step")
 

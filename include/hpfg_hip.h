@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 122
+#define HPFG_VERSION 123
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -346,6 +346,12 @@ int hpfg_adamw_step(float* p, const float* g, float* m, float* v, long n, const 
                     float weight_decay, float grad_scale, void* stream);
 /* EMA teacher: t = alpha*t + (1-alpha)*s over flat buffers (utils/utils.py:82-86); alpha read from device */
 int hpfg_ema_update(float* t, const float* s, long n, const float* alpha_dev, void* stream);
+
+/* Both in one pass over the student's flat buffers -- the last two statements of every Mean-Teacher-family iteration
+ * (2017_03_NIPS_Mean-Teacher_ACDC.py:108-113: optimizer.step(); update_ema_variables(...)): t[i] = alpha*t[i] + (1-alpha)*p_new[i] for i < n_ema
+ * (n_ema = n, or the leading backbone slice of main.py:68-76).  Bit-identical to hpfg_sgd_step followed by hpfg_ema_update. */
+int hpfg_sgd_ema_step(float* p, const float* g, float* mom, long n, const float* lr_dev, float momentum, float weight_decay, float grad_scale,
+                      float* t, long n_ema, const float* alpha_dev, void* stream);
 
 /* ---- attention core on the matrix cores (SegFormer branch; reference model/segformer.py:92-128 after the q / kv projections) -------------- */
 /* out = softmax(scale * q k^T) v per (image, head): q [B,N,heads,32], kv [B,M,2,heads,32] (the kv Linear's output), M <= 64 keys, head dim 32;

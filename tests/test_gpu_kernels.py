@@ -337,3 +337,24 @@ def test_planes_from_pooled_and_concatenated_sources():
     pl, keep = _planes(s, b, N, H, W, 2 * C_)
     got, _ = layer2.conv(pl, None, N, H, W, math=L.MATH_BF16X3)
     assert maxerr(got.cpu(), ref.cpu()) < 1e-5 * max(1.0, float(ref.abs().max()))      # the concat kernel blends the bilinear taps from an LDS patch: same values, other rounding order
+
+
+def test_sgd_ema_step_equals_the_two_launches_bitwise():
+    """hpfg_sgd_ema_step == hpfg_sgd_step followed by hpfg_ema_update (full buffer and a leading slice), bit for bit."""
+    from hpfg_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(11)
+    n = 100_003
+    st = torch.cuda.current_stream(DEV).cuda_stream
+    for n_ema in (n, 4097, 0):
+        p0, gr, m0, t0 = (torch.randn(n, generator=g).to(DEV) for _ in range(4))
+        lr = torch.tensor([0.0123], device=DEV)
+        al = torch.tensor([0.987], device=DEV)
+        pa, ma, ta = p0.clone(), m0.clone(), t0.clone()
+        L.check(lib.hpfg_sgd_step(L.ptr(pa), L.ptr(gr), L.ptr(ma), n, L.ptr(lr), 0.9, 5e-4, 0.5, st), "sgd")
+        if n_ema:
+            L.check(lib.hpfg_ema_update(L.ptr(ta), L.ptr(pa), n_ema, L.ptr(al), st), "ema")
+        pb, mb, tb = p0.clone(), m0.clone(), t0.clone()
+        L.check(lib.hpfg_sgd_ema_step(L.ptr(pb), L.ptr(gr), L.ptr(mb), n, L.ptr(lr), 0.9, 5e-4, 0.5, L.ptr(tb), n_ema, L.ptr(al), st), "sgd_ema")
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(ta, tb), n_ema
