@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ, ACT_PLANES = range(8)
 LOSS_NSUM = 32
-VERSION = 123
+VERSION = 124
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -102,6 +102,7 @@ PROTOTYPES = {
     "hpfg_conv_kc": (_i, [_i, _i, _i]),
     "hpfg_wpk16_elems": (_l, [_i, _i, _i, _i]),
     "hpfg_pack_weights": (_i, [_p, C.POINTER(PackDesc), _i, _p]),
+    "hpfg_pack_weights_bump": (_i, [_p, C.POINTER(PackDesc), _i, _p, _i, _p, _i, _p]),
     "hpfg_act_materialize": (_i, [C.POINTER(Act), C.POINTER(Act), _i, _i, _i, _p, _p]),
     "hpfg_act_to_planes": (_i, [C.POINTER(Act), C.POINTER(Act), _i, _i, _i, _p, _p]),
     "hpfg_dropout_mask": (_i, [_p, _l, _f, _u32, _p, _p]),

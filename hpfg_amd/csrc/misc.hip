@@ -19,7 +19,14 @@ namespace {
 // ---- weight packing: OIHW -> MFMA B-fragment order (see conv.hip) ------------------------------------------------------
 // fwd  : wpk[tap][ch][nt][lane][ks] = W[co = nt*16 + (lane&15)][ci = ch*16 + ks*4 + (lane>>4)][tap]
 // dgrad: wpk[tap][ch][nt][lane][ks] = W[co = ch*16 + ks*4 + (lane>>4)][ci = nt*16 + (lane&15)][taps-1-tap]
-__global__ __launch_bounds__(256) void pack_weights_kernel(const HpfgPackDesc* __restrict__ table) {
+// Two per-forward device counters ride along (one workgroup, before any packing): num_batches_tracked of the network's BatchNorm layers
+// (+1 each) and the dropout seed word of the engine (+seed_add) -- no launches of their own in front of every forward.
+__global__ __launch_bounds__(256) void pack_weights_kernel(const HpfgPackDesc* __restrict__ table, long long* __restrict__ counters, int n_counters,
+                                                           int* __restrict__ seed_word, int seed_add) {
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    for (int i = threadIdx.x; i < n_counters; i += 256) counters[i] += 1;
+    if (threadIdx.x == 0 && seed_word && seed_add) *seed_word = (*seed_word + seed_add) & 0x7FFFFFFF;
+  }
   const HpfgPackDesc d = table[blockIdx.y];
   const long total = (long)d.taps * d.CinPad * d.CoutPad;
   const int nt_f = d.CoutPad / 16, nch_f = d.CinPad / 16;
@@ -493,8 +500,10 @@ extern "C" long hpfg_wpk16_elems(int Kchannels, int NchannelsPad, int taps, int 
   return (long)((Kchannels + kc - 1) / kc) * ksteps * (NchannelsPad / 16) * 2 * 64 * 8;
 }
 
-extern "C" int hpfg_pack_weights(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, void* stream) {
+extern "C" int hpfg_pack_weights_bump(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, long long* counters, int n_counters,
+                                      int32_t* seed_word, int seed_add, void* stream) {
   HPFG_ARG_CHECK(table_dev && table_host && nlayers > 0 && nlayers < 65536, "pack_weights: bad args");
+  HPFG_ARG_CHECK(n_counters >= 0 && (n_counters == 0 || counters) && (seed_add == 0 || seed_word), "pack_weights: bad counter arguments");
   long mx = 0;
   for (int i = 0; i < nlayers; ++i) {
     const HpfgPackDesc& d = table_host[i];
@@ -504,8 +513,13 @@ extern "C" int hpfg_pack_weights(const HpfgPackDesc* table_dev, const HpfgPackDe
     long t = (long)d.taps * d.CinPad * d.CoutPad;
     if (t > mx) mx = t;
   }
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(mx, 256), nlayers), dim3(256), 0, (hipStream_t)stream, table_dev);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(mx, 256), nlayers), dim3(256), 0, (hipStream_t)stream, table_dev, counters, n_counters, seed_word,
+                     seed_add);
   return hpfg_launch_status("pack_weights_kernel");
+}
+
+extern "C" int hpfg_pack_weights(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, void* stream) {
+  return hpfg_pack_weights_bump(table_dev, table_host, nlayers, nullptr, 0, nullptr, 0, stream);
 }
 
 namespace {

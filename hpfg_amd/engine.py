@@ -17,6 +17,8 @@ import torch
 
 from . import _lib as L
 
+SEED_BUMP = -1      # seed_step value: advance the engine's seed word on the device (inside the forward's first launch)
+
 WIDTHS = (16, 32, 64, 128, 256)          # model/unet.py:161
 ENC_DROPOUT = (0.05, 0.1, 0.2, 0.3, 0.5)  # model/unet.py:162
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -105,6 +107,7 @@ class UNetEngine:
                         for s in self.packed}
         self._pack_tables: Dict[tuple, tuple] = {}   # (math, with_dgrad) -> (host descriptors, device copy), built on first use
         self.seed_dev = torch.zeros(1, dtype=torch.int32, device=device)   # run-time dropout seed word
+        self.bump_counters: Optional[torch.Tensor] = None      # set by the module in front of a train-mode forward: int64 counters the pack launch advances
         self.base_seed = 0x1234567
         self.train_stats = True
         self.bwd_ready = False
@@ -262,9 +265,15 @@ class UNetEngine:
             self._pack_tables[key] = (descs, dev)
         return self._pack_tables[key]
 
-    def pack(self, with_dgrad: bool = True):
+    def pack(self, with_dgrad: bool = True, counters: Optional[torch.Tensor] = None, seed_add: int = 0):
+        """counters: int64 tensor whose elements the same launch advances by one (num_batches_tracked of the network's BatchNorm layers);
+        seed_add: advance of the engine's dropout seed word (hpfg_pack_weights_bump)."""
         host, dev = self._pack_table(self.math, with_dgrad)
-        L.check(self.lib.hpfg_pack_weights(dev.data_ptr(), host, len(self.packed), self._stream()), "pack_weights")
+        if counters is not None:
+            assert counters.dtype == torch.int64 and counters.is_contiguous() and counters.device == self.dev
+        L.check(self.lib.hpfg_pack_weights_bump(dev.data_ptr(), host, len(self.packed), L.ptr(counters) if counters is not None else None,
+                                                counters.numel() if counters is not None else 0, L.ptr(self.seed_dev), int(seed_add), self._stream()),
+                "pack_weights")
 
     def _finalize_bn(self, s: ConvSpec, nblk: int, track: bool):
         if self._skip_fin and self._fin_done.get(s.name):      # timing experiment only (HPFG_SKIP_FINALIZE=1): stale tables
@@ -290,9 +299,12 @@ class UNetEngine:
         self.x = x
         self.train_mode = train
         self.dropout_on = train if dropout is None else dropout
-        if seed_step is not None:
+        # seed_step: None = leave the seed word alone; SEED_BUMP = advance it on the device (a step being captured into a hipGraph: every
+        # replay then draws new masks); otherwise the host's per-forward counter value
+        if seed_step is not None and seed_step != SEED_BUMP:
             self.seed_dev.fill_(int(seed_step) & 0x7FFFFFFF)
-        self.pack(with_dgrad=bool(train and needs_grad))
+        counters, self.bump_counters = self.bump_counters, None
+        self.pack(with_dgrad=bool(train and needs_grad), counters=counters, seed_add=1 if seed_step == SEED_BUMP else 0)
         return torch.empty(self.N, self.H, self.W, self.ncls, dtype=torch.float32, device=self.dev)
 
     def _conv_args(self, s: ConvSpec, out: torch.Tensor, want_stats: bool) -> L.ConvArgs:

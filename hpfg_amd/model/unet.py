@@ -83,10 +83,14 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor: torch.Tensor, x: torch.Tensor, net: "UNet", want_feat: bool, needs_grad: bool):
         eng = net._acquire_engine(x)
+        if getattr(net, "_bn_bump_pending", False):
+            eng.bump_counters, net._bn_bump_pending = net._flat_long, False
         comp, net._companion = getattr(net, "_companion", None), None
         if comp is not None:      # forward_pair(): a second network of the same geometry rides along in the same launches (no gradient)
             net_b, x_b, side = comp
             eng_b = net_b._acquire_engine(x_b)
+            if getattr(net_b, "_bn_bump_pending", False):
+                eng_b.bump_counters, net_b._bn_bump_pending = net_b._flat_long, False
             if side is not None:      # two streams, launches issued alternately
                 logits, logits_b = E.UNetEngine.forward_interleaved(eng, eng_b, x, x_b, side, seed_steps=(net._next_seed(), net_b._next_seed()),
                                                                     needs_grad=(needs_grad, False))
@@ -273,17 +277,15 @@ class UNet(nn.Module):
 
     # ---- engines ----------------------------------------------------------------------------------------------
     def _next_seed(self):
-        """Per-forward dropout seed word.  While a step is being captured into a hipGraph the engines keep their device seed
-        word untouched (None): GraphedStep bumps it on the device before every replay instead."""
+        """Per-forward dropout seed word.  While a step is being captured into a hipGraph the forward advances the engine's device seed
+        word itself (E.SEED_BUMP, inside its first launch), so every replay draws new masks."""
         if getattr(self, "_graph_seed_mode", False):
-            return None
+            return E.SEED_BUMP
         self._seed_counter += 1
         return self._seed_counter
 
     def bump_graph_seed(self):
-        for pool in self._engines.values():
-            for e in pool:
-                e.seed_dev.add_(1)
+        """Nothing to do in front of a replay: a forward captured in graph-seed mode advances its engine's seed word itself (E.SEED_BUMP)."""
 
     def _acquire_engine(self, x: torch.Tensor) -> E.UNetEngine:
         if not x.is_cuda:
@@ -347,7 +349,9 @@ class UNet(nn.Module):
                     p.grad = self._flat_grad[off:off + k].view(p.shape)
 
     def _bump_bn_counters(self):
-        self._flat_long.add_(1)      # num_batches_tracked of all 18 BatchNorm layers, one kernel
+        """num_batches_tracked += 1 of all 18 BatchNorm layers (one flat int64 buffer): done by the forward's first launch, the weight packing
+        (UNetEngine.bump_counters -> hpfg_pack_weights_bump), not by a kernel of its own."""
+        self._bn_bump_pending = True
 
     def _run(self, x: torch.Tensor, want_feat: bool):
         self._ensure_flat()

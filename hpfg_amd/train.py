@@ -815,7 +815,7 @@ class GraphedStep:
         self.s.host_scalars(cur_itrs, **kw)
         self.s.sc.push()          # eager H2D copy of this step's scalars from a fresh ring slot, ordered in front of the replay
         for m in self._models():
-            m.bump_graph_seed()
+            m.bump_graph_seed()      # (the U-Nets advance their seed words inside the captured forward; the SegFormer branch does it here)
         if self.split:
             dp = self.s.dp
             for i, g in enumerate(self.graphs):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 123
+#define HPFG_VERSION 124
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -175,6 +175,11 @@ int hpfg_bn_eval_table(const float* gamma, const float* beta, const float* runni
 int hpfg_conv_kc(int H, int W, int taps);
 long hpfg_wpk16_elems(int Kchannels, int NchannelsPad, int taps, int kc);   /* bf16 elements of one wpk16 buffer */
 int hpfg_pack_weights(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, void* stream);
+/* The same launch also advances two per-forward device counters (nn.BatchNorm2d's num_batches_tracked += 1 of a train-mode forward,
+ * model/unet.py:14-27 via torch; and the engine's dropout seed word, so that a replayed hipGraph draws fresh nn.Dropout masks):
+ * counters[0..n_counters) += 1 (int64), *seed_word = (*seed_word + seed_add) & 0x7fffffff.  Either may be absent (0 / NULL). */
+int hpfg_pack_weights_bump(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, long long* counters, int n_counters,
+                           int32_t* seed_word, int seed_add, void* stream);
 /* evaluate a virtual activation into memory (tests, projection-neck inputs): out [N,H,W,a0.C+a1.C] */
 int hpfg_act_materialize(const HpfgAct* a0, const HpfgAct* a1, int N, int H, int W, float* out, void* stream);
 /* the dropout keep-mask the loaders use, as bytes [n_elems] (tests feed it to the oracle) */
