@@ -358,3 +358,35 @@ def test_sgd_ema_step_equals_the_two_launches_bitwise():
         L.check(lib.hpfg_sgd_ema_step(L.ptr(pb), L.ptr(gr), L.ptr(mb), n, L.ptr(lr), 0.9, 5e-4, 0.5, L.ptr(tb), n_ema, L.ptr(al), st), "sgd_ema")
         torch.cuda.synchronize()
         assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(ta, tb), n_ema
+
+
+def test_forward_advances_bn_counters_and_seed_word_inside_the_pack_launch():
+    """num_batches_tracked += 1 per train-mode forward and the engine's dropout seed word (host-counted when eager, +1 on the device in
+    graph-seed mode) are advanced by hpfg_pack_weights_bump, the forward's first launch -- same values as nn.BatchNorm2d would hold."""
+    from hpfg_amd.model import UNet
+    from hpfg_amd.model.unet import reset_dropout_streams
+    reset_dropout_streams()
+    torch.manual_seed(0)
+    m = UNet(1, 4).to(DEV)
+    m.train()
+    x = torch.randn(2, 1, 32, 32, device=DEV)
+    for k in range(1, 4):
+        m(x).sum().backward()                          # (backward releases the engine: the next forward takes the same one)
+        torch.cuda.synchronize()
+        nbt = [int(b) for n, b in m.named_buffers() if n.endswith("num_batches_tracked")]
+        assert len(nbt) == 18 and all(v == k for v in nbt), (k, nbt)
+    engs = [e for pool in m._engines.values() for e in pool]
+    assert len(engs) == 1
+    eng = engs[0]
+    assert int(eng.seed_dev) == 3                      # eager: the module's per-forward counter
+    m._graph_seed_mode = True                          # what GraphedStep sets while capturing: the forward bumps the word on the device
+    m(x).sum().backward()
+    m(x).sum().backward()
+    m._graph_seed_mode = False
+    torch.cuda.synchronize()
+    assert int(eng.seed_dev) == 5
+    m.eval()
+    with torch.no_grad():
+        m(x)
+    torch.cuda.synchronize()
+    assert all(int(b) == 5 for n, b in m.named_buffers() if n.endswith("num_batches_tracked"))      # eval forwards do not count
