@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ, ACT_PLANES = range(8)
 LOSS_NSUM = 32
-VERSION = 124
+VERSION = 125
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -138,6 +138,7 @@ PROTOTYPES = {
     "hpfg_dwgelu_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "hpfg_dwgelu_bwd_blocks": (_i, [_i, _i, _i]),
     "hpfg_resize_bilinear_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "hpfg_resize_sum_fwd": (_i, [_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), _i, _p, _i, _i, _i, _i, _p]),
     "hpfg_resize_bilinear_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "hpfg_residual_scale": (_i, [_p, _p, _p, _p, _i, _l, _p]),
     "hpfg_scale_rows": (_i, [_p, _p, _p, _i, _l, _p]),

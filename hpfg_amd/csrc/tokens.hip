@@ -413,6 +413,7 @@ __global__ __launch_bounds__(256) void dwgelu_fwd_kernel(const float* __restrict
 }
 
 // du = dy * gelu'(u) (u recomputed), plus per-workgroup partial sums of dbias and dweight[9] in part[blockIdx][10][C]
+constexpr int DWG_QW = 64;
 __global__ __launch_bounds__(256) void dwgelu_bwd_du_kernel(const float* __restrict__ x, const float* __restrict__ w9, const float* __restrict__ bias,
                                                             const float* __restrict__ dy, float* __restrict__ du, float* __restrict__ part, int B, int H,
                                                             int W, int C) {
@@ -420,14 +421,17 @@ __global__ __launch_bounds__(256) void dwgelu_bwd_du_kernel(const float* __restr
   const int Q = C / 4;                       // 256 % Q == 0 or Q % 256 == 0 is NOT required: a thread's channel quad changes per item,
   const long total = (long)B * H * W * Q;    // so the partial sums are accumulated per (item % Q) through LDS below
   // each workgroup owns a contiguous range of pixels and loops over channel quads inside: thread t <-> quad (t % Qw), pixel lane t / Qw
-  const int Qw = Q < 256 ? Q : 256;          // quads handled concurrently
+  // and blockIdx.y picks a slice of DWG_QW channel quads, so that at least 4 pixels are in flight per workgroup whatever C is (with all of a
+  // wide stage's quads in one workgroup a thread walked its 32 pixels one after the other: 70 - 160 us of pure load latency per launch)
+  const int Qw = Q < DWG_QW ? Q : DWG_QW;    // quads handled concurrently
   const int PL = 256 / Qw;                   // pixel lanes
   const long npix = (long)B * H * W;
   const long per = (npix + gridDim.x - 1) / gridDim.x;
   const long p0 = (long)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
   const int ql = threadIdx.x % Qw, pl = threadIdx.x / Qw;
   (void)total;
-  for (int qb = 0; qb < Q; qb += Qw) {
+  {
+    const int qb = blockIdx.y * Qw;
     const int c = (qb + ql) * 4;
     f32x4 acc[10];
 #pragma unroll
@@ -512,6 +516,41 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict
     const f32x4 cc = *reinterpret_cast<const f32x4*>(base + ((long)y1 * w + x0) * C), d = *reinterpret_cast<const f32x4*>(base + ((long)y1 * w + x1) * C);
     const f32x4 top = a + (bb - a) * wx, bot = cc + (d - cc) * wx;
     *reinterpret_cast<f32x4*>(y + p * C + c) = top + (bot - top) * wy;
+  }
+}
+
+// y = base + sum_k resize(x_k): the SegFormer head's fused feature map as one pass (model/segformer.py head: the stage outputs, already through
+// their slice of linear_fuse, are brought to the 1/4-resolution grid and added) -- one read of base, one write of y, the low-res maps from L2.
+struct ResizeSrc {
+  const float* x;
+  int h, w;
+  float sy, sx;
+};
+__global__ __launch_bounds__(256) void resize_sum_fwd_kernel(const float* __restrict__ base, ResizeSrc s0, ResizeSrc s1, ResizeSrc s2, int nsrc,
+                                                             float* __restrict__ y, int B, int H, int W, int C) {
+  const int Q = C / 4;
+  const long total = (long)B * H * W * Q;
+  const ResizeSrc src[3] = {s0, s1, s2};
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % Q) * 4;
+    const long p = i / Q;
+    const int X = (int)(p % W), Y = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+    f32x4 acc = *reinterpret_cast<const f32x4*>(base + p * C + c);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k >= nsrc) break;
+      const int h = src[k].h, w = src[k].w;
+      int y0, y1, x0, x1;
+      float wy, wx;
+      rs_src(Y, src[k].sy, h, y0, y1, wy);
+      rs_src(X, src[k].sx, w, x0, x1, wx);
+      const float* bp = src[k].x + (long)b * h * w * C + c;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(bp + ((long)y0 * w + x0) * C), bb = *reinterpret_cast<const f32x4*>(bp + ((long)y0 * w + x1) * C);
+      const f32x4 cc = *reinterpret_cast<const f32x4*>(bp + ((long)y1 * w + x0) * C), d = *reinterpret_cast<const f32x4*>(bp + ((long)y1 * w + x1) * C);
+      const f32x4 top = a + (bb - a) * wx, bot = cc + (d - cc) * wx;
+      acc += top + (bot - top) * wy;
+    }
+    *reinterpret_cast<f32x4*>(y + p * C + c) = acc;
   }
 }
 
@@ -878,7 +917,8 @@ extern "C" int hpfg_dwgelu_bwd(const float* x, const float* w9, const float* bia
                                float* partials, int B, int H, int W, int C, void* stream) {
   HPFG_ARG_CHECK(x && w9 && bias && dy && du && dx && dw9 && dbias && partials && B > 0 && H > 0 && W > 0 && C % 4 == 0 && C >= 4, "dwgelu_bwd: bad args");
   const int nblk = hpfg_dwgelu_bwd_blocks(B, H, W);
-  hipLaunchKernelGGL(dwgelu_bwd_du_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, w9, bias, dy, du, partials, B, H, W, C);
+  const int Q = C / 4, Qw = Q < DWG_QW ? Q : DWG_QW;
+  hipLaunchKernelGGL(dwgelu_bwd_du_kernel, dim3(nblk, (Q + Qw - 1) / Qw), dim3(256), 0, (hipStream_t)stream, x, w9, bias, dy, du, partials, B, H, W, C);
   hipLaunchKernelGGL(dw_bwd_dx_kernel, dim3(grid_cap((long)B * H * W * (C / 4), 8192)), dim3(256), 0, (hipStream_t)stream, du, w9, dx, B, H, W, C);
   HPFG_ARG_CHECK(dbias == dw9 + 9 * C, "dwgelu_bwd: dw9 and dbias must be one [10][C] buffer");
   hipLaunchKernelGGL(col_reduce_kernel, dim3(10 * C), dim3(64), 0, (hipStream_t)stream, partials, nblk, 10 * C, dw9);
@@ -890,6 +930,19 @@ extern "C" int hpfg_resize_bilinear_fwd(const float* x, float* y, int B, int h, 
   hipLaunchKernelGGL(resize_fwd_kernel, dim3(grid_cap((long)B * H * W * (C / 4), 8192)), dim3(256), 0, (hipStream_t)stream, x, y, B, h, w, H, W, C,
                      (float)h / (float)H, (float)w / (float)W);
   return hpfg_launch_status("resize_fwd_kernel");
+}
+
+extern "C" int hpfg_resize_sum_fwd(const float* base, const float* const* xs, const int* hs, const int* ws, int nsrc, float* y, int B, int H, int W, int C,
+                                   void* stream) {
+  HPFG_ARG_CHECK(base && xs && hs && ws && y && nsrc >= 0 && nsrc <= 3 && B > 0 && H > 0 && W > 0 && C % 4 == 0 && C >= 4, "resize_sum_fwd: bad args");
+  ResizeSrc s[3] = {{nullptr, 1, 1, 1.f, 1.f}, {nullptr, 1, 1, 1.f, 1.f}, {nullptr, 1, 1, 1.f, 1.f}};
+  for (int k = 0; k < nsrc; ++k) {
+    HPFG_ARG_CHECK(xs[k] && hs[k] > 0 && ws[k] > 0, "resize_sum_fwd: bad source %d", k);
+    s[k] = ResizeSrc{xs[k], hs[k], ws[k], (float)hs[k] / (float)H, (float)ws[k] / (float)W};
+  }
+  hipLaunchKernelGGL(resize_sum_fwd_kernel, dim3(grid_cap((long)B * H * W * (C / 4), 8192)), dim3(256), 0, (hipStream_t)stream, base, s[0], s[1], s[2], nsrc,
+                     y, B, H, W, C);
+  return hpfg_launch_status("resize_sum_fwd_kernel");
 }
 
 extern "C" int hpfg_resize_bilinear_bwd(const float* dy, float* dx, int B, int h, int w, int H, int W, int C, void* stream) {

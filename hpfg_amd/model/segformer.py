@@ -22,10 +22,12 @@ Tokens are kept as [B, N, C] == NHWC throughout.  Stochastic depth and the head'
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
-from ..ops_tokens import attention, bn_relu_dropout, dwconv_gelu, im2col, layer_norm, linear, residual_scale, resize_bilinear
+from ..ops_tokens import attention, bn_relu_dropout, dwconv_gelu, im2col, layer_norm, linear, residual_scale, resize_bilinear, resize_sum
 
 MIT_SETTINGS = {"B0": [[32, 64, 160, 256], [2, 2, 2, 2]]}
 HEADS, SR = [1, 2, 5, 8], [8, 4, 2, 1]
@@ -179,15 +181,29 @@ class SegFormerHead(nn.Module):
     def forward(self, feats, dropout_mask=None):
         B = feats[0][0].shape[0]
         H, W = feats[0][1], feats[0][2]
-        outs = []
-        for i, (t, h, w) in enumerate(feats):
-            p = getattr(self, f"linear_c{i + 1}").proj
-            y = linear(t, p.weight, p.bias)                                      # [B, h*w, E] tokens
-            if i > 0:
-                y = resize_bilinear(y.view(B, h, w, -1), H, W).view(B, H * W, -1)          # HIP, NHWC
-            outs.append(y)
         cv, bn = self.linear_fuse.conv, self.linear_fuse.bn
-        z = linear(torch.cat(outs[::-1], dim=2), cv.weight.reshape(cv.weight.shape[0], -1))      # 1x1 conv without bias == GEMM over tokens
+        wf = cv.weight.reshape(cv.weight.shape[0], -1)                           # [E, 4E]; the concat order is c4, c3, c2, c1
+        E = wf.shape[1] // len(feats)
+        if os.environ.get("HPFG_HEAD_FUSE_LOWRES", "1") == "1":
+            # linear_fuse(cat(up(y4), up(y3), up(y2), y1)) = sum_i up(W_i y_i): the bias-free 1x1 conv acts per pixel and the bilinear resize per
+            # channel, so they commute -- each stage's slice of the fuse weights is applied at the stage's own resolution (1/4 .. 1/64 of the
+            # pixels) and only the E-channel results are resized and added.  No [B, H*W, 4E] concat (411 MB at 32 x 56 x 56 tokens) is written,
+            # read by the GEMM and by its two backward GEMMs; the same sum in a different association (fp32, |diff| ~ 1e-6 relative).
+            zs = []
+            for i, (t, h, w) in enumerate(feats):
+                p = getattr(self, f"linear_c{i + 1}").proj
+                slot = len(feats) - 1 - i
+                zs.append(linear(linear(t, p.weight, p.bias), wf[:, slot * E:(slot + 1) * E]).view(B, h, w, -1))      # NHWC [B, h, w, E]
+            z = resize_sum(zs[0], *zs[1:]).view(B, H * W, -1)                   # one HIP pass: zs[0] + sum of the resized others
+        else:
+            outs = []
+            for i, (t, h, w) in enumerate(feats):
+                p = getattr(self, f"linear_c{i + 1}").proj
+                y = linear(t, p.weight, p.bias)                                      # [B, h*w, E] tokens
+                if i > 0:
+                    y = resize_bilinear(y.view(B, h, w, -1), H, W).view(B, H * W, -1)          # HIP, NHWC
+                outs.append(y)
+            z = linear(torch.cat(outs[::-1], dim=2), wf)      # 1x1 conv without bias == GEMM over tokens
         if self.training:          # nn.BatchNorm2d (train) + ReLU + nn.Dropout2d(0.1) (whole channels per sample): HIP kernels over the tokens
             if dropout_mask is None:
                 dropout_mask = torch.empty(B, z.shape[2], 1, 1, device=z.device).bernoulli_(0.9)

@@ -2,6 +2,8 @@
 softmax(q k^T) v, and depthwise-3x3 + GELU.  Device tensors only; the library raises if it is missing (no fallback)."""
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 import torch.nn.functional as F
 
@@ -168,6 +170,44 @@ class _Resize(torch.autograd.Function):
         dx = torch.empty(B, h, w, C_, dtype=torch.float32, device=dy.device)
         L.check(L.load().hpfg_resize_bilinear_bwd(L.ptr(dyc), L.ptr(dx), B, h, w, H, W, C_, _st(dy)), "resize_bwd")
         return dx, None, None
+
+
+class _ResizeSum(torch.autograd.Function):
+    """base [B,H,W,C] + sum_k resize(x_k [B,h_k,w_k,C]) in one pass (hpfg_resize_sum_fwd); backward: the gradient itself for base, the
+    resize backward of it for every x_k."""
+
+    @staticmethod
+    def forward(ctx, base, *xs):
+        _need_gpu(base, "resize_sum")
+        bc = base.contiguous().float()
+        B, H, W, C_ = bc.shape
+        xc = [x.contiguous().float() for x in xs]
+        assert 1 <= len(xc) <= 3 and all(x.shape[0] == B and x.shape[3] == C_ for x in xc)
+        y = torch.empty_like(bc)
+        ptrs = (C.c_void_p * len(xc))(*[x.data_ptr() for x in xc])
+        hs, ws = (C.c_int * len(xc))(*[x.shape[1] for x in xc]), (C.c_int * len(xc))(*[x.shape[2] for x in xc])
+        L.check(L.load().hpfg_resize_sum_fwd(L.ptr(bc), ptrs, hs, ws, len(xc), L.ptr(y), B, H, W, C_, _st(base)), "resize_sum_fwd")
+        ctx.geo = (B, H, W, C_, [(x.shape[1], x.shape[2]) for x in xc])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C_, lows = ctx.geo
+        dyc = dy.contiguous()
+        outs = [dyc if ctx.needs_input_grad[0] else None]
+        for k, (h, w) in enumerate(lows):
+            if not ctx.needs_input_grad[1 + k]:
+                outs.append(None)
+                continue
+            dx = torch.empty(B, h, w, C_, dtype=torch.float32, device=dy.device)
+            L.check(L.load().hpfg_resize_bilinear_bwd(L.ptr(dyc), L.ptr(dx), B, h, w, H, W, C_, _st(dy)), "resize_bwd")
+            outs.append(dx)
+        return tuple(outs)
+
+
+def resize_sum(base: torch.Tensor, *xs: torch.Tensor) -> torch.Tensor:
+    """base + sum_k F.interpolate(x_k, size=base's, mode="bilinear", align_corners=False), NHWC, C % 4 == 0, up to 3 addends."""
+    return _ResizeSum.apply(base, *xs)
 
 
 def resize_bilinear(x: torch.Tensor, H: int, W: int) -> torch.Tensor:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 124
+#define HPFG_VERSION 125
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -317,6 +317,10 @@ int hpfg_dwgelu_bwd_blocks(int B, int H, int W);
 /* F.interpolate(mode="bilinear", align_corners=False) of SegFormerHead.forward (:314,319) on NHWC [B,h,w,C] -> [B,H,W,C]; backward is a
  * gather over the outputs that tap a source pixel (no atomics), upsampling only */
 int hpfg_resize_bilinear_fwd(const float* x, float* y, int B, int h, int w, int H, int W, int C, void* stream);
+/* y = base + sum_k resize(xs[k]) (same bilinear map per source; base, y: [B,H,W,C]; xs[k]: [B,hs[k],ws[k],C]; nsrc <= 3; y may alias base):
+ * the head's sum over stages of F.interpolate(...) (model/segformer.py:309-314 with linear_fuse applied per stage) in one pass */
+int hpfg_resize_sum_fwd(const float* base, const float* const* xs, const int* hs, const int* ws, int nsrc, float* y, int B, int H, int W, int C,
+                        void* stream);
 int hpfg_resize_bilinear_bwd(const float* dy, float* dx, int B, int h, int w, int H, int W, int C, void* stream);
 /* ConvModule's BatchNorm2d (train) + ReLU and the head's Dropout2d (segformer.py:288-296,307,318) over tokens [R,C]:
  * column sums (sum x, sum x^2) -> the caller forms mean / rstd (and the running statistics) -> apply; mask [R/rows_per_image][C] of

@@ -91,6 +91,28 @@ def test_resize_bilinear(B, h, w, H, W, C_):
     assert maxerr(xd.grad.cpu(), xr.grad) < 2e-5
 
 
+@pytest.mark.parametrize("B,H,W,C_,lows", [(2, 56, 56, 256, [(28, 28), (14, 14), (7, 7)]), (3, 24, 20, 8, [(12, 10)]), (1, 16, 16, 64, [(8, 8), (4, 4)])])
+def test_resize_sum(B, H, W, C_, lows):
+    """base + sum_k interpolate(x_k) in one pass (the head's fused map, model/segformer.py:309-314 with linear_fuse applied per stage)."""
+    from hpfg_amd.ops_tokens import resize_sum
+    g = torch.Generator().manual_seed(H * 7 + len(lows))
+    base = torch.randn(B, H, W, C_, generator=g)
+    xs = [torch.randn(B, h, w, C_, generator=g) for h, w in lows]
+    dy = torch.randn(B, H, W, C_, generator=g)
+    br, xr = base.clone().requires_grad_(True), [x.clone().requires_grad_(True) for x in xs]
+    yr = br
+    for x in xr:
+        yr = yr + F.interpolate(x.permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    yr.backward(dy)
+    bd, xd = base.to(DEV).requires_grad_(True), [x.to(DEV).requires_grad_(True) for x in xs]
+    y = resize_sum(bd, *xd)
+    y.backward(dy.to(DEV))
+    assert maxerr(y.detach().cpu(), yr.detach()) < 2e-5
+    assert maxerr(bd.grad.cpu(), br.grad) == 0.0
+    for a_, r_ in zip(xd, xr):
+        assert maxerr(a_.grad.cpu(), r_.grad) < 5e-5
+
+
 @pytest.mark.parametrize("B,N,C_,use_mask", [(2, 256, 256, True), (3, 49, 256, False), (2, 1000, 64, True)])
 def test_bn_relu_dropout(B, N, C_, use_mask):
     g = torch.Generator().manual_seed(N)
