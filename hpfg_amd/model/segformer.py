@@ -12,7 +12,9 @@ Same module tree, parameter names and constructor order as the reference's ``mod
     head dim 32 = one MFMA k-step; forward, dQ and dK / dV kernels without LDS transposes of the probabilities);
   - every LayerNorm, depthwise 3x3 + GELU of the Mix-FFN, the head's bilinear resizes and its BatchNorm(train) + ReLU + Dropout2d,
     im2col / col2im of the overlap patch embeddings, residual adds with their drop-path factor (``csrc/tokens.hip``);
-* still plain PyTorch-ROCm ops: the channel concat of the head and the token <-> image reshape copies (memory movement only).
+* the head never builds the 4E-channel concat: ``linear_fuse`` (bias-free 1x1 conv) is applied per stage at the stage's resolution and the four
+  E-channel maps are resized and added in one pass (``hpfg_resize_sum_fwd``; reference model/segformer.py:309-315 up to fp32 association);
+* still plain PyTorch-ROCm ops: the token <-> image reshape copies and the slices of the fuse weight (memory movement only).
 No MIOpen call is left in the module: with MIOpen convolutions / BatchNorm the forward was not bit-reproducible between identical runs
 (logits differing by ~4e-7), and one ReLU gate of the head flipping on such noise moves every gradient upstream by ~1e-3; without it the
 forward is bit-identical run to run.
