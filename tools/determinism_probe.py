@@ -7,6 +7,8 @@ import test_gpu_fullsize as T
 from hpfg_amd.train import MeanTeacherStep
 from hpfg_amd.datasets.synthetic import synth_batch
 def run():
+    from hpfg_amd.model.unet import reset_dropout_streams
+    reset_dropout_streams()          # every network instance owns a dropout stream: the second run must start where the first one did
     a = T._cfg("mean_teacher_unet_30k_224x224_ACDC.yaml")
     torch.manual_seed(a.seed)
     m = T.build_model(a).to(T.DEV); e = T._teacher(m); m.train(); e.train()
