@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ, ACT_PLANES = range(8)
 LOSS_NSUM = 32
-VERSION = 125
+VERSION = 126
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -175,6 +175,8 @@ PROTOTYPES = {
     "hpfg_gemm_f32_splitk": (_i, [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _p, _i, _i, _p, _p]),
     "hpfg_gemm_f32_splits": (_i, [_i, _i, _i]),
     "hpfg_gemm_bf16x3": (_i, [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _p, _i, _i, _p]),
+    "hpfg_gemm_bf16x3_splits": (_i, [_i, _i, _i]),
+    "hpfg_gemm_bf16x3_splitk": (_i, [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _p, _i, _i, _p, _p]),
     "hpfg_gemm_bf16x3_ok": (_i, [_p, _l, _l, _p, _l, _l, _i, _i, _i]),
     "hpfg_gemm_tn_bf16x3": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _p]),
     "hpfg_gemm_tn_splits": (_i, [_l, _i, _i]),

@@ -284,7 +284,9 @@ struct Gemm16Args {
   int M, N, K, relu, accumulate;
 };
 
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(Gemm16Args p) {
+// blockIdx.z = K split (as gemm_f32_kernel): split z covers k in [z * kper, (z + 1) * kper), kper a multiple of 32, and with several splits writes
+// its partial product (no bias / activation) to C + z * M * ldc; gemm_splitk_finish_kernel adds them in a fixed order.
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(Gemm16Args p, int kper) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * PLANE_B];      // A hi | A lo | B hi | B lo
   unsigned char* ldsA = lds;
   unsigned char* ldsB = lds + 2 * PLANE_B;
@@ -297,10 +299,15 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(Gemm16Args p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 ra[4], rb[4];
-  tile_load(p.a, m0, 0, tid, ra);
-  tile_load(p.b, n0, 0, tid, rb);
+  const int kbeg = blockIdx.z * kper, kend = kbeg + kper < p.K ? kbeg + kper : p.K;
+  p.a.K = kend;            // (the loaders read zeros beyond their operand's K)
+  p.b.K = kend;
+  p.K = kend;
+  if (gridDim.z > 1) p.C += (long)blockIdx.z * p.M * p.ldc;
+  tile_load(p.a, m0, kbeg, tid, ra);
+  tile_load(p.b, n0, kbeg, tid, rb);
   const bool atr = p.a.sk != 1, btr = p.b.sk != 1;          // workgroup-uniform
-  for (int k0 = 0; k0 < p.K; k0 += BK) {
+  for (int k0 = kbeg; k0 < p.K; k0 += BK) {
     __syncthreads();            // the previous chunk's fragment reads are done
     tile_store(p.a, ldsA, tid, ra);
     tile_store(p.b, ldsB, tid, rb);
@@ -378,8 +385,39 @@ extern "C" int hpfg_gemm_bf16x3(const float* A, long sam, long sak, const float*
   HPFG_ARG_CHECK(hpfg_gemm_bf16x3_ok(A, sam, sak, B, sbk, sbn, M, N, K), "gemm_bf16x3: operands need a unit stride and 4-element alignment");
   Gemm16Args p{{A, sam, sak, M, K}, {B, sbn, sbk, N, K}, Cm, bias, ldc, M, N, K, relu, accumulate};
   dim3 grid((N + BM - 1) / BM, (M + BM - 1) / BM);
-  hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, (K + BK - 1) / BK * BK);
   return hpfg_launch_status("gemm_bf16x3_kernel");
+}
+
+/* K splits for a product with few 128 x 128 output tiles and a long contraction -- the 1568-token layers of the SegFormer branch (stage 4, and
+ * the keys / values after the spatial reduction: 13 row tiles, K up to 2048): one workgroup per tile walked its 64 chunks alone (121 us for
+ * 13 MB of operands).  1 = do not split. */
+extern "C" int hpfg_gemm_bf16x3_splits(int M, int N, int K) {
+  const long tiles = (long)((M + BM - 1) / BM) * ((N + BM - 1) / BM);
+  if (tiles >= 128 || K < 256) return 1;
+  long s = 256 / tiles;
+  const long by_k = K / 128;                      // at least 4 chunks of K per split
+  if (s > by_k) s = by_k;
+  return (int)(s < 1 ? 1 : (s > 16 ? 16 : s));
+}
+
+/* hpfg_gemm_bf16x3 with the contraction split over workgroups; scratch: hpfg_gemm_bf16x3_splits(M, N, K) * M * N floats (unused when 1 split).
+ * Deterministic: the partial products are added in split order by one finishing launch, which also applies bias / ReLU / accumulate. */
+extern "C" int hpfg_gemm_bf16x3_splitk(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* Cm, long ldc, int M, int N, int K,
+                                       const float* bias, int relu, int accumulate, float* scratch, void* stream) {
+  const int S = hpfg_gemm_bf16x3_splits(M, N, K);
+  if (S <= 1) return hpfg_gemm_bf16x3(A, sam, sak, B, sbk, sbn, Cm, ldc, M, N, K, bias, relu, accumulate, stream);
+  HPFG_ARG_CHECK(A && B && Cm && scratch && M > 0 && N > 0 && K > 0 && ldc >= N, "gemm_bf16x3_splitk: bad args");
+  HPFG_ARG_CHECK(hpfg_gemm_bf16x3_ok(A, sam, sak, B, sbk, sbn, M, N, K), "gemm_bf16x3_splitk: operands need a unit stride and 4-element alignment");
+  int kper = (K + S - 1) / S;
+  kper = (kper + BK - 1) / BK * BK;
+  Gemm16Args p{{A, sam, sak, M, K}, {B, sbn, sbk, N, K}, scratch, nullptr, (long)N, M, N, K, 0, 0};
+  dim3 grid((N + BM - 1) / BM, (M + BM - 1) / BM, (K + kper - 1) / kper);
+  hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, kper);
+  const long total = (long)M * N;
+  hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scratch, (int)grid.z, M, N, (long)N, Cm,
+                     ldc, bias, relu, accumulate);
+  return hpfg_launch_status("gemm_bf16x3_splitk");
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------

@@ -13,7 +13,8 @@ Same module tree, parameter names and constructor order as the reference's ``mod
   - every LayerNorm, depthwise 3x3 + GELU of the Mix-FFN, the head's bilinear resizes and its BatchNorm(train) + ReLU + Dropout2d,
     im2col / col2im of the overlap patch embeddings, residual adds with their drop-path factor (``csrc/tokens.hip``);
 * the head never builds the 4E-channel concat: ``linear_fuse`` (bias-free 1x1 conv) is applied per stage at the stage's resolution and the four
-  E-channel maps are resized and added in one pass (``hpfg_resize_sum_fwd``; reference model/segformer.py:309-315 up to fp32 association);
+  E-channel maps are resized and added in one pass (``hpfg_resize_sum_fwd``; reference model/segformer.py:309-315 up to fp32 association); each
+  stage's ``linear_c`` projection is composed with its slice of the fuse weights first (one C_i -> E GEMM per stage);
 * still plain PyTorch-ROCm ops: the token <-> image reshape copies and the slices of the fuse weight (memory movement only).
 No MIOpen call is left in the module: with MIOpen convolutions / BatchNorm the forward was not bit-reproducible between identical runs
 (logits differing by ~4e-7), and one ReLU gate of the head flipping on such noise moves every gradient upstream by ~1e-3; without it the
@@ -191,11 +192,17 @@ class SegFormerHead(nn.Module):
             # channel, so they commute -- each stage's slice of the fuse weights is applied at the stage's own resolution (1/4 .. 1/64 of the
             # pixels) and only the E-channel results are resized and added.  No [B, H*W, 4E] concat (411 MB at 32 x 56 x 56 tokens) is written,
             # read by the GEMM and by its two backward GEMMs; the same sum in a different association (fp32, |diff| ~ 1e-6 relative).
+            # ... and the stage's projection (linear_c_i: C_i -> E, with bias) composes with its slice of the fuse weights into ONE map C_i -> E:
+            # W_eff = W_f,i W_c,i (E x C_i), b_eff = W_f,i b_c,i -- two E x E x C_i products on the weights instead of an E-wide GEMM over every
+            # token (100 k tokens at stage 1) forward, for dX and for dW; autograd differentiates the composition through the same HIP ops.
             zs = []
             for i, (t, h, w) in enumerate(feats):
                 p = getattr(self, f"linear_c{i + 1}").proj
                 slot = len(feats) - 1 - i
-                zs.append(linear(linear(t, p.weight, p.bias), wf[:, slot * E:(slot + 1) * E]).view(B, h, w, -1))      # NHWC [B, h, w, E]
+                wfi = wf[:, slot * E:(slot + 1) * E]                             # [E, E]
+                w_eff = linear(p.weight.t(), wfi).t()                            # (W_c^T W_f^T)^T = W_f W_c: [E, C_i]
+                b_eff = linear(p.bias[None, :], wfi)[0]                          # W_f b_c: [E]
+                zs.append(linear(t, w_eff, b_eff).view(B, h, w, -1))             # NHWC [B, h, w, E]
             z = resize_sum(zs[0], *zs[1:]).view(B, H * W, -1)                   # one HIP pass: zs[0] + sum of the resized others
         else:
             outs = []

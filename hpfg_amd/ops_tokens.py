@@ -268,7 +268,13 @@ def _gemm(a, sam, sak, b, sbk, sbn, m, n, k, bias=None, math="bf16x3"):
     lib = L.load()
     out = torch.empty(m, n, dtype=torch.float32, device=a.device)
     if math == "bf16x3" and lib.hpfg_gemm_bf16x3_ok(L.ptr(a), sam, sak, L.ptr(b), sbk, sbn, m, n, k):
-        L.check(lib.hpfg_gemm_bf16x3(L.ptr(a), sam, sak, L.ptr(b), sbk, sbn, L.ptr(out), n, m, n, k, L.ptr(bias), 0, 0, _st(a)), "gemm_bf16x3")
+        splits = lib.hpfg_gemm_bf16x3_splits(m, n, k)      # few output tiles + long K (the 1568-token layers): split the contraction
+        if splits > 1:
+            scratch = torch.empty(splits * m * n, dtype=torch.float32, device=a.device)
+            L.check(lib.hpfg_gemm_bf16x3_splitk(L.ptr(a), sam, sak, L.ptr(b), sbk, sbn, L.ptr(out), n, m, n, k, L.ptr(bias), 0, 0, L.ptr(scratch), _st(a)),
+                    "gemm_bf16x3_splitk")
+        else:
+            L.check(lib.hpfg_gemm_bf16x3(L.ptr(a), sam, sak, L.ptr(b), sbk, sbn, L.ptr(out), n, m, n, k, L.ptr(bias), 0, 0, _st(a)), "gemm_bf16x3")
     else:
         L.check(lib.hpfg_gemm_f32(L.ptr(a), sam, sak, L.ptr(b), sbk, sbn, L.ptr(out), n, m, n, k, L.ptr(bias), 0, 0, _st(a)), "gemm_f32")
     return out

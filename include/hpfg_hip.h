@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 125
+#define HPFG_VERSION 126
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -388,6 +388,11 @@ int hpfg_gemm_f32_splits(int M, int N, int K);
  * hpfg_gemm_bf16x3_ok() tells; callers fall back to hpfg_gemm_f32 otherwise. */
 int hpfg_gemm_bf16x3(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N, int K,
                      const float* bias, int relu, int accumulate, void* stream);
+/* The same product with the contraction split over workgroups where the output has few 128 x 128 tiles and K is long (hpfg_gemm_bf16x3_splits > 1:
+ * the 1568-token layers, K up to 2048); scratch: splits * M * N floats; partial products are added in split order (deterministic) */
+int hpfg_gemm_bf16x3_splits(int M, int N, int K);
+int hpfg_gemm_bf16x3_splitk(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* Cm, long ldc, int M, int N, int K,
+                            const float* bias, int relu, int accumulate, float* scratch, void* stream);
 int hpfg_gemm_bf16x3_ok(const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M, int N, int K);
 /* weight gradient dW[N][K] = dY^T X over R tokens (dY [R][N], X [R][K] contiguous) in split-bf16 arithmetic: operands staged as they lie in
  * memory, fragments through the transposing LDS read, rows split over workgroups, partials summed in a fixed order.

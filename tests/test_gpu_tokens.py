@@ -184,11 +184,12 @@ def test_residual_scale():
         assert maxerr(xd.grad.cpu(), xr.grad) < 1e-6 and maxerr(yd.grad.cpu(), yr.grad) < 1e-6
 
 
-@pytest.mark.parametrize("R,N,K", [(1568, 256, 1024), (6272, 640, 160), (25088, 128, 64), (392, 160, 640), (100, 4, 256), (3136, 32, 49), (130, 36, 20)])
+@pytest.mark.parametrize("R,N,K", [(1568, 32, 2048), (1568, 256, 1024), (6272, 640, 160), (25088, 128, 64), (392, 160, 640), (100, 4, 256), (3136, 32, 49), (130, 36, 20)])
 @pytest.mark.parametrize("math", ["bf16x3", "f32"])
 def test_linear_on_the_hip_gemms(R, N, K, math):
     """nn.Linear / 1x1 conv of the SegFormer branch on hpfg_gemm_bf16x3 (split-bf16 MFMA; all three products: X W^T + b, dY W, dY^T X)
-    and, where an operand is not 4-aligned (the 7x7x1 patch embedding: K = 49) or HPFG_MATH=f32, on the exact-fp32 MFMA GEMM."""
+    and, where an operand is not 4-aligned (the 7x7x1 patch embedding: K = 49) or HPFG_MATH=f32, on the exact-fp32 MFMA GEMM.  The 1568-token
+    shapes have few output tiles and a long contraction: they run K-split (hpfg_gemm_bf16x3_splitk, 16 / 8 / 2 splits)."""
     from hpfg_amd import ops_tokens
     g = torch.Generator().manual_seed(R + N)
     x, w, b = torch.randn(R, K, generator=g), torch.randn(N, K, generator=g) * 0.2, torch.randn(N, generator=g)
