@@ -436,20 +436,33 @@ __global__ __launch_bounds__(256) void dwgelu_bwd_du_kernel(const float* __restr
     f32x4 acc[10];
 #pragma unroll
     for (int t = 0; t < 10; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (pl < PL && qb + ql < Q)
+    if (pl < PL && qb + ql < Q) {
+      // the thread's channel quad is fixed: its 9 tap weights and bias stay in registers, and the 9 input taps of a pixel are loaded ONCE
+      // for both the recomputed pre-activation and the weight-gradient sums (29 -> 10 loads per pixel)
+      f32x4 wr[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wr[t] = *reinterpret_cast<const f32x4*>(w9 + t * C + c);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + c);
       for (long p = p0 + pl; p < p1; p += PL) {
         const int xx = (int)(p % W), yy = (int)((p / W) % H), b = (int)(p / ((long)W * H));
-        const f32x4 u = dw_at(x, w9, bias, b, yy, xx, c, H, W, C);
+        f32x4 xs[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
+          xs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) xs[t] = *reinterpret_cast<const f32x4*>(x + (((long)b * H + y2) * W + x2) * C + c);
+        }
         const f32x4 d = *reinterpret_cast<const f32x4*>(dy + p * C + c);
+        f32x4 u = b4;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) u += xs[t] * wr[t];
         const f32x4 g = f32x4{d[0] * gelu_grad(u[0]), d[1] * gelu_grad(u[1]), d[2] * gelu_grad(u[2]), d[3] * gelu_grad(u[3])};
         *reinterpret_cast<f32x4*>(du + p * C + c) = g;
         acc[9] += g;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
-          if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) acc[t] += g * *reinterpret_cast<const f32x4*>(x + (((long)b * H + y2) * W + x2) * C + c);
-        }
+        for (int t = 0; t < 9; ++t) acc[t] += g * xs[t];
       }
+    }
     // all ten sums of every channel quad in one LDS round: red[thread][t][j]
     __syncthreads();
 #pragma unroll
