@@ -568,18 +568,22 @@ __global__ __launch_bounds__(256) void resize_sum_fwd_kernel(const float* __rest
 }
 
 // backward as a gather (no atomics: reproducible): a source pixel sums, over the outputs whose two taps per axis include it, the
-// matching weights.  Candidates per axis: outputs [ (i - 1) * out/in , (i + 2) * out/in ).
+// matching weights.
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int h, int w, int H, int W, int C,
                                                          float sy, float sx) {
   const int Q = C / 4;
   const long total = (long)B * h * w * Q;
-  const int ry = (H + h - 1) / h, rx = (W + w - 1) / w;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % Q) * 4;
     const long p = i / Q;
     const int xi = (int)(p % w), yi = (int)((p / w) % h), b = (int)(p / ((long)w * h));
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int Y0 = max(0, (yi - 1) * ry), Y1 = min(H, (yi + 2) * ry), X0 = max(0, (xi - 1) * rx), X1 = min(W, (xi + 2) * rx);
+    // outputs whose lower tap is i have source coordinate in [i, i + 1), those whose upper tap is i in [i - 1, i): together the outputs
+    // [(i - 0.5) / s - 0.5, (i + 1.5) / s - 0.5) -- 2 * out/in candidates per axis (one more on either side for rounding; the tests below
+    // decide), not the 3 * out/in of the whole-pixel bounds
+    const float qy = 1.f / sy, qx = 1.f / sx;
+    const int Y0 = max(0, (int)floorf((yi - 0.5f) * qy - 0.5f) - 1), Y1 = min(H, (int)ceilf((yi + 1.5f) * qy - 0.5f) + 1);
+    const int X0 = max(0, (int)floorf((xi - 0.5f) * qx - 0.5f) - 1), X1 = min(W, (int)ceilf((xi + 1.5f) * qx - 0.5f) + 1);
     for (int Y = Y0; Y < Y1; ++Y) {
       int y0, y1;
       float wy;
