@@ -109,33 +109,34 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstPair pp, int N, in
   }
 }
 
-// ---- the 1-channel first layer on the matrix cores -------------------------------------------------------------------------------------
-// K = 9 taps is three k-steps of v_mfma_f32_16x16x4_f32 (exact fp32, an fmaf chain in tap order -- the arithmetic of the loop above): the
+// ---- the 1- / 3-channel first layer on the matrix cores -------------------------------------------------------------------------------------
+// K = 9 taps (x 3 channels: 27) is three (seven) k-steps of v_mfma_f32_16x16x4_f32 (exact fp32, an fmaf chain in tap order -- the arithmetic of the loop above): the
 // 9 x 16 weights are the A operand (M = output channel; three VGPRs per lane for the whole launch), the B operand is gathered from the 18 x 18
 // input tile in LDS (N = 16 pixels of one tile row, k = tap: one ds_read_b32 per k-step), and a lane ends up with 4 consecutive output
 // channels of one pixel -- a 16-byte store.  The VALU form reads its weights as 36 broadcast ds_read_b128 per pixel and spends half of its
 // cycles in the LDS pipe; this one issues 3 four-byte gathers per 16 pixels.  The next tile's input is in flight (registers) while a tile
 // multiplies.  Same partial-sum rows (one per workgroup) and the same output as conv_first_kernel.
-template <bool PAIR>
+template <int CIN, bool PAIR>
 __global__ __launch_bounds__(256) void conv_first_mfma_kernel(FirstPair pp, int N, int H, int W, int tiles_x, int tiles_y) {
-  constexpr int T = 16, TP = T + 2, CO = 16, NPIX = TP * TP;
+  constexpr int T = 16, TP = T + 2, CO = 16, NPIX = TP * TP, KT = 9 * CIN, KS = (KT + 3) / 4, NLD = (CIN * NPIX + 255) / 256;
   const HpfgFirstConvArgs& q = pp.g[PAIR ? blockIdx.y : 0];
   const HpfgAct& x = q.x;
   const float* __restrict__ w = q.w_oihw;
   float* __restrict__ out = q.out;
   float* __restrict__ stat = q.stat_partials;
-  __shared__ float tin[NPIX];
+  __shared__ float tin[CIN * NPIX];
   __shared__ float red[2][4][CO];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = tiles_x * tiles_y, nwork = ntiles * N;
   const int co_a = lane & 15, kq = lane >> 4;                 // A: row = output channel, k-local = lane >> 4; B: column = pixel, k-local = lane >> 4
-  float wa[3];
-  int boff[3];
+  // k = ci * 9 + tap, ascending: the order of the VALU loop (for ci: for tap), so the fmaf chain of the MFMA reproduces its sums
+  float wa[KS];
+  int boff[KS];
 #pragma unroll
-  for (int s_ = 0; s_ < 3; ++s_) {
-    const int tap = 4 * s_ + kq;
-    wa[s_] = tap < 9 ? w[co_a * 9 + tap] : 0.f;              // W[co][0][tap]
-    boff[s_] = tap < 9 ? (tap / 3) * TP + (lane & 15) + tap % 3 : 0;         // (taps 9..11 of the third k-step are padding: their B value is forced to 0)
+  for (int s_ = 0; s_ < KS; ++s_) {
+    const int k = 4 * s_ + kq, ci = k / 9, tap = k - 9 * ci;
+    wa[s_] = k < KT ? w[co_a * KT + k] : 0.f;                // W[co][ci][tap]
+    boff[s_] = k < KT ? ci * NPIX + (tap / 3) * TP + (lane & 15) + tap % 3 : 0;      // (k >= KT in the last k-step is padding: its B value is forced to 0)
   }
   const f32x4 b4 = *reinterpret_cast<const f32x4*>(q.bias + 4 * kq);          // D rows 4 * (lane >> 4) + j
   // BatchNorm partial sums in the VALU form's association, so that both forms hand the finalize bit-identical rows: there a thread owns the
@@ -148,8 +149,14 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(FirstPair pp, int 
   }
   // tile coordinates are derived once per tile (two run-time divisions), for the tile whose input is being fetched; the multiply phase of the
   // next iteration inherits them
-  const int p0 = tid, p1 = tid + 256;
-  const int py0 = p0 / TP - 1, px0 = p0 % TP - 1, py1 = p1 / TP - 1, px1 = p1 % TP - 1;
+  int pci[NLD], ppy[NLD], ppx[NLD];          // staging piece i of this thread: element tid + 256 i of the [CIN][18][18] tile
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = tid + 256 * i, pix = e % NPIX;
+    pci[i] = e / NPIX;
+    ppy[i] = pix / TP - 1;
+    ppx[i] = pix % TP - 1;
+  }
   int n = 0, ty0 = 0, tx0 = 0;
   auto coords = [&](int wk) {
     n = wk / ntiles;
@@ -157,13 +164,15 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(FirstPair pp, int 
     ty0 = tyi * T;
     tx0 = (tile - tyi * tiles_x) * T;
   };
-  auto fetch = [&](float (&v)[2]) {
+  auto fetch = [&](float (&v)[NLD]) {
     const float* xb = x.z + (long)n * x.sn;
-    const int gy0 = ty0 + py0, gx0 = tx0 + px0, gy1 = ty0 + py1, gx1 = tx0 + px1;
-    v[0] = (gy0 >= 0 && gy0 < H && gx0 >= 0 && gx0 < W) ? xb[(long)gy0 * x.sy + (long)gx0 * x.sx] : 0.f;
-    v[1] = (p1 < NPIX && gy1 >= 0 && gy1 < H && gx1 >= 0 && gx1 < W) ? xb[(long)gy1 * x.sy + (long)gx1 * x.sx] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int gy = ty0 + ppy[i], gx = tx0 + ppx[i];
+      v[i] = (tid + 256 * i < CIN * NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[(long)pci[i] * x.sc + (long)gy * x.sy + (long)gx * x.sx] : 0.f;
+    }
   };
-  float v[2];
+  float v[NLD];
   int wk = blockIdx.x;
   if (wk < nwork) {
     coords(wk);
@@ -173,8 +182,9 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(FirstPair pp, int 
   for (; wk < nwork; wk += gridDim.x) {
     const int cn = n, cy0 = ty0, cx0 = tx0;          // this tile
     __syncthreads();          // the previous tile's gathers are done
-    tin[tid] = v[0];
-    if (p1 < NPIX) tin[p1] = v[1];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if (tid + 256 * i < CIN * NPIX) tin[tid + 256 * i] = v[i];
     __syncthreads();
     if (wk + (int)gridDim.x < nwork) {
       coords(wk + gridDim.x);
@@ -187,9 +197,9 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(FirstPair pp, int 
       const int ly = 4 * wave + r;
       f32x4 acc = b4;
 #pragma unroll
-      for (int s_ = 0; s_ < 3; ++s_) {
+      for (int s_ = 0; s_ < KS; ++s_) {
         float bv = tin[ly * TP + boff[s_]];
-        if (s_ == 2 && kq != 0) bv = 0.f;          // 0 * (whatever the tile holds there) must not be NaN
+        if (s_ == KS - 1 && 4 * s_ + kq >= KT) bv = 0.f;          // 0 * (whatever the tile holds there) must not be NaN
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s_], bv, acc, 0, 0, 0);
       }
       if (cy0 + ly < H && gx < W) *reinterpret_cast<f32x4*>(orow + (long)r * W * CO) = acc;
@@ -332,9 +342,12 @@ static int conv_first_impl(const HpfgFirstConvArgs* a, const HpfgFirstConvArgs* 
   pp.g[0] = *a;
   pp.g[1] = b ? *b : *a;
   const char* fe = getenv("HPFG_FIRST_MFMA");      // 0: the VALU form for the 1-channel layer too (A/B runs)
-  if (Cin == 1 && !(fe && atoi(fe) == 0)) {
-    if (b) hipLaunchKernelGGL(conv_first_mfma_kernel<true>, dim3(conv_first_grid(N, H, W), 2), dim3(256), 0, (hipStream_t)stream, pp, N, H, W, tx, ty);
-    else hipLaunchKernelGGL(conv_first_mfma_kernel<false>, dim3(conv_first_grid(N, H, W)), dim3(256), 0, (hipStream_t)stream, pp, N, H, W, tx, ty);
+  if ((Cin == 1 || Cin == 3) && !(fe && atoi(fe) == 0)) {      // grey-scale (ACDC / LIDC) and RGB (CPS config) inputs
+    const dim3 g1(conv_first_grid(N, H, W)), g2(conv_first_grid(N, H, W), 2);
+    if (Cin == 1 && b) hipLaunchKernelGGL((conv_first_mfma_kernel<1, true>), g2, dim3(256), 0, (hipStream_t)stream, pp, N, H, W, tx, ty);
+    else if (Cin == 1) hipLaunchKernelGGL((conv_first_mfma_kernel<1, false>), g1, dim3(256), 0, (hipStream_t)stream, pp, N, H, W, tx, ty);
+    else if (b) hipLaunchKernelGGL((conv_first_mfma_kernel<3, true>), g2, dim3(256), 0, (hipStream_t)stream, pp, N, H, W, tx, ty);
+    else hipLaunchKernelGGL((conv_first_mfma_kernel<3, false>), g1, dim3(256), 0, (hipStream_t)stream, pp, N, H, W, tx, ty);
     return hpfg_launch_status("conv_first_mfma_kernel");
   }
   if (b) hipLaunchKernelGGL(conv_first_kernel<true>, dim3(conv_first_grid(N, H, W), 2), dim3(256), 0, (hipStream_t)stream, pp, N, H, W, Cin, tx, ty);

@@ -392,19 +392,20 @@ def test_forward_advances_bn_counters_and_seed_word_inside_the_pack_launch():
     assert all(int(b) == 5 for n, b in m.named_buffers() if n.endswith("num_batches_tracked"))      # eval forwards do not count
 
 
-@pytest.mark.parametrize("N,H,W", [(2, 32, 32), (3, 224, 224), (1, 16, 48), (2, 40, 24)])
-def test_first_conv_mfma_form_equals_the_valu_form(N, H, W, monkeypatch):
-    """The 1-channel first layer on v_mfma_f32_16x16x4_f32 (three k-steps of 4 taps: an fmaf chain in tap order) gives the output and the
+@pytest.mark.parametrize("cin", [1, 3])
+@pytest.mark.parametrize("N,H,W", [(2, 32, 32), (3, 224, 224), (1, 16, 48), (2, 40, 24), (4, 96, 96)])
+def test_first_conv_mfma_form_equals_the_valu_form(N, H, W, cin, monkeypatch):
+    """The 1- / 3-channel first layer on v_mfma_f32_16x16x4_f32 (three / seven k-steps of 4 taps: an fmaf chain in (channel, tap) order) gives the output and the
     BatchNorm partial sums of the VALU loop it replaces, bit for bit (the fixture traces of tests/test_gpu_steps.py are chaotic enough on their
     4-image batches that a last-bit change of the first layer's statistics moves the logits by 1e-3 after three steps); also on sizes that are
     not multiples of 16 (no statistics there)."""
     lib = L.load()
     g = torch.Generator().manual_seed(H + W)
-    x = torch.randn(N, 1, H, W, generator=g).to(DEV)
-    w = (torch.randn(16, 1, 3, 3, generator=g) * 0.3).to(DEV)
+    x = torch.randn(N, cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(16, cin, 3, 3, generator=g) * 0.3).to(DEV)
     b = torch.randn(16, generator=g).to(DEV)
     a = L.Act()
-    a.z, a.mode, a.C, a.Hs, a.Ws = L.ptr(x), L.ACT_STRIDED, 1, H, W
+    a.z, a.mode, a.C, a.Hs, a.Ws = L.ptr(x), L.ACT_STRIDED, cin, H, W
     a.sn, a.sc, a.sy, a.sx = x.stride()
     nblk = lib.hpfg_conv_first_rows(N, H, W)
     with_stats = H % 16 == 0 and W % 16 == 0
@@ -413,7 +414,7 @@ def test_first_conv_mfma_form_equals_the_valu_form(N, H, W, monkeypatch):
         monkeypatch.setenv("HPFG_FIRST_MFMA", form)
         out = torch.full((N, H, W, 16), float("nan"), device=DEV)
         part = torch.full((nblk * 2 * 16,), float("nan"), device=DEV)
-        L.check(lib.hpfg_conv3x3_first_fwd(C.byref(a), L.ptr(w), L.ptr(b), L.ptr(out), L.ptr(part) if with_stats else None, N, H, W, 1, 16, stream(DEV)), "first")
+        L.check(lib.hpfg_conv3x3_first_fwd(C.byref(a), L.ptr(w), L.ptr(b), L.ptr(out), L.ptr(part) if with_stats else None, N, H, W, cin, 16, stream(DEV)), "first")
         torch.cuda.synchronize()
         res.append((out, part.clone()))
     assert torch.equal(res[0][0], res[1][0])
