@@ -300,15 +300,16 @@ def dominant_kernel_roofline(model, step, inputs, it, dev, eager_ok=True):
     if eager_ok:
         engines = [e for m in (model, step.ema_model) for pool in m._engines.values() for e in pool]
         for e in engines:
-            e.probe = (name, [])
+            e.probe = (name, [], [])
         for k in range(6):
             step.step(*inputs, it + 1 + k)
         torch.cuda.synchronize(dev)
         ts = [e0.elapsed_time(e1) * 1e3 for e in engines for (e0, e1) in e.probe[1][len(e.probe[1]) // 3:]]     # first third = warm-up
+        tb = [e0.elapsed_time(e1) * 1e3 for e in engines for (e0, e1) in e.probe[2][len(e.probe[2]) // 3:]]     # the event bracket around nothing
         for e in engines:
             e.probe = None
         if ts:
-            in_step_us = sum(ts) / len(ts)
+            in_step_us = sum(ts) / len(ts) - (sum(tb) / len(tb) if tb else 0.0)
     a0, a1 = eng.input_acts(name)
     ca = L.ConvArgs()
     ca.a0, ca.a1 = a0, a1
@@ -346,7 +347,8 @@ def dominant_kernel_roofline(model, step, inputs, it, dev, eager_ok=True):
     return {"kernel": kname + "<16x16 tile, 16 output channels, 3x3, CAT loader> @ decoder.up4.conv.conv_conv.0 (32->16ch, 224x224, skip concat + "
                       "bilinear upsample + BN + LeakyReLU fused on load, BN partial sums in the epilogue)",
             "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
-            "avg_launch_us": round(us, 2), "timing": "in-step (events around the launch inside eager steps)" if in_step_us is not None else "solo",
+            "avg_launch_us": round(us, 2),
+            "timing": "in-step (HIP events around the launch inside eager steps, net of the same event bracket around nothing)" if in_step_us is not None else "solo",
             "solo_launch_us": round(solo_us, 2), "frac_solo": round(bytes_alg / (solo_us * 1e-6) / 8e12, 4),
             "algorithmic_bytes_per_launch": bytes_alg, "flops_per_launch": flops, "achieved_TFLOPs": round(flops / (us * 1e-6) / 1e12, 2),
             "note": "no single kernel dominates the step (largest template instance ~7 % of kernel time): step_roofline is the figure that matters"}

@@ -343,6 +343,11 @@ class UNetEngine:
             ca = self._conv_args(s, out, want_stats)
             probe = self.probe is not None and self.probe[0] == s.name
             if probe:
+                if len(self.probe) > 2:          # calibration: the same event bracket around nothing (see _fused_bwd)
+                    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    b0.record(torch.cuda.current_stream(self.dev))
+                    b1.record(torch.cuda.current_stream(self.dev))
+                    self.probe[2].append((b0, b1))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(torch.cuda.current_stream(self.dev))
             L.check(self.lib.hpfg_conv_fwd(C.byref(ca), st), f"conv_fwd[{s.name}]")
