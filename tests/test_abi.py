@@ -55,3 +55,17 @@ def test_argument_errors_are_reported_not_crashed():
     assert lib.hpfg_conv_stat_blocks(2, 32, 32) == 2 * 4 and lib.hpfg_conv_stat_blocks(1, 24, 24) == 12
     assert lib.hpfg_wgrad_splits(16, 224, 224, 16, 16, 9) >= 1
     assert ctypes.sizeof(L.Act) % 8 == 0
+
+
+def test_host_side_size_queries():
+    """Size / split queries are plain host arithmetic (no GPU call): the values the Python side sizes its workspaces with."""
+    lib = L.load()
+    # K-split of the split-bf16 GEMM: only products with few 128 x 128 output tiles and a long contraction (the 1568-token SegFormer layers)
+    assert lib.hpfg_gemm_bf16x3_splits(1568, 32, 2048) == 16          # 13 tiles, K = 2048: capped at 16 splits of >= 128
+    assert lib.hpfg_gemm_bf16x3_splits(1568, 256, 1024) == 8          # 26 tiles -> 256 / 26 = 9, K / 128 = 8
+    assert lib.hpfg_gemm_bf16x3_splits(1568, 256, 256) == 2
+    assert lib.hpfg_gemm_bf16x3_splits(100352, 256, 256) == 1         # 1568 tiles: enough workgroups
+    assert lib.hpfg_gemm_bf16x3_splits(1568, 256, 64) == 1            # nothing to split
+    # one BatchNorm partial-sum row per workgroup of the first layer, at most 1024
+    assert lib.hpfg_conv_first_rows(16, 224, 224) == 1024 and lib.hpfg_conv_first_rows(2, 32, 32) == 8
+    assert lib.hpfg_upsample2x_bwd_blocks(16, 112, 112, 16) % 8 == 0   # (the XCD-aware ranges need a multiple of 8 workgroups)
