@@ -19,6 +19,10 @@ import subprocess
 import sys
 import time
 
+import faulthandler
+
+faulthandler.enable()      # a fault inside the HIP runtime still leaves the Python stack on stderr
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 
 # enums from include/hpfg_hip.h
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
-ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ, ACT_PLANES = range(8)
+ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ = range(7)
 LOSS_NSUM = 32
 VERSION = 126
 MATH_F32, MATH_BF16X3 = 0, 1
@@ -42,15 +42,6 @@ class WgradArgs(C.Structure):
     _fields_ = [("a0", Act), ("a1", Act), ("g", Act), ("slab", C.c_void_p), ("dw_oihw", C.c_void_p), ("Cin", C.c_int32),
                 ("CinPad", C.c_int32), ("Cout", C.c_int32), ("CoutPad", C.c_int32), ("N", C.c_int32), ("H", C.c_int32),
                 ("W", C.c_int32), ("taps", C.c_int32), ("S", C.c_int32), ("math", C.c_int32), ("defer_reduce", C.c_int32)]
-
-
-class FirstConvArgs(C.Structure):
-    _fields_ = [("x", Act), ("w_oihw", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("stat_partials", C.c_void_p)]
-
-
-class BnFinalizeArgs(C.Structure):
-    _fields_ = [("partials", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
-                ("bn", C.c_void_p)]
 
 
 class FusedBwdArgs(C.Structure):
@@ -104,7 +95,6 @@ PROTOTYPES = {
     "hpfg_pack_weights": (_i, [_p, C.POINTER(PackDesc), _i, _p]),
     "hpfg_pack_weights_bump": (_i, [_p, C.POINTER(PackDesc), _i, _p, _i, _p, _i, _p]),
     "hpfg_act_materialize": (_i, [C.POINTER(Act), C.POINTER(Act), _i, _i, _i, _p, _p]),
-    "hpfg_act_to_planes": (_i, [C.POINTER(Act), C.POINTER(Act), _i, _i, _i, _p, _p]),
     "hpfg_dropout_mask": (_i, [_p, _l, _f, _u32, _p, _p]),
     "hpfg_bn_eval_table": (_i, [_p, _p, _p, _p, _f, _p, _i, _p]),
     "hpfg_bn_bwd_reduce": (_i, [C.POINTER(Act), _i, _i, _i, _p, _p]),
@@ -114,9 +104,6 @@ PROTOTYPES = {
     "hpfg_bn_bwd_finalize": (_i, [_p, _i, _p, _d, _p, _p, _p, _p, _i, _f, _p]),
     "hpfg_wgrad": (_i, [C.POINTER(WgradArgs), _p]),
     "hpfg_fused_bwd": (_i, [C.POINTER(FusedBwdArgs), _p]),
-    "hpfg_conv_fwd_pair": (_i, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), _p]),
-    "hpfg_conv3x3_first_fwd_pair": (_i, [C.POINTER(FirstConvArgs), C.POINTER(FirstConvArgs), _i, _i, _i, _i, _i, _p]),
-    "hpfg_bn_fwd_finalize_pair": (_i, [C.POINTER(BnFinalizeArgs), C.POINTER(BnFinalizeArgs), _i, C.c_double, C.c_float, C.c_float, _i, _p]),
     "hpfg_fused_bwd_grid": (_i, [C.POINTER(FusedBwdArgs)]),
     "hpfg_slab_reduce_multi": (_i, [_p, C.POINTER(SlabDesc), _i, _p]),
     "hpfg_wgrad_splits": (_i, [_i, _i, _i, _i, _i, _i]),

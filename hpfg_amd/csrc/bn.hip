@@ -69,14 +69,17 @@ __device__ inline void sum_partials(const float* __restrict__ partials, int nblk
 }
 
 // grid = C blocks; partials [nblk][2][C]
-struct FinalizePair {
-  HpfgBnFinalizeArgs g[2];
+struct HpfgBnFinalizeArgs {
+  const float* partials;
+  const float* gamma;
+  const float* beta;
+  float* running_mean;  // or NULL: statistics not tracked
+  float* running_var;
+  float* bn;
 };
-template <bool PAIR>
-__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(FinalizePair pp, int nblk, const double* __restrict__ sums, double count, float momentum,
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(HpfgBnFinalizeArgs q, int nblk, const double* __restrict__ sums, double count, float momentum,
                                                               float eps, int C) {
   __shared__ double sh[8];
-  const HpfgBnFinalizeArgs& q = pp.g[PAIR ? blockIdx.y : 0];      // blockIdx.y: which of the two layers sharing the launch
   const float* __restrict__ partials = q.partials;
   const float* __restrict__ gamma = q.gamma;
   const float* __restrict__ beta = q.beta;
@@ -297,21 +300,8 @@ extern "C" int hpfg_bn_fwd_finalize(const float* partials, int nblk, const doubl
                                     float* running_mean, float* running_var, float momentum, float eps, float* bn, int C, void* stream) {
   HPFG_ARG_CHECK((partials && nblk > 0) || sums, "bn_fwd_finalize: need partials or sums");
   HPFG_ARG_CHECK(gamma && beta && bn && C > 0 && count > 0, "bn_fwd_finalize: bad args");
-  FinalizePair pp;
-  pp.g[0] = HpfgBnFinalizeArgs{partials, gamma, beta, running_mean, running_var, bn};
-  pp.g[1] = pp.g[0];
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel<false>, dim3(C), dim3(256), 0, (hipStream_t)stream, pp, nblk, sums, count, momentum, eps, C);
-  return hpfg_launch_status("bn_fwd_finalize_kernel");
-}
-
-extern "C" int hpfg_bn_fwd_finalize_pair(const HpfgBnFinalizeArgs* a, const HpfgBnFinalizeArgs* b, int nblk, double count, float momentum, float eps,
-                                         int C, void* stream) {
-  HPFG_ARG_CHECK(a && b && a->partials && b->partials && nblk > 0, "bn_fwd_finalize_pair: need the partial sums of both layers");
-  HPFG_ARG_CHECK(a->gamma && a->beta && a->bn && b->gamma && b->beta && b->bn && a->bn != b->bn && C > 0 && count > 0, "bn_fwd_finalize_pair: bad args");
-  FinalizePair pp;
-  pp.g[0] = *a;
-  pp.g[1] = *b;
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel<true>, dim3(C, 2), dim3(256), 0, (hipStream_t)stream, pp, nblk, nullptr, count, momentum, eps, C);
+  const HpfgBnFinalizeArgs q{partials, gamma, beta, running_mean, running_var, bn};
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, q, nblk, sums, count, momentum, eps, C);
   return hpfg_launch_status("bn_fwd_finalize_kernel");
 }
 

@@ -215,13 +215,7 @@ __device__ static inline f32x4 cat_load4(const HpfgAct& a0, const ActCtx& c0, co
 
 
 // ---- single-mode loaders (compile-time mode): keep the conv kernels' staging code small and register-light -------------
-// Kernel argument of the bf16x3 conv kernels: up to two independent layers of identical geometry (the same conv of the student and the
-// teacher network, hpfg_conv_fwd_pair) share one launch; blockIdx.z (3x3) / blockIdx.y / N (1x1) selects the set.
-struct HpfgConvPair {
-  HpfgConvArgs g[2];
-};
-
-enum { HPFG_KIND_PLAIN = 0, HPFG_KIND_BNACT = 1, HPFG_KIND_POOL = 2, HPFG_KIND_CAT = 3, HPFG_KIND_DZ = 4, HPFG_KIND_PLANES = 5 };
+enum { HPFG_KIND_PLAIN = 0, HPFG_KIND_BNACT = 1, HPFG_KIND_POOL = 2, HPFG_KIND_CAT = 3, HPFG_KIND_DZ = 4 };
 
 template <int MODE>
 __device__ static inline f32x4 act_load4_mode(const HpfgAct& s, const ActCtx& cx, int n, int y, int x, int c) {
@@ -252,7 +246,6 @@ static inline int hpfg_kind_of(const HpfgAct& a0, const HpfgAct& a1) {
     case HPFG_ACT_BNACT: return HPFG_KIND_BNACT;
     case HPFG_ACT_BNACT_POOL: return HPFG_KIND_POOL;
     case HPFG_ACT_DZ: return HPFG_KIND_DZ;
-    case HPFG_ACT_PLANES: return HPFG_KIND_PLANES;
     default: return -1;
   }
 }

@@ -17,19 +17,22 @@
 
 namespace {
 
+struct HpfgFirstConvArgs {   // kernel argument of the first-layer kernels
+  HpfgAct x;            // STRIDED source: the network input
+  const float* w_oihw;
+  const float* bias;
+  float* out;
+  float* stat_partials; // or NULL
+};
+
 inline bool tile_is_big(int H, int W) { return (H % 16 == 0) && (W % 16 == 0); }
 
 // ---- first layer: Cin <= 4, direct fp32 FMA (K = 9*Cin is too small for the matrix cores) --------------------------
 // Persistent: a workgroup walks tiles w = blockIdx.x, + gridDim.x, ...; the BatchNorm partial sums stay in registers across its
 // tiles and are reduced once (the per-tile wave butterfly of 32 values used to cost more than the 144 FMAs of the convolution),
 // so the layer also hands only gridDim.x rows to the finalize instead of one per tile.
-struct FirstPair {
-  HpfgFirstConvArgs g[2];
-};
-template <bool PAIR>
-__global__ __launch_bounds__(256) void conv_first_kernel(FirstPair pp, int N, int H, int W, int Cin, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) void conv_first_kernel(HpfgFirstConvArgs q, int N, int H, int W, int Cin, int tiles_x, int tiles_y) {
   constexpr int T = 16, TP = T + 2, CO = 16;
-  const HpfgFirstConvArgs& q = pp.g[PAIR ? blockIdx.y : 0];      // blockIdx.y: which of the two networks sharing the launch
   const HpfgAct& x = q.x;
   const float* __restrict__ w = q.w_oihw;
   const float* __restrict__ bias = q.bias;
@@ -116,10 +119,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstPair pp, int N, in
 // channels of one pixel -- a 16-byte store.  The VALU form reads its weights as 36 broadcast ds_read_b128 per pixel and spends half of its
 // cycles in the LDS pipe; this one issues 3 four-byte gathers per 16 pixels.  The next tile's input is in flight (registers) while a tile
 // multiplies.  Same partial-sum rows (one per workgroup) and the same output as conv_first_kernel.
-template <int CIN, bool PAIR>
-__global__ __launch_bounds__(256) void conv_first_mfma_kernel(FirstPair pp, int N, int H, int W, int tiles_x, int tiles_y) {
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_first_mfma_kernel(HpfgFirstConvArgs q, int N, int H, int W, int tiles_x, int tiles_y) {
   constexpr int T = 16, TP = T + 2, CO = 16, NPIX = TP * TP, KT = 9 * CIN, KS = (KT + 3) / 4, NLD = (CIN * NPIX + 255) / 256;
-  const HpfgFirstConvArgs& q = pp.g[PAIR ? blockIdx.y : 0];
   const HpfgAct& x = q.x;
   const float* __restrict__ w = q.w_oihw;
   float* __restrict__ out = q.out;
@@ -245,24 +247,9 @@ extern "C" int hpfg_conv_stat_blocks(int N, int H, int W) {
 
 extern "C" int hpfg_conv_first_rows(int N, int H, int W) { return conv_first_grid(N, H, W); }
 
-static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only, const HpfgConvArgs* b = nullptr);
+static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only);
 
 extern "C" int hpfg_conv_fwd(const HpfgConvArgs* a, void* stream) { return conv_fwd_impl(a, stream, nullptr); }
-
-// Two layers of identical geometry (the same conv of two networks) in one launch: b goes through a's checks, then the geometry is compared.
-extern "C" int hpfg_conv_fwd_pair(const HpfgConvArgs* a, const HpfgConvArgs* b, void* stream) {
-  HPFG_ARG_CHECK(a && b, "conv_fwd_pair: null pointer");
-  HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && b->math == a->math, "conv_fwd_pair: split-bf16 math mode only, the same for both");
-  HPFG_ARG_CHECK(!a->bwd_stats && !b->bwd_stats && !a->out_split && !b->out_split, "conv_fwd_pair: forward convolutions only");
-  HPFG_ARG_CHECK(a->taps == b->taps && a->N == b->N && a->H == b->H && a->W == b->W && a->Cout == b->Cout && a->CoutPad == b->CoutPad &&
-                     a->a0.C == b->a0.C && a->a1.C == b->a1.C && hpfg_kind_of(a->a0, a->a1) == hpfg_kind_of(b->a0, b->a1) &&
-                     a->a0.mode == b->a0.mode && (a->stat_partials != nullptr) == (b->stat_partials != nullptr) && (a->bias != nullptr) == (b->bias != nullptr),
-                 "conv_fwd_pair: the two layers must have the same geometry, source kinds and outputs");
-  HPFG_ARG_CHECK(a->out != b->out && (!a->stat_partials || a->stat_partials != b->stat_partials), "conv_fwd_pair: the two layers must write different buffers");
-  int rows = 0;
-  if (conv_fwd_impl(b, nullptr, &rows)) return -1;      // b's own argument checks
-  return conv_fwd_impl(a, stream, nullptr, b);
-}
 
 // rows of stat_partials ([rows][2][CoutPad]) that hpfg_conv_fwd(args) fills; <0 on argument errors
 extern "C" int hpfg_conv_stat_rows(const HpfgConvArgs* a) {
@@ -271,7 +258,7 @@ extern "C" int hpfg_conv_stat_rows(const HpfgConvArgs* a) {
   return rc ? -1 : rows;
 }
 
-static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only, const HpfgConvArgs* b) {
+static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
   HPFG_ARG_CHECK(a && a->wpk && a->out, "conv_fwd: null pointer");
   HPFG_ARG_CHECK(a->taps == 9 || a->taps == 1, "conv_fwd: taps must be 1 or 9 (got %d)", a->taps);
   HPFG_ARG_CHECK(a->CoutPad % 16 == 0 && a->Cout <= a->CoutPad && a->Cout > 0, "conv_fwd: bad Cout %d / pad %d", a->Cout, a->CoutPad);
@@ -285,26 +272,23 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only, co
   hipStream_t st = (hipStream_t)stream;
   if (a->bwd_stats) {
     const int kind = hpfg_kind_of(a->a0, a->a1);
-    HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && (kind == HPFG_KIND_DZ || kind == HPFG_KIND_PLAIN || kind == HPFG_KIND_PLANES),
-                   "conv_fwd: bwd_stats is a dgrad feature of the bf16x3 kernels (DZ, PLAIN or PLANES source)");
+    HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && (kind == HPFG_KIND_DZ || kind == HPFG_KIND_PLAIN),
+                   "conv_fwd: bwd_stats is a dgrad feature of the bf16x3 kernels (DZ or PLAIN source)");
     HPFG_ARG_CHECK(a->stat_partials && a->bwd_of.z && a->bwd_of.bn && !a->bias, "conv_fwd: bwd_stats needs stat_partials, bwd_of.z / .bn and no bias");
     HPFG_ARG_CHECK(a->bwd_of.C == a->Cout && a->Cout == a->CoutPad && a->bwd_of.Hs == a->H && a->bwd_of.Ws == a->W && a->bwd_of.pstride % 4 == 0,
                    "conv_fwd: bwd_of must describe a layer with C == Cout == CoutPad (%d/%d/%d) at the output size", a->bwd_of.C, a->Cout, a->CoutPad);
   }
   if ((a->math & 0xff) == HPFG_MATH_BF16X3) {
-    if (!b) {      // the thin 16-pixel-aligned layers have a kernel of their own
+    {      // the thin 16-pixel-aligned layers have a kernel of their own
       const int r = hpfg_conv_thin_try(*a, st, rows_only);
       if (r != HPFG_THIN_NONE) return r;
     }
     switch (hpfg_kind_of(a->a0, a->a1)) {
-      case HPFG_KIND_PLAIN: return hpfg_conv16_launch_plain(*a, st, rows_only, b);
-      case HPFG_KIND_BNACT: return hpfg_conv16_launch_bnact(*a, st, rows_only, b);
-      case HPFG_KIND_POOL: return hpfg_conv16_launch_pool(*a, st, rows_only, b);
-      case HPFG_KIND_CAT: return hpfg_conv16_launch_cat(*a, st, rows_only, b);
-      case HPFG_KIND_DZ: return hpfg_conv16_launch_dz(*a, st, rows_only, b);
-      case HPFG_KIND_PLANES:
-        HPFG_ARG_CHECK(a->a0.C % 8 == 0 && a->a0.pstride % 8 == 0, "conv_fwd: a PLANES source needs C %% 8 == 0 (got %d)", a->a0.C);
-        return hpfg_conv16_launch_planes(*a, st, rows_only, b);
+      case HPFG_KIND_PLAIN: return hpfg_conv16_launch_plain(*a, st, rows_only);
+      case HPFG_KIND_BNACT: return hpfg_conv16_launch_bnact(*a, st, rows_only);
+      case HPFG_KIND_POOL: return hpfg_conv16_launch_pool(*a, st, rows_only);
+      case HPFG_KIND_CAT: return hpfg_conv16_launch_cat(*a, st, rows_only);
+      case HPFG_KIND_DZ: return hpfg_conv16_launch_dz(*a, st, rows_only);
       default: break;
     }
     hpfg_set_error("conv_fwd(bf16x3): unsupported source combination (a0.mode=%d, a1.mode=%d)", a->a0.mode, a->a1.mode);
@@ -327,31 +311,21 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only, co
   return -1;
 }
 
-static int conv_first_impl(const HpfgFirstConvArgs* a, const HpfgFirstConvArgs* b, int N, int H, int W, int Cin, int Cout, void* stream) {
+static int conv_first_impl(const HpfgFirstConvArgs* q, int N, int H, int W, int Cin, int Cout, void* stream) {
   HPFG_ARG_CHECK(Cin >= 1 && Cin <= 4 && Cout == 16, "conv_first: needs Cin<=4, Cout==16 (got %d,%d)", Cin, Cout);
-  for (const HpfgFirstConvArgs* q : {a, b}) {
-    if (!q) continue;
-    HPFG_ARG_CHECK(q->x.z && q->w_oihw && q->bias && q->out, "conv_first: null pointer");
-    HPFG_ARG_CHECK(q->x.mode == HPFG_ACT_STRIDED, "conv_first: input must be a STRIDED source");
-    // stat partial layout must match hpfg_conv_stat_blocks(): 16x16 tiles only when H,W are multiples of 16
-    HPFG_ARG_CHECK(q->stat_partials == nullptr || tile_is_big(H, W), "conv_first: BN partials need H,W multiples of 16 (got %dx%d)", H, W);
-  }
-  HPFG_ARG_CHECK(!b || (a->out != b->out && (a->stat_partials != nullptr) == (b->stat_partials != nullptr)), "conv_first_pair: outputs must differ");
+  HPFG_ARG_CHECK(q->x.z && q->w_oihw && q->bias && q->out, "conv_first: null pointer");
+  HPFG_ARG_CHECK(q->x.mode == HPFG_ACT_STRIDED, "conv_first: input must be a STRIDED source");
+  // stat partial layout must match hpfg_conv_stat_blocks(): 16x16 tiles only when H,W are multiples of 16
+  HPFG_ARG_CHECK(q->stat_partials == nullptr || tile_is_big(H, W), "conv_first: BN partials need H,W multiples of 16 (got %dx%d)", H, W);
   int tx = (W + 15) / 16, ty = (H + 15) / 16;
-  FirstPair pp;
-  pp.g[0] = *a;
-  pp.g[1] = b ? *b : *a;
   const char* fe = getenv("HPFG_FIRST_MFMA");      // 0: the VALU form for the 1-channel layer too (A/B runs)
+  const dim3 g1(conv_first_grid(N, H, W));
   if ((Cin == 1 || Cin == 3) && !(fe && atoi(fe) == 0)) {      // grey-scale (ACDC / LIDC) and RGB (CPS config) inputs
-    const dim3 g1(conv_first_grid(N, H, W)), g2(conv_first_grid(N, H, W), 2);
-    if (Cin == 1 && b) hipLaunchKernelGGL((conv_first_mfma_kernel<1, true>), g2, dim3(256), 0, (hipStream_t)stream, pp, N, H, W, tx, ty);
-    else if (Cin == 1) hipLaunchKernelGGL((conv_first_mfma_kernel<1, false>), g1, dim3(256), 0, (hipStream_t)stream, pp, N, H, W, tx, ty);
-    else if (b) hipLaunchKernelGGL((conv_first_mfma_kernel<3, true>), g2, dim3(256), 0, (hipStream_t)stream, pp, N, H, W, tx, ty);
-    else hipLaunchKernelGGL((conv_first_mfma_kernel<3, false>), g1, dim3(256), 0, (hipStream_t)stream, pp, N, H, W, tx, ty);
+    if (Cin == 1) hipLaunchKernelGGL((conv_first_mfma_kernel<1>), g1, dim3(256), 0, (hipStream_t)stream, *q, N, H, W, tx, ty);
+    else hipLaunchKernelGGL((conv_first_mfma_kernel<3>), g1, dim3(256), 0, (hipStream_t)stream, *q, N, H, W, tx, ty);
     return hpfg_launch_status("conv_first_mfma_kernel");
   }
-  if (b) hipLaunchKernelGGL(conv_first_kernel<true>, dim3(conv_first_grid(N, H, W), 2), dim3(256), 0, (hipStream_t)stream, pp, N, H, W, Cin, tx, ty);
-  else hipLaunchKernelGGL(conv_first_kernel<false>, dim3(conv_first_grid(N, H, W)), dim3(256), 0, (hipStream_t)stream, pp, N, H, W, Cin, tx, ty);
+  hipLaunchKernelGGL(conv_first_kernel, g1, dim3(256), 0, (hipStream_t)stream, *q, N, H, W, Cin, tx, ty);
   return hpfg_launch_status("conv_first_kernel");
 }
 
@@ -359,10 +333,6 @@ extern "C" int hpfg_conv3x3_first_fwd(const HpfgAct* x, const float* w_oihw, con
                                       int N, int H, int W, int Cin, int Cout, void* stream) {
   HPFG_ARG_CHECK(x, "conv_first: null pointer");
   HpfgFirstConvArgs a = {*x, w_oihw, bias, out, stat_partials};
-  return conv_first_impl(&a, nullptr, N, H, W, Cin, Cout, stream);
+  return conv_first_impl(&a, N, H, W, Cin, Cout, stream);
 }
 
-extern "C" int hpfg_conv3x3_first_fwd_pair(const HpfgFirstConvArgs* a, const HpfgFirstConvArgs* b, int N, int H, int W, int Cin, int Cout, void* stream) {
-  HPFG_ARG_CHECK(a && b, "conv_first_pair: null pointer");
-  return conv_first_impl(a, b, N, H, W, Cin, Cout, stream);
-}

@@ -1,9 +1,9 @@
 #include "conv_bf16_kernel.h"
 
-int hpfg_conv16_launch_cat(const HpfgConvArgs& a, hipStream_t st, int* rows_only, const HpfgConvArgs* b) {
+int hpfg_conv16_launch_cat(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   if (a.taps != 9) {
     hpfg_set_error("conv_fwd(bf16x3): 1x1 convolution with a cat loader is not instantiated");
     return -1;
   }
-  return hpfg_conv16::conv_dispatch_kind<HPFG_KIND_CAT, 9>(a, st, rows_only, b);
+  return hpfg_conv16::conv_dispatch_kind<HPFG_KIND_CAT, 9>(a, st, rows_only);
 }

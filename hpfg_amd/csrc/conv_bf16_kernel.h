@@ -266,12 +266,9 @@ constexpr int wg_per_cu() {
 
 // BWD: the dgrad variant whose epilogue also produces the BatchNorm-backward sums of the layer below (p.bwd_stats); a separate
 // instantiation so that the plain kernels keep their register budget.
-// PAIR: the launch carries two layers (blockIdx.z selects); a separate instantiation, because indexing the kernel arguments with a run-time
-// value cost the single-layer launches 3 % of the step (every argument field becomes a scalar load behind an address computation).
-template <class C, int KIND, bool BWD = false, bool PAIR = false>
-__global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kernel(HpfgConvPair pp, int tiles_x, int tiles_y) {
+template <class C, int KIND, bool BWD = false>
+__global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   static_assert(C::TAPS == 9, "persistent kernel is the 3x3 path");
-  const HpfgConvArgs& p = pp.g[PAIR ? blockIdx.z : 0];
   constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
   constexpr int NR = eff_nr<KIND>();
   constexpr bool CATK = KIND == HPFG_KIND_CAT;
@@ -577,18 +574,16 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
 }
 
 // 1x1: one tile per workgroup, K = 32 input channels per MFMA step, no halo.
-template <class C, int KIND, bool BWD = false, bool PAIR = false>
-__global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvPair pp, int tiles_x, int tiles_y) {
+template <class C, int KIND, bool BWD = false>
+__global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   static_assert(C::TAPS == 1, "1x1 path");
-  const int grp = PAIR ? (int)blockIdx.y / pp.g[0].N : 0;
-  const HpfgConvArgs& p = pp.g[grp];
   constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
   constexpr int NR = RawCount<KIND>::N;
   __shared__ __attribute__((aligned(16))) unsigned char lds[C::BUF_BYTES + STAT_BYTES];
   float* ldsf = reinterpret_cast<float*>(lds + C::BUF_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % C::WM, wn = wave / C::WM;
-  const int tile = blockIdx.x, n = (int)blockIdx.y - grp * p.N, cb = blockIdx.z;
+  const int tile = blockIdx.x, n = blockIdx.y, cb = blockIdx.z;
   const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
   const int H = p.H, W = p.W;
   const ActCtx cx0 = make_ctx(p.a0);
@@ -672,80 +667,47 @@ int persistent_grid(const HpfgConvArgs& a) {
   return (int)((nwork + rounds - 1) / rounds);
 }
 
-}  // namespace hpfg_conv16
-#include "conv_ws_kernel.h"
-namespace hpfg_conv16 {
-
 template <class C, int KIND>
-int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only, const HpfgConvArgs* b = nullptr) {
+int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   int tx = (a.W + C::TW - 1) / C::TW, ty = (a.H + C::TH - 1) / C::TH;
-  bool ws = false;
-  if constexpr (C::TAPS == 9) ws = ws_enabled<C, KIND>() && a.a0.C + a.a1.C <= WS_CT && !a.bwd_stats && !b;
-  HpfgConvPair pp;
-  pp.g[0] = a;
-  pp.g[1] = b ? *b : a;
-  const unsigned ng = b ? 2 : 1;
   if (rows_only) {
-    if constexpr (C::TAPS == 9) *rows_only = ws ? ws_grid<C, KIND>(a) : persistent_grid<C, KIND>(a);
+    if constexpr (C::TAPS == 9) *rows_only = persistent_grid<C, KIND>(a);
     else *rows_only = tx * ty * a.N;
     return 0;
   }
   if constexpr (C::TAPS == 9) {
-    if (ws) {
-      dim3 grid((unsigned)ws_grid<C, KIND>(a), a.CoutPad / C::BN);
-      hipLaunchKernelGGL((conv_ws_kernel<C, KIND>), grid, dim3(512), 0, st, a, tx, ty);
-      return hpfg_launch_status("conv_ws_kernel");
-    }
-    dim3 grid((unsigned)persistent_grid<C, KIND>(a), a.CoutPad / C::BN, ng);
-    if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLAIN || KIND == HPFG_KIND_PLANES) {
+    dim3 grid((unsigned)persistent_grid<C, KIND>(a), a.CoutPad / C::BN);
+    if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLAIN) {
       if (a.bwd_stats) {
-        hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND, true>), grid, dim3(256), 0, st, pp, tx, ty);
+        hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND, true>), grid, dim3(256), 0, st, a, tx, ty);
         return hpfg_launch_status("conv_bf16x3_kernel<bwd stats>");
       }
     }
-    if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLANES) {
-      if (b) {
-        hpfg_set_error("conv_fwd_pair: forward source kinds only");
-        return -1;
-      }
-    } else if (b) {
-      hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND, false, true>), grid, dim3(256), 0, st, pp, tx, ty);
-      return hpfg_launch_status("conv_bf16x3_kernel<pair>");
-    }
-    hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND>), grid, dim3(256), 0, st, pp, tx, ty);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND>), grid, dim3(256), 0, st, a, tx, ty);
   } else {
-    dim3 grid(tx * ty, a.N * ng, a.CoutPad / C::BN);
+    dim3 grid(tx * ty, a.N, a.CoutPad / C::BN);
     if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLAIN) {
       if (a.bwd_stats) {
-        hipLaunchKernelGGL((conv1x1_bf16x3_kernel<C, KIND, true>), grid, dim3(256), 0, st, pp, tx, ty);
+        hipLaunchKernelGGL((conv1x1_bf16x3_kernel<C, KIND, true>), grid, dim3(256), 0, st, a, tx, ty);
         return hpfg_launch_status("conv1x1_bf16x3_kernel<bwd stats>");
       }
     }
-    if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLANES) {
-      if (b) {
-        hpfg_set_error("conv_fwd_pair: forward source kinds only");
-        return -1;
-      }
-    } else if (b) {
-      hipLaunchKernelGGL((conv1x1_bf16x3_kernel<C, KIND, false, true>), grid, dim3(256), 0, st, pp, tx, ty);
-      return hpfg_launch_status("conv1x1_bf16x3_kernel<pair>");
-    }
-    hipLaunchKernelGGL((conv1x1_bf16x3_kernel<C, KIND>), grid, dim3(256), 0, st, pp, tx, ty);
+    hipLaunchKernelGGL((conv1x1_bf16x3_kernel<C, KIND>), grid, dim3(256), 0, st, a, tx, ty);
   }
   return hpfg_launch_status("conv_bf16x3_kernel");
 }
 
 template <int KIND, int TAPS>
-int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st, int* rows_only, const HpfgConvArgs* b = nullptr) {
+int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   const bool big = (a.H % 16 == 0) && (a.W % 16 == 0);
   const int cp = a.CoutPad;
   constexpr int KCB = TAPS == 9 ? 16 : 32;
   if (big) {
     if constexpr (TAPS == 1) {
-      if (cp % 64 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 4, TAPS, KCB>, KIND>(a, st, rows_only, b);
+      if (cp % 64 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 4, TAPS, KCB>, KIND>(a, st, rows_only);
     }
-    if (cp % 32 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 2, TAPS, KCB>, KIND>(a, st, rows_only, b);   // 3x3: 32-channel slices (B ring = 80 VGPRs)
-    return launch_cfg<Cfg<16, 16, 4, 1, 1, TAPS, KCB>, KIND>(a, st, rows_only, b);
+    if (cp % 32 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 2, TAPS, KCB>, KIND>(a, st, rows_only);   // 3x3: 32-channel slices (B ring = 80 VGPRs)
+    return launch_cfg<Cfg<16, 16, 4, 1, 1, TAPS, KCB>, KIND>(a, st, rows_only);
   }
   if constexpr (TAPS == 9) {
     // 3x3 on sizes that are not multiples of 16 (56, 28, 14, ...): 4x16-pixel tiles.  Same 64 pixels per workgroup as an 8x8 tile
@@ -756,27 +718,26 @@ int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st, int* rows_only, co
     const char* f = getenv("HPFG_SMALL_BN");
     const int force = f ? atoi(f) : 0;
     if (force != 999) {
-      if (cp % 128 == 0 && force == 128) return launch_cfg<Cfg<4, 16, 1, 4, 2, TAPS, 32>, KIND>(a, st, rows_only, b);
-      if (cp % 64 == 0 && force != 32) return launch_cfg<Cfg<4, 16, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only, b);
-      if (cp % 32 == 0) return launch_cfg<Cfg<4, 16, 2, 2, 1, TAPS, 32>, KIND>(a, st, rows_only, b);
-      return launch_cfg<Cfg<4, 16, 4, 1, 1, TAPS, 32>, KIND>(a, st, rows_only, b);
+      if (cp % 128 == 0 && force == 128) return launch_cfg<Cfg<4, 16, 1, 4, 2, TAPS, 32>, KIND>(a, st, rows_only);
+      if (cp % 64 == 0 && force != 32) return launch_cfg<Cfg<4, 16, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only);
+      if (cp % 32 == 0) return launch_cfg<Cfg<4, 16, 2, 2, 1, TAPS, 32>, KIND>(a, st, rows_only);
+      return launch_cfg<Cfg<4, 16, 4, 1, 1, TAPS, 32>, KIND>(a, st, rows_only);
     }
   }
   // small spatial sizes have few 8x8 tiles: narrow the output-channel slice per workgroup until there are >= 2 workgroups per CU
   const long nwork = (long)a.N * ((a.H + 7) / 8) * ((a.W + 7) / 8);
-  if (cp % 128 == 0 && nwork * (cp / 128) >= 512) return launch_cfg<Cfg<8, 8, 1, 4, 2, TAPS, 32>, KIND>(a, st, rows_only, b);
-  if (cp % 64 == 0 && (nwork * (cp / 64) >= 512 || cp % 32 != 0)) return launch_cfg<Cfg<8, 8, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only, b);
-  if (cp % 32 == 0) return launch_cfg<Cfg<8, 8, 2, 2, 1, TAPS, 32>, KIND>(a, st, rows_only, b);
-  return launch_cfg<Cfg<8, 8, 4, 1, 1, TAPS, 32>, KIND>(a, st, rows_only, b);
+  if (cp % 128 == 0 && nwork * (cp / 128) >= 512) return launch_cfg<Cfg<8, 8, 1, 4, 2, TAPS, 32>, KIND>(a, st, rows_only);
+  if (cp % 64 == 0 && (nwork * (cp / 64) >= 512 || cp % 32 != 0)) return launch_cfg<Cfg<8, 8, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only);
+  if (cp % 32 == 0) return launch_cfg<Cfg<8, 8, 2, 2, 1, TAPS, 32>, KIND>(a, st, rows_only);
+  return launch_cfg<Cfg<8, 8, 4, 1, 1, TAPS, 32>, KIND>(a, st, rows_only);
 }
 
 }  // namespace hpfg_conv16
 
 constexpr int HPFG_THIN_NONE = -100;
 int hpfg_conv_thin_try(const HpfgConvArgs& a, hipStream_t st, int* rows_only);      // conv_thin.hip
-int hpfg_conv16_launch_plain(const HpfgConvArgs& a, hipStream_t st, int* rows_only, const HpfgConvArgs* b = nullptr);
-int hpfg_conv16_launch_bnact(const HpfgConvArgs& a, hipStream_t st, int* rows_only, const HpfgConvArgs* b = nullptr);
-int hpfg_conv16_launch_pool(const HpfgConvArgs& a, hipStream_t st, int* rows_only, const HpfgConvArgs* b = nullptr);
-int hpfg_conv16_launch_cat(const HpfgConvArgs& a, hipStream_t st, int* rows_only, const HpfgConvArgs* b = nullptr);
-int hpfg_conv16_launch_dz(const HpfgConvArgs& a, hipStream_t st, int* rows_only, const HpfgConvArgs* b = nullptr);
-int hpfg_conv16_launch_planes(const HpfgConvArgs& a, hipStream_t st, int* rows_only, const HpfgConvArgs* b = nullptr);
+int hpfg_conv16_launch_plain(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
+int hpfg_conv16_launch_bnact(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
+int hpfg_conv16_launch_pool(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
+int hpfg_conv16_launch_cat(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
+int hpfg_conv16_launch_dz(const HpfgConvArgs& a, hipStream_t st, int* rows_only);

@@ -522,39 +522,6 @@ extern "C" int hpfg_pack_weights(const HpfgPackDesc* table_dev, const HpfgPackDe
   return hpfg_pack_weights_bump(table_dev, table_host, nlayers, nullptr, 0, nullptr, 0, stream);
 }
 
-namespace {
-// one thread per (pixel, group of 8 channels): 8 values of the virtual activation [a0 | a1] -> 16 B of bf16 hi + 16 B of bf16 lo
-__global__ __launch_bounds__(256) void act_to_planes_kernel(HpfgAct a0, HpfgAct a1, long npix, int H, int W, int Ctot, float* __restrict__ out) {
-  const int G = Ctot >> 3;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= npix * G) return;
-  const long pix = idx / G;
-  const int c = (int)(idx % G) * 8;
-  const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
-  const ActCtx c0 = make_ctx(a0), c1 = make_ctx(a1);
-  const f32x4 v0 = cat_load4(a0, c0, a1, c1, n, y, x, c), v1 = cat_load4(a0, c0, a1, c1, n, y, x, c + 4);
-  hpfg_stage::bf16x8 hi, lo;
-  hpfg_stage::split8(v0, v1, hi, lo);
-  hpfg_stage::bf16x8* o = reinterpret_cast<hpfg_stage::bf16x8*>(out + pix * Ctot + c);
-  o[0] = hi;
-  o[1] = lo;
-}
-}  // namespace
-
-extern "C" int hpfg_act_to_planes(const HpfgAct* a0, const HpfgAct* a1, int N, int H, int W, void* planes, void* stream) {
-  HPFG_ARG_CHECK(a0 && planes && N > 0 && H > 0 && W > 0, "act_to_planes: bad args");
-  HpfgAct none;
-  memset(&none, 0, sizeof(none));
-  const HpfgAct& b = a1 ? *a1 : none;
-  const int ctot = a0->C + (b.mode == HPFG_ACT_NONE ? 0 : b.C);
-  HPFG_ARG_CHECK(ctot % 8 == 0 && a0->C % 4 == 0 && a0->mode != HPFG_ACT_STRIDED && a0->mode != HPFG_ACT_PLANES,
-                 "act_to_planes: needs C_total %% 8 == 0 (got %d) and a float4-loadable source", ctot);
-  const long npix = (long)N * H * W, total = npix * (ctot / 8);
-  hipLaunchKernelGGL(act_to_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a0, b, npix, H, W, ctot,
-                     reinterpret_cast<float*>(planes));
-  return hpfg_launch_status("act_to_planes_kernel");
-}
-
 extern "C" int hpfg_act_materialize(const HpfgAct* a0, const HpfgAct* a1, int N, int H, int W, float* out, void* stream) {
   HPFG_ARG_CHECK(a0 && out && N > 0 && H > 0 && W > 0, "act_materialize: bad args");
   HpfgAct none;

@@ -182,8 +182,7 @@ extern "C" int hpfg_wgrad(const HpfgWgradArgs* a, void* stream) {
   if ((a->math & 0xff) == HPFG_MATH_BF16X3 && a->taps == 1 && (a->g.mode == HPFG_ACT_PLAIN || a->g.mode == HPFG_ACT_STRIDED) && a->g.C % 4 == 0)
     rc = hpfg_wgrad16_launch_1x1(*a, akind, st);          // 1 = kind not covered, use the fp32 kernel below
   if (rc != 1) {
-  } else if (b16 && a->g.mode == HPFG_ACT_PLANES) rc = hpfg_wgrad16_launch_planes(*a, akind, st);
-  else if (b16 && a->g.mode == HPFG_ACT_DZ) rc = hpfg_wgrad16_launch_dz(*a, akind, st);
+  } else if (b16 && a->g.mode == HPFG_ACT_DZ) rc = hpfg_wgrad16_launch_dz(*a, akind, st);
   else if (b16 && (a->g.mode == HPFG_ACT_PLAIN || a->g.mode == HPFG_ACT_STRIDED)) rc = hpfg_wgrad16_launch_plain(*a, akind, st);
   else if (a->g.mode == HPFG_ACT_DZ) rc = hpfg_wgrad_launch_dz(*a, akind, st);
   else if (a->g.mode == HPFG_ACT_PLAIN || a->g.mode == HPFG_ACT_STRIDED) rc = hpfg_wgrad_launch_plain(*a, akind, st);

@@ -134,14 +134,7 @@ class UNetEngine:
         self.math = L.MATH_F32      # L.MATH_BF16X3 selects the split-bf16 matrix-core kernels for conv forward / dgrad
         self.ext_masks: Dict[str, torch.Tensor] = {}   # conv name -> uint8 NHWC keep-mask (parity tests replaying torch's masks)
         self.allreduce = None    # callable(tensor) -> in-place sum across ranks (data parallel), set by hpfg_amd.parallel
-        # Channel-rich layers (>= 64 channels in and out, <= 56x56): in the split-bf16 math mode their input activation (and, in backward,
-        # dZ) is MATERIALISED once in split-bf16 form (hpfg_act_to_planes -> HPFG_ACT_PLANES) and the conv / dgrad / wgrad kernels stage
-        # it with no arithmetic.  On-load fusion stays where it is free: the thin 224x224 / 112x112 layers are byte-bound and stage each
-        # tile once, these layers re-stage every tile once per output-channel slice (wgrad: Cout/32 + Cin/32 times).
         self._skip_fin, self._fin_done = os.environ.get("HPFG_SKIP_FINALIZE", "0") == "1", {}
-        self.use_planes = os.environ.get("HPFG_PLANES", "0") == "1"      # measured: the extra streaming passes eat what the conv / wgrad kernels gain -> off by default
-        self.planes: Dict[str, torch.Tensor] = {}
-        self.dz_planes: Optional[torch.Tensor] = None
         self.probe = None        # bench.py: (conv name, [(event, event), ...]) -- HIP events around that layer's forward launch (eager steps only)
 
     # ---------------------------------------------------------------------------------------------------------
@@ -185,41 +178,6 @@ class UNetEngine:
             a.drop_p, a.drop_seed, a.seed_dev = s.drop_p, self.layer_seed(s), L.ptr(self.seed_dev)
             a.drop_mask = L.ptr(self.ext_masks.get(name)) if self.ext_masks else None
         return a
-
-    def is_deep(self, s: ConvSpec) -> bool:
-        return (self.use_planes and self.math == L.MATH_BF16X3 and self.wgrad_overlap in (0, 3) and s.taps == 9 and s.cin >= 64 and s.cout >= 64
-                and s.h <= 56 and s.w <= 56 and s.cin % 8 == 0 and s.cout % 8 == 0)
-
-    def _act_planes(self, t: torch.Tensor, C_: int, h: int, w: int) -> L.Act:
-        a = L.Act()
-        a.z, a.mode, a.C, a.Hs, a.Ws, a.pstride = L.ptr(t), L.ACT_PLANES, C_, h, w, C_
-        return a
-
-    def _to_planes(self, a0: L.Act, a1: Optional[L.Act], s: ConvSpec, C_: int, out: torch.Tensor) -> L.Act:
-        L.check(self.lib.hpfg_act_to_planes(C.byref(a0), C.byref(a1) if a1 is not None else None, self.N, s.h, s.w, L.ptr(out), self._stream()),
-                f"act_to_planes[{s.name}]")
-        return self._act_planes(out, C_, s.h, s.w)
-
-    def staged_inputs(self, s: ConvSpec, fresh: bool):
-        """(a0, a1) the conv / wgrad kernels of layer s read: the on-load description, or for a channel-rich layer its materialised
-        split-bf16 planes (written when `fresh`, i.e. by the forward pass; backward re-uses them for the weight gradient)."""
-        if not self.is_deep(s):
-            return self.input_acts(s.name)
-        if s.name not in self.planes:
-            self.planes[s.name] = torch.empty(self.N, s.h, s.w, s.cin, dtype=torch.float32, device=self.dev)   # 4 B per channel: bf16 hi + bf16 lo
-        if fresh:
-            a0, a1 = self.input_acts(s.name)
-            self._to_planes(a0, a1, s, s.cin, self.planes[s.name])
-        return self._act_planes(self.planes[s.name], s.cin, s.h, s.w), L.Act()
-
-    def staged_dz(self, s: ConvSpec, g: L.Act) -> L.Act:
-        """dZ source of layer s for dgrad / wgrad: the DZ description, or for a channel-rich layer dZ materialised once as planes."""
-        if not self.is_deep(s):
-            return g
-        if self.dz_planes is None:
-            need = max(self.N * t.h * t.w * t.cout for t in self.order if self.is_deep(t))
-            self.dz_planes = torch.empty(need, dtype=torch.float32, device=self.dev)
-        return self._to_planes(g, None, s, s.cout, self.dz_planes)
 
     def input_acts(self, name: str):
         """(a0, a1) virtual input of conv `name` (forward view)."""
@@ -309,7 +267,7 @@ class UNetEngine:
 
     def _conv_args(self, s: ConvSpec, out: torch.Tensor, want_stats: bool) -> L.ConvArgs:
         ca = L.ConvArgs()
-        ca.a0, ca.a1 = self.staged_inputs(s, fresh=True)
+        ca.a0, ca.a1 = self.input_acts(s.name)
         ca.math = self.math
         ca.wpk = L.ptr(self.wpk16_f[s.name]) if self.math == L.MATH_BF16X3 else L.ptr(self.wpk_f[s.name])
         ca.bias, ca.out = L.ptr(self.bias_pad[s.name]), L.ptr(out)
@@ -334,7 +292,7 @@ class UNetEngine:
         want_stats = bool(s.bn) and train
         nblk = self.lib.hpfg_conv_stat_blocks(self.N, s.h, s.w)
         if s.idx == 0:
-            a0, _ = self.staged_inputs(s, fresh=True)
+            a0, _ = self.input_acts(s.name)
             L.check(self.lib.hpfg_conv3x3_first_fwd(C.byref(a0), L.ptr(self.params[f"{s.name}.weight"]), L.ptr(self.params[f"{s.name}.bias"]),
                                                     L.ptr(out), L.ptr(self.partials) if want_stats else None, self.N, s.h, s.w, s.cin, s.cout, st),
                     "conv3x3_first_fwd")
@@ -363,69 +321,6 @@ class UNetEngine:
                 L.check(self.lib.hpfg_bn_eval_table(L.ptr(self.params[f"{s.bn}.weight"]), L.ptr(self.params[f"{s.bn}.bias"]),
                                                     L.ptr(self.buffers[f"{s.bn}.running_mean"]), L.ptr(self.buffers[f"{s.bn}.running_var"]), BN_EPS,
                                                     L.ptr(self.bn[s.name]), s.cout, st), "bn_eval_table")
-
-    @staticmethod
-    def forward_interleaved(ea: "UNetEngine", eb: "UNetEngine", xa: torch.Tensor, xb: torch.Tensor, stream_b, track_running=(True, True),
-                            seed_steps=(None, None), needs_grad=(True, False)):
-        """Train-mode forward of two networks with the same schedule, `ea` on the current stream and `eb` on `stream_b` (already forked behind
-        the current one), their launches ISSUED ALTERNATELY, layer by layer.  Same kernels, same results as ea.forward / eb.forward on those two
-        streams; only the order in which the launches are queued (and captured into a hipGraph) differs: a graph's nodes reach the hardware
-        queues in creation order, one after the other, so a network whose whole forward is captured first keeps the other one's first kernel
-        waiting for its ~60 submissions (`tools/stream_timeline.py`: 108 us)."""
-        assert len(ea.order) == len(eb.order)
-        la = ea._fwd_begin(xa, True, None, seed_steps[0], needs_grad[0])
-        with torch.cuda.stream(stream_b):
-            lb = eb._fwd_begin(xb, True, None, seed_steps[1], needs_grad[1])
-        for sa, sb in zip(ea.order, eb.order):
-            ea._fwd_layer(sa, la, True, track_running[0])
-            with torch.cuda.stream(stream_b):
-                eb._fwd_layer(sb, lb, True, track_running[1])
-        ea.bwd_ready, eb.bwd_ready = bool(needs_grad[0]), bool(needs_grad[1])
-        return la, lb
-
-    def pairable(self, other: "UNetEngine") -> bool:
-        """Can forward_pair() run this engine and `other` layer by layer in shared launches?"""
-        return (other is not self and (self.N, self.H, self.W, self.in_ch, self.ncls) == (other.N, other.H, other.W, other.in_ch, other.ncls)
-                and self.dev == other.dev and self.math == L.MATH_BF16X3 and other.math == L.MATH_BF16X3
-                and self.world == 1 and other.world == 1 and not self.force_sync and not other.force_sync
-                and not self.use_planes and not other.use_planes and self.probe is None and other.probe is None)
-
-    @staticmethod
-    def forward_pair(ea: "UNetEngine", eb: "UNetEngine", xa: torch.Tensor, xb: torch.Tensor, track_running=(True, True), seed_steps=(None, None),
-                     needs_grad=(True, False)):
-        """Train-mode forward of two networks of identical geometry (student + teacher of Mean-Teacher, 2017_03_NIPS_Mean-Teacher_ACDC.py:94-101;
-        the two students of CPS), every layer of both in ONE launch (hpfg_conv_fwd_pair, hpfg_bn_fwd_finalize_pair).  Results are bit-identical
-        to ea.forward(xa), eb.forward(xb); the step has half the forward launches and no second stream competing for the chip."""
-        assert ea.pairable(eb)
-        lib, st = ea.lib, ea._stream()
-        la = ea._fwd_begin(xa, True, None, seed_steps[0], needs_grad[0])
-        lb = eb._fwd_begin(xb, True, None, seed_steps[1], needs_grad[1])
-        for s in ea.order:
-            oa = la if s.name == "decoder.out_conv" else ea.z[s.name]
-            ob = lb if s.name == "decoder.out_conv" else eb.z[s.name]
-            want_stats = bool(s.bn)
-            if s.idx == 0:
-                fa, fb = L.FirstConvArgs(), L.FirstConvArgs()
-                for f, e, o in ((fa, ea, oa), (fb, eb, ob)):
-                    f.x, _ = e.staged_inputs(s, fresh=True)
-                    f.w_oihw, f.bias, f.out = L.ptr(e.params[f"{s.name}.weight"]), L.ptr(e.params[f"{s.name}.bias"]), L.ptr(o)
-                    f.stat_partials = L.ptr(e.partials) if want_stats else None
-                L.check(lib.hpfg_conv3x3_first_fwd_pair(C.byref(fa), C.byref(fb), ea.N, s.h, s.w, s.cin, s.cout, st), "conv3x3_first_fwd_pair")
-                nblk = lib.hpfg_conv_first_rows(ea.N, s.h, s.w)
-            else:
-                ca, cb = ea._conv_args(s, oa, want_stats), eb._conv_args(s, ob, want_stats)
-                L.check(lib.hpfg_conv_fwd_pair(C.byref(ca), C.byref(cb), st), f"conv_fwd_pair[{s.name}]")
-                nblk = lib.hpfg_conv_stat_rows(C.byref(ca)) if want_stats else 0
-            if s.bn:
-                qa, qb = L.BnFinalizeArgs(), L.BnFinalizeArgs()
-                for q, e, track in ((qa, ea, track_running[0]), (qb, eb, track_running[1])):
-                    q.partials, q.gamma, q.beta, q.bn = L.ptr(e.partials), L.ptr(e.params[f"{s.bn}.weight"]), L.ptr(e.params[f"{s.bn}.bias"]), L.ptr(e.bn[s.name])
-                    q.running_mean = L.ptr(e.buffers[f"{s.bn}.running_mean"]) if track else None
-                    q.running_var = L.ptr(e.buffers[f"{s.bn}.running_var"]) if track else None
-                L.check(lib.hpfg_bn_fwd_finalize_pair(C.byref(qa), C.byref(qb), nblk, float(ea.N * s.h * s.w), BN_MOMENTUM, BN_EPS, s.cout, st),
-                        "bn_fwd_finalize_pair")
-        ea.bwd_ready, eb.bwd_ready = bool(needs_grad[0]), bool(needs_grad[1])
-        return la, lb
 
     def materialize(self, name: str, mode=L.ACT_BNACT) -> torch.Tensor:
         """Activated output of conv `name` as a real [N,h,w,C] tensor (projection-neck input, tests)."""
@@ -559,7 +454,6 @@ class UNetEngine:
         """Both gradients of layer s from the same dZ source (they only read it, so their order is free)."""
         if s.name in self.fused_grid:
             return self._fused_bwd(s, g, dgrad_out, stats_for, out2)
-        g = self.staged_dz(s, g)
         if self._deferred is not None:      # decoder half: the weight gradient is queued for the side stream (see backward())
             self._dgrad(s, g, dgrad_out, stats_for, out2)
             self._deferred.append((s, g))
@@ -622,7 +516,7 @@ class UNetEngine:
         else:
             stream = main.cuda_stream
         wa = L.WgradArgs()
-        wa.a0, wa.a1 = self.staged_inputs(s, fresh=False)
+        wa.a0, wa.a1 = self.input_acts(s.name)
         wa.g = g
         wa.slab, wa.dw_oihw, wa.defer_reduce = L.ptr(self.slab_of[s.name]), L.ptr(self.grads[f"{s.name}.weight"]), 1
         wa.Cin, wa.CinPad, wa.Cout, wa.CoutPad = s.cin, s.cin_pad, s.cout, s.cout_pad

@@ -85,24 +85,7 @@ class _UNetFn(torch.autograd.Function):
         eng = net._acquire_engine(x)
         if getattr(net, "_bn_bump_pending", False):
             eng.bump_counters, net._bn_bump_pending = net._flat_long, False
-        comp, net._companion = getattr(net, "_companion", None), None
-        if comp is not None:      # forward_pair(): a second network of the same geometry rides along in the same launches (no gradient)
-            net_b, x_b, side = comp
-            eng_b = net_b._acquire_engine(x_b)
-            if getattr(net_b, "_bn_bump_pending", False):
-                eng_b.bump_counters, net_b._bn_bump_pending = net_b._flat_long, False
-            if side is not None:      # two streams, launches issued alternately
-                logits, logits_b = E.UNetEngine.forward_interleaved(eng, eng_b, x, x_b, side, seed_steps=(net._next_seed(), net_b._next_seed()),
-                                                                    needs_grad=(needs_grad, False))
-            elif eng.pairable(eng_b):
-                logits, logits_b = E.UNetEngine.forward_pair(eng, eng_b, x, x_b, seed_steps=(net._next_seed(), net_b._next_seed()),
-                                                             needs_grad=(needs_grad, False))
-            else:      # (e.g. a timing probe is attached to one of the engines): the same two forwards, one after the other
-                logits = eng.forward(x, train=True, track_running=True, seed_step=net._next_seed(), needs_grad=needs_grad)
-                logits_b = eng_b.forward(x_b, train=True, track_running=True, seed_step=net_b._next_seed(), needs_grad=False)
-            net._companion_out = logits_b.permute(0, 3, 1, 2)
-        else:
-            logits = eng.forward(x, train=net.training, track_running=True, seed_step=net._next_seed(), needs_grad=needs_grad)
+        logits = eng.forward(x, train=net.training, track_running=True, seed_step=net._next_seed(), needs_grad=needs_grad)
         ctx.net, ctx.eng, ctx.want_feat = net, eng, want_feat
         out = logits.permute(0, 3, 1, 2)
         if want_feat:
@@ -363,42 +346,6 @@ class UNet(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._run(x, False)[0]
-
-
-def can_pair(net_a: UNet, net_b: UNet, x_a: torch.Tensor, x_b: torch.Tensor) -> bool:
-    """forward_pair() preconditions: two plain U-Nets of the same geometry in train mode on one device, split-bf16 math, no sync-BatchNorm."""
-    if os.environ.get("HPFG_PAIR_FWD", "0") != "1" or type(net_a) is not UNet or type(net_b) is not UNet or net_a is net_b:
-        return False
-    if not (net_a.training and net_b.training and x_a.is_cuda and tuple(x_a.shape) == tuple(x_b.shape) and x_a.device == x_b.device):
-        return False
-    if (net_a.in_channels, net_a.num_classes, net_a.math) != (net_b.in_channels, net_b.num_classes, "bf16x3") or net_b.math != "bf16x3":
-        return False
-    for n in (net_a, net_b):
-        if n.dp is not None and getattr(n.dp, "sync_bn", True) and (n.dp.world_size > 1 or getattr(n.dp, "force_sync", False)):
-            return False
-    return True
-
-
-def can_interleave(net_a: UNet, net_b: UNet, x_a: torch.Tensor, x_b: torch.Tensor) -> bool:
-    """forward_pair(side=stream) preconditions: two plain U-Nets of the same geometry in train mode on one device."""
-    if os.environ.get("HPFG_INTERLEAVE_FWD", "0") != "1" or type(net_a) is not UNet or type(net_b) is not UNet or net_a is net_b:
-        return False
-    return bool(net_a.training and net_b.training and x_a.is_cuda and tuple(x_a.shape) == tuple(x_b.shape) and x_a.device == x_b.device
-                and (net_a.in_channels, net_a.num_classes, net_a.math) == (net_b.in_channels, net_b.num_classes, net_b.math))
-
-
-def forward_pair(net_a: UNet, x_a: torch.Tensor, net_b: UNet, x_b: torch.Tensor, side=None):
-    """(net_a(x_a), net_b(x_b) under no_grad) -- the student / teacher pair of the Mean-Teacher step (2017_03_NIPS_Mean-Teacher_ACDC.py:94-101).
-    side None: every layer of both networks in ONE launch (callers check can_pair() first).  side = a stream already waiting on the current
-    one: net_b runs there, its launches issued alternately with net_a's (callers check can_interleave(); the caller joins the stream).
-    Bit-identical to the two separate calls either way."""
-    net_b._ensure_flat()
-    if net_b.training:
-        net_b._bump_bn_counters()
-    net_a._companion = (net_b, x_b.float(), side)
-    out_a = net_a(x_a)
-    out_b, net_a._companion_out = net_a._companion_out, None
-    return out_a, out_b
 
 
 class UNet_Plus(UNet):

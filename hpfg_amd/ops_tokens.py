@@ -103,12 +103,18 @@ class _Attention(torch.autograd.Function):
         P = torch.empty(B, h, N, M, dtype=torch.float32, device=q.device)
         dS = torch.empty_like(P)
         L.check(lib.hpfg_attn_bwd(L.ptr(q), L.ptr(kv), L.ptr(do), L.ptr(dq), L.ptr(P), L.ptr(dS), B, N, M, h, ctx.scale, _st(q)), "attn_bwd")
-        # dV = P^T dO, dK = scale * dS^T Q per (image, head)
-        doh = do.view(B, N, h, d).permute(0, 2, 1, 3)
-        qh = q.view(B, N, h, d).permute(0, 2, 1, 3)
-        dv = torch.matmul(P.transpose(-1, -2), doh)                    # [B,h,M,d]
-        dk = torch.matmul(dS.transpose(-1, -2), qh) * ctx.scale
-        dkv = torch.stack([dk, dv], 0).permute(1, 3, 0, 2, 4).reshape(B, M, 2 * C_)      # -> [B,M,2,h,d]
+        # dV = P^T dO, dK = scale * dS^T Q per (image, head): exact-fp32 MFMA GEMMs (hpfg_gemm_f32) writing straight into the [B,M,2,h,d] layout
+        dkv = torch.empty(B, M, 2, h, d, dtype=torch.float32, device=q.device)
+        st = _st(q)
+        for b in range(B):
+            for hh in range(h):
+                pbh, sbh = P[b, hh], dS[b, hh]                      # [N, M] each: A(m, k) = X[k, m] -> sam = 1, sak = M
+                L.check(lib.hpfg_gemm_f32(L.ptr(pbh), 1, M, do.data_ptr() + 4 * (b * N * C_ + hh * d), C_, 1, L.ptr(dkv[b, 0, 1, hh]), 2 * C_,
+                                          M, d, N, None, 0, 0, st), "attn dV")
+                L.check(lib.hpfg_gemm_f32(L.ptr(sbh), 1, M, q.data_ptr() + 4 * (b * N * C_ + hh * d), C_, 1, L.ptr(dkv[b, 0, 0, hh]), 2 * C_,
+                                          M, d, N, None, 0, 0, st), "attn dK")
+        dkv[:, :, 0].mul_(ctx.scale)
+        dkv = dkv.view(B, M, 2 * C_)
         return dq, dkv, None, None
 
 

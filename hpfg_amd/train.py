@@ -30,7 +30,6 @@ from .utils import (BoxMaskGenerator, build_lr_scheduler, build_optimizer, ema_a
                     update_ema_variables, update_ema_variables_backbone)
 from .utils.loss import _nhwc
 from .utils.optim import FusedSGD
-from .model.unet import can_interleave, can_pair, forward_pair
 
 # layout of the per-step scalar block (device fp32 [32])
 S_LR1, S_LR2, S_ALPHA, S_THRESH, S_COEF_A, S_COEF_B = 0, 1, 2, 3, 8, 16
@@ -263,20 +262,6 @@ class MeanTeacherStep(_StepBase):
         nl = label_img.shape[0]
         x = cat_batch(label_img, unlabel_img)
         self._mark(0)
-        if can_pair(self.model, self.ema_model, x, x):      # student and teacher layer by layer in shared launches
-            out, t_out = forward_pair(self.model, x, self.ema_model, x)
-            self._mark(4)
-            return self._loss_bwd(out, t_out, target_label, nl)
-        if self.overlap and can_interleave(self.model, self.ema_model, x, x):      # two streams, launches issued layer by layer in turn
-            self.side.wait_stream(torch.cuda.current_stream(self.dev))
-            self._mark(1)
-            out, t_out = forward_pair(self.model, x, self.ema_model, x, side=self.side)
-            self._pending_join = True
-            with torch.cuda.stream(self.side):
-                self._mark(3)
-            self._mark(4)
-            self._join_teacher(t_out)
-            return self._loss_bwd(out, t_out, target_label, nl)
         t_out = self._teacher_forward(self.ema_model, x)
         self._mark(1)
         out = self.model(x)

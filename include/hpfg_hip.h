@@ -37,12 +37,7 @@ enum {
   HPFG_ACT_BNACT = 3,      /* v = drop(lrelu(z*scale+shift))       unet.py:19-21,23-24 (BN train, LeakyReLU .01, Dropout) */
   HPFG_ACT_BNACT_POOL = 4, /* v = max 2x2 of lrelu(z*scale+shift)  unet.py:37 (MaxPool2d(2)) fused on load   */
   HPFG_ACT_UP2X = 5,       /* v = bilinear x2, align_corners=True  unet.py:51,56 fused on load               */
-  HPFG_ACT_DZ = 6,         /* v = k1*g + k2*z + k3, g = aux*dropmask*lrelu'(z*scale+shift): BN/LeakyReLU/Dropout backward */
-  HPFG_ACT_PLANES = 7      /* a MATERIALISED activation in split-bf16 form (hpfg_act_to_planes): per pixel and group of 8 channels
-                              32 bytes = 8 x bf16 hi, 8 x bf16 lo (x = hi + lo); z points at it, pstride = C (4-byte units), C % 8 == 0.
-                              Consumed by the bf16x3 conv / dgrad / wgrad kernels with no arithmetic in their loaders: the channel-rich
-                              layers re-stage every input tile once per output-channel slice, so the producer chain + split is done
-                              ONCE by a streaming pass instead (bf16x3 math mode only) */
+  HPFG_ACT_DZ = 6          /* v = k1*g + k2*z + k3, g = aux*dropmask*lrelu'(z*scale+shift): BN/LeakyReLU/Dropout backward */
 };
 
 typedef struct HpfgAct {
@@ -99,23 +94,6 @@ typedef struct HpfgWgradArgs {
   int32_t defer_reduce; /* 1: leave the slabs in `slab`; the caller sums them later with hpfg_slab_reduce_multi (one launch per backward) */
 } HpfgWgradArgs;
 
-typedef struct HpfgFirstConvArgs {   /* one network's side of hpfg_conv3x3_first_fwd_pair */
-  HpfgAct x;            /* STRIDED source: the network input */
-  const float* w_oihw;
-  const float* bias;
-  float* out;
-  float* stat_partials; /* or NULL */
-} HpfgFirstConvArgs;
-
-typedef struct HpfgBnFinalizeArgs {  /* one layer's side of hpfg_bn_fwd_finalize_pair (fields as in hpfg_bn_fwd_finalize) */
-  const float* partials;
-  const float* gamma;
-  const float* beta;
-  float* running_mean;  /* or NULL: statistics not tracked */
-  float* running_var;
-  float* bn;
-} HpfgBnFinalizeArgs;
-
 typedef struct HpfgFusedBwdArgs {   /* hpfg_fused_bwd: both gradients of a thin 3x3 layer from ONE staging of dZ (see below) */
   HpfgConvArgs d;       /* the dgrad side exactly as hpfg_conv_fwd takes it: a0 = dZ (DZ or PLAIN), wpk = wpk16_dgrad, out / out2 = dX,
                            Cout / CoutPad = the layer's Cin / CinPad, bwd_stats / bwd_of / stat_partials; math = HPFG_MATH_BF16X3 */
@@ -154,14 +132,6 @@ int hpfg_conv_first_rows(int N, int H, int W);            /* rows of stat_partia
 /* nn.Conv2d k3/k1 (+ fused producer BN/LeakyReLU/Dropout/MaxPool/Upsample/cat on load) + BN partial sums.
  * Also serves dgrad: a0 = dZ (mode DZ/PLAIN), wpk = wpk_dgrad. */
 int hpfg_conv_fwd(const HpfgConvArgs* args, void* stream);
-/* The SAME layer of two independent networks of identical geometry in ONE launch -- student and teacher of the Mean-Teacher step
- * (2017_03_NIPS_Mean-Teacher_ACDC.py:94-101: model(x), then ema_model(x) under no_grad), the two students of CPS.  Every result is bit-identical
- * to two separate launches (same tile -> workgroup mapping per network); what changes is that each launch carries twice the tiles instead of the
- * two networks' launches competing from two streams, and the step has half the forward launches.  bf16x3 math, forward convolutions only. */
-int hpfg_conv_fwd_pair(const HpfgConvArgs* a, const HpfgConvArgs* b, void* stream);
-int hpfg_conv3x3_first_fwd_pair(const HpfgFirstConvArgs* a, const HpfgFirstConvArgs* b, int N, int H, int W, int Cin, int Cout, void* stream);
-int hpfg_bn_fwd_finalize_pair(const HpfgBnFinalizeArgs* a, const HpfgBnFinalizeArgs* b, int nblk, double count, float momentum, float eps, int C,
-                              void* stream);
 int hpfg_conv_stat_blocks(int N, int H, int W);          /* rows written by the fp32 kernels / upper bound for workspace sizing */
 int hpfg_conv_stat_rows(const HpfgConvArgs* args);         /* rows hpfg_conv_fwd(args) writes (depends on args->math) */
 /* BatchNorm2d train-mode statistics -> table rows mean/rstd/scale/shift, running stats (momentum .1, unbiased var)
@@ -183,9 +153,6 @@ int hpfg_pack_weights_bump(const HpfgPackDesc* table_dev, const HpfgPackDesc* ta
 /* evaluate a virtual activation into memory (tests, projection-neck inputs): out [N,H,W,a0.C+a1.C] */
 int hpfg_act_materialize(const HpfgAct* a0, const HpfgAct* a1, int N, int H, int W, float* out, void* stream);
 /* the dropout keep-mask the loaders use, as bytes [n_elems] (tests feed it to the oracle) */
-/* planes[n,y,x, C/8 groups][hi 8 x bf16 | lo 8 x bf16] = split-bf16 form of the virtual activation [a0 | a1] (any source kinds, incl. the
- * max-pooled, concatenated + upsampled and DZ ones); C_total % 8 == 0.  See HPFG_ACT_PLANES. */
-int hpfg_act_to_planes(const HpfgAct* a0, const HpfgAct* a1 /* or NULL */, int N, int H, int W, void* planes, void* stream);
 int hpfg_dropout_mask(uint8_t* out, long n_elems, float p, uint32_t seed, const uint32_t* seed_dev, void* stream);
 
 /* ---- backward ------------------------------------------------------------------------------------------ */

@@ -268,77 +268,6 @@ def test_box_masks_device_equals_host():
             assert dev.shape == host.shape and np.array_equal(dev.cpu().numpy(), host.astype(np.float32))
 
 
-def _planes(a0, a1, N, H, W, Ct):
-    out = torch.empty(N, H, W, Ct, device=DEV)          # 4 bytes per channel: bf16 hi + bf16 lo
-    L.check(L.load().hpfg_act_to_planes(C.byref(a0), C.byref(a1) if a1 is not None else None, N, H, W, L.ptr(out), stream(DEV)), "planes")
-    a = L.Act()
-    a.z, a.mode, a.C, a.Hs, a.Ws, a.pstride = L.ptr(out), L.ACT_PLANES, Ct, H, W, Ct
-    return a, out
-
-
-@pytest.mark.parametrize("N,H,W,cin,cout,p", [(2, 28, 28, 64, 128, 0.2), (2, 14, 14, 128, 64, 0.0), (1, 56, 56, 64, 64, 0.3), (2, 12, 20, 96, 64, 0.0)])
-def test_planes_source_equals_the_on_load_chain(N, H, W, cin, cout, p):
-    """HPFG_ACT_PLANES: an activation (BN + LeakyReLU + Dropout of a raw tensor) or a dZ materialised once in split-bf16 form feeds the
-    bf16x3 conv / dgrad / wgrad kernels the same hi / lo words the on-load loaders compute -> bit-identical results."""
-    g = torch.Generator().manual_seed(H + cin)
-    zd = torch.randn(N, H, W, cin, generator=g).to(DEV)
-    tabd = _bn_table(cin, 7).to(DEV)
-    a = L.Act()
-    a.z, a.bn, a.mode, a.C, a.Hs, a.Ws, a.pstride, a.bn_stride = L.ptr(zd), L.ptr(tabd), L.ACT_BNACT, cin, H, W, cin, cin
-    a.drop_p, a.drop_seed = p, 4242
-    layer = AdHocConv(cin, cout, 9, DEV, seed=3, hw=(H, W))
-    ref, rpart = layer.conv(a, None, N, H, W, stats=True, math=L.MATH_BF16X3)
-    ap, keep_a = _planes(a, None, N, H, W, cin)
-    got, gpart = layer.conv(ap, None, N, H, W, stats=True, math=L.MATH_BF16X3)
-    assert torch.equal(got, ref) and torch.equal(gpart, rpart)
-    # the planes hold hi + lo == the fp32 activation to 2^-17
-    act = _materialize(a, None, N, H, W, cin)
-    words = keep_a.cpu().view(torch.int32).view(N, H, W, cin // 8, 8)
-    hi = torch.stack([(words[..., :4] << 16), (words[..., :4] & -65536)], -1).view(torch.float32).reshape(N, H, W, cin // 8, 8)
-    lo = torch.stack([(words[..., 4:] << 16), (words[..., 4:] & -65536)], -1).view(torch.float32).reshape(N, H, W, cin // 8, 8)
-    assert maxerr((hi + lo).reshape(N, H, W, cin), act) < 2e-5 * max(1.0, float(act.abs().max()))
-    # dgrad / wgrad from a DZ source and from its planes
-    zo = torch.randn(N, H, W, cout, generator=g).to(DEV)
-    dA = torch.randn(N, H, W, cout, generator=g).to(DEV)
-    tabo = _bn_table(cout, 11).to(DEV)
-    d = L.Act()
-    d.z, d.bn, d.aux, d.mode, d.C, d.Hs, d.Ws, d.pstride, d.aux_pstride, d.bn_stride = L.ptr(zo), L.ptr(tabo), L.ptr(dA), L.ACT_DZ, cout, H, W, cout, cout, cout
-    dp, keep_d = _planes(d, None, N, H, W, cout)
-    dx_ref, _ = layer.conv(d, None, N, H, W, dgrad=True, math=L.MATH_BF16X3)
-    dx, _ = layer.conv(dp, None, N, H, W, dgrad=True, math=L.MATH_BF16X3)
-    # (the two dZ evaluations may contract their multiply-adds differently: equal to an fp32 rounding of dZ, not bit for bit)
-    assert maxerr(dx.cpu(), dx_ref.cpu()) < 2e-6 * max(1.0, float(dx_ref.abs().max()))
-    dw_ref = layer.wgrad(a, None, d, N, H, W, math=L.MATH_BF16X3)
-    dw = layer.wgrad(ap, None, dp, N, H, W, math=L.MATH_BF16X3)
-    assert maxerr(dw.cpu(), dw_ref.cpu()) < 2e-6 * max(1.0, float(dw_ref.abs().max()))
-
-
-def test_planes_from_pooled_and_concatenated_sources():
-    """hpfg_act_to_planes over the fused sources of the deep layers: MaxPool2d(2) of an activated tensor and cat([skip, bilinear x2])."""
-    N, H, W, C_ = 2, 12, 16, 64
-    g = torch.Generator().manual_seed(5)
-    zd = torch.randn(N, 2 * H, 2 * W, C_, generator=g).to(DEV)
-    tabd = _bn_table(C_, 5).to(DEV)
-    a = L.Act()
-    a.z, a.bn, a.mode, a.C, a.Hs, a.Ws, a.pstride, a.bn_stride = L.ptr(zd), L.ptr(tabd), L.ACT_BNACT_POOL, C_, 2 * H, 2 * W, C_, C_
-    layer = AdHocConv(C_, 64, 9, DEV, seed=1, hw=(H, W))
-    ref, _ = layer.conv(a, None, N, H, W, math=L.MATH_BF16X3)
-    pa, keep0 = _planes(a, None, N, H, W, C_)
-    got, _ = layer.conv(pa, None, N, H, W, math=L.MATH_BF16X3)
-    assert torch.equal(got, ref)
-    sk = torch.randn(N, H, W, C_, generator=g).to(DEV)
-    ud = torch.randn(N, H // 2, W // 2, C_, generator=g).to(DEV)
-    s = L.Act()
-    s.z, s.bn, s.mode, s.C, s.Hs, s.Ws, s.pstride, s.bn_stride = L.ptr(sk), L.ptr(tabd), L.ACT_BNACT, C_, H, W, C_, C_
-    b = L.Act()
-    b.z, b.mode, b.C, b.Hs, b.Ws, b.pstride = L.ptr(ud), L.ACT_UP2X, C_, H // 2, W // 2, C_
-    layer2 = AdHocConv(2 * C_, 64, 9, DEV, seed=2, hw=(H, W))
-    ref, _ = layer2.conv(s, b, N, H, W, math=L.MATH_BF16X3)
-    pl, keep = _planes(s, b, N, H, W, 2 * C_)
-    got, _ = layer2.conv(pl, None, N, H, W, math=L.MATH_BF16X3)
-    assert maxerr(got.cpu(), ref.cpu()) < 1e-5 * max(1.0, float(ref.abs().max()))      # the concat kernel blends the bilinear taps from an LDS patch: same values, other rounding order
-
-
 def test_sgd_ema_step_equals_the_two_launches_bitwise():
     """hpfg_sgd_ema_step == hpfg_sgd_step followed by hpfg_ema_update (full buffer and a leading slice), bit for bit."""
     from hpfg_amd import _lib as L
