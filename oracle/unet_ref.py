@@ -26,6 +26,8 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn.functional as F
 
+from . import bf16x3_ref
+
 WIDTHS = (16, 32, 64, 128, 256)
 ENC_DROPOUT = (0.05, 0.1, 0.2, 0.3, 0.5)
 BN_EPS = 1e-5
@@ -131,7 +133,7 @@ def draw_dropout_masks(n: int, h: int, w: int) -> List[torch.Tensor]:
 
 
 def _conv_bn_act(x, st, conv, bn, train, track):
-    z = F.conv2d(x, st[f"{conv}.weight"], st[f"{conv}.bias"], padding=1)
+    z = bf16x3_ref.conv2d(x, st[f"{conv}.weight"], st[f"{conv}.bias"], padding=1, first_layer=conv == "encoder.in_conv.conv_conv.0")
     if train:
         rm = st[f"{bn}.running_mean"] if track else None
         rv = st[f"{bn}.running_var"] if track else None
@@ -172,13 +174,13 @@ def unet_forward(st, x, train: bool = True, drop_masks: Optional[List[Optional[t
         feats.append(h)
     h = feats[4]
     for k in range(1, 5):
-        u = F.conv2d(h, st[f"decoder.up{k}.conv1x1.weight"], st[f"decoder.up{k}.conv1x1.bias"])
+        u = bf16x3_ref.conv2d(h, st[f"decoder.up{k}.conv1x1.weight"], st[f"decoder.up{k}.conv1x1.bias"])
         if taps is not None:
             taps[f"decoder.up{k}.conv1x1"] = u
         u = F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=True)
         h = torch.cat([feats[4 - k], u], dim=1)
         h = _block(h, st, dec_block_prefix(k), train, track_running, None, 0.0, taps)
-    logits = F.conv2d(h, st["decoder.out_conv.weight"], st["decoder.out_conv.bias"], padding=1)
+    logits = bf16x3_ref.conv2d(h, st["decoder.out_conv.weight"], st["decoder.out_conv.bias"], padding=1)
     if not plus:
         return logits
     return logits, projection_neck(st, "dense_projection_high", feats[4]), projection_neck(st, "dense_projection_head", logits)

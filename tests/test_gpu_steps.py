@@ -26,17 +26,18 @@ _DRIFT = {}
 
 def logit_tol(math, trace=None, replay=None, keys=(), **kw):
     """Bound on the final logits of a trace.  Exact-fp32 products ("f32"): 1e-3, flat.  Split-bf16 products ("bf16x3", the default
-    math mode): 1e-3 plus FIVE times the drift the CPU oracle itself shows on this trace when its conv weights are perturbed by a relative
-    1e-6 (tests/trace_replay.py: the committed control run; the tiny fixtures amplify such a perturbation up to ~1000x through
-    few-sample BatchNorm and 2-3 SGD steps, e.g. 1.25e-3 on the Mean-Teacher trace and 7e-6 on the ICT one).  Five: the same factor as
-    the 25-iteration test (tests/test_gpu_train_parity.py); the split-bf16 product error, 2^-17 = 7.6e-6 relative, is 7.6x the control's
-    perturbation (measured ratios error / drift on the traces: 1.2 ... 4.9).  The control is run lazily, once per trace."""
+    math mode): 1e-3 plus TWICE what the error model itself does to this trace -- the CPU oracle re-run with emulated split-bf16
+    convolutions (oracle/bf16x3_ref.py: the device's hi / lo operands and its three partial products; tests/trace_replay.py::
+    emulation_drift) against the nominal fp32 oracle.  On the reference-module traces at BASELINE-like sizes (tests/test_gpu_parity_r3.py)
+    that distance is < 1e-4 and the bound there is the flat 1e-3; the 32..64-pixel fixtures used here put as few as 16 samples into a
+    BatchNorm channel and amplify ANY rounding difference through 2-3 optimizer steps, which this control measures instead of assuming.
+    The control is run lazily, once per trace."""
     if math == "f32" or trace is None:
         return TOL
     if trace not in _DRIFT:
         d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"trace_{trace}.npz"))
-        _DRIFT[trace] = R.control_drift(replay, d, list(keys), **kw)
-    return TOL + 5.0 * _DRIFT[trace]
+        _DRIFT[trace] = R.emulation_drift(replay, d, list(keys), **kw)[0]
+    return TOL + 2.0 * _DRIFT[trace]
 
 
 def _masks(d, key, n, hw):

@@ -9,7 +9,7 @@ from hpfg_amd import engine as E
 from hpfg_amd.model import UNet
 from hpfg_amd.train import MeanTeacherStep
 from hpfg_amd.utils import AttrDict
-from oracle import laws_ref, losses_ref, steps_ref, unet_ref
+from oracle import bf16x3_ref, laws_ref, losses_ref, steps_ref, unet_ref
 from oracle.make_golden import synth_batch
 from tests.helpers import maxerr
 
@@ -35,28 +35,35 @@ def _batch(k):
     return xl, yl, xu, unet_ref.draw_dropout_masks(NL + NU, HW, HW), unet_ref.draw_dropout_masks(NL + NU, HW, HW)
 
 
+def _train_oracle(mode):
+    """ITERS Mean-Teacher iterations of the CPU oracle in one arithmetic mode of oracle/bf16x3_ref.py; returns (losses, student, teacher)."""
+    st = unet_ref.init_state(1337, 1, 4)
+    ema_st, bufs, losses = unet_ref.clone_state(st), {}, []
+    with bf16x3_ref.math_mode(mode):
+        for k in range(1, ITERS + 1):
+            xl, yl, xu, ms, mt = _batch(k)
+            lr, al = laws_ref.medical_lr(k, 0.01, 30000), laws_ref.ema_alpha(k, 0.99)
+            losses.append(steps_ref.mean_teacher_step(st, ema_st, bufs, xl, yl.long(), xu, lr, CONS_W, al, 0.9, 1e-4, ms, mt)["loss"])
+    return np.array(losses), st, ema_st
+
+
 @pytest.fixture(scope="module")
 def oracle_run():
-    """The CPU oracle trained for ITERS iterations, plus the control run from weights one rounding away; shared by both math modes."""
-    st = unet_ref.init_state(1337, 1, 4)
-    ema_st, bufs = unet_ref.clone_state(st), {}
-    ctl = unet_ref.clone_state(st)
-    for n_ in ctl:
-        if n_.endswith(".weight") and ctl[n_].dim() == 4:
-            ctl[n_] = (ctl[n_].double() * (1 + 1e-6)).float()
-    ctl_ema, ctl_bufs = unet_ref.clone_state(ctl), {}
-    losses = []
-    for k in range(1, ITERS + 1):
-        xl, yl, xu, ms, mt = _batch(k)
-        lr, al = laws_ref.medical_lr(k, 0.01, 30000), laws_ref.ema_alpha(k, 0.99)
-        losses.append(steps_ref.mean_teacher_step(st, ema_st, bufs, xl, yl.long(), xu, lr, CONS_W, al, 0.9, 1e-4, ms, mt)["loss"])
-        steps_ref.mean_teacher_step(ctl, ctl_ema, ctl_bufs, xl, yl.long(), xu, lr, CONS_W, al, 0.9, 1e-4, ms, mt)
+    """The CPU oracle trained for ITERS iterations (the reference run), plus the two CONTROL runs that bound the eval logits:
+      * "f64acc": the same fp32 products accumulated in fp64 -- the oracle up to summation-order noise, which is all that separates a correct
+        exact-fp32 kernel from it; 25 SGD steps on 8 images of 64 x 64 amplify that noise far beyond 1e-3 on the logits;
+      * "bf16x3": the oracle with the device's split-bf16 products (its error model) -- what the default math mode is allowed to differ by.
+    A math mode's eval logits must stay within 1e-3 + 2x its control's distance from the reference run."""
+    losses, st, ema_st = _train_oracle("f32")
     xe, ye = synth_batch(777, 8, HW, HW)
-    out = {"losses": np.array(losses), "xe": xe, "ye": ye}
+    out = {"losses": losses, "xe": xe, "ye": ye}
     with torch.no_grad():
-        for who, a, b in (("student", st, ctl), ("teacher", ema_st, ctl_ema)):
-            out[who] = unet_ref.unet_forward(a, xe, False)
-            out[who + "_drift"] = maxerr(unet_ref.unet_forward(b, xe, False), out[who])
+        out["student"], out["teacher"] = unet_ref.unet_forward(st, xe, False), unet_ref.unet_forward(ema_st, xe, False)
+    for math, mode in (("f32", "f64acc"), ("bf16x3", "bf16x3")):
+        _, a, b = _train_oracle(mode)
+        with torch.no_grad():
+            out[f"student_ctl_{math}"] = maxerr(unet_ref.unet_forward(a, xe, False), out["student"])
+            out[f"teacher_ctl_{math}"] = maxerr(unet_ref.unet_forward(b, xe, False), out["teacher"])
     return out
 
 
@@ -88,8 +95,8 @@ def test_mean_teacher_25_iterations_then_dice(oracle_run, math):
     for net, who in ((m, "student"), (ema, "teacher")):
         with torch.no_grad():
             got = net(xe.to(DEV)).cpu()
-        ref, drift = oracle_run[who], oracle_run[who + "_drift"]
-        assert maxerr(got, ref) < 5 * drift + 1e-3, (who, maxerr(got, ref), drift)
+        ref, ctl = oracle_run[who], oracle_run[f"{who}_ctl_{math}"]
+        assert maxerr(got, ref) < 1e-3 + 2.0 * ctl, (who, maxerr(got, ref), ctl)
         d_got = losses_ref.mean_foreground_dice(got.argmax(1).numpy(), ye.numpy(), 4)
         d_ref = losses_ref.mean_foreground_dice(ref.argmax(1).numpy(), ye.numpy(), 4)
         assert abs(d_got - d_ref) < 1e-3, (who, d_got, d_ref)

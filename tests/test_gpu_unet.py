@@ -8,7 +8,7 @@ import torch
 from hpfg_amd.datasets.synthetic import synth_batch
 from hpfg_amd.model import UNet, UNet_Plus, reset_dropout_streams
 from hpfg_amd.utils import Med_Sup_Loss
-from oracle import losses_ref, steps_ref, unet_ref
+from oracle import bf16x3_ref, losses_ref, steps_ref, unet_ref
 from tests.helpers import engine_masks, maxerr, nchw, state_from_module
 
 pytestmark = pytest.mark.gpu
@@ -94,23 +94,45 @@ def test_backward_all_parameter_gradients(n, hw, in_ch, ncls, seed, math):
     rl = losses_ref.med_sup_loss(ro, lab.long())
     rg = steps_ref._grads(rl, st, names)
     assert abs(float(loss) - float(rl)) < 1e-4
-    # Discrete events (a LeakyReLU sign or a max-pool arg-max sitting on a tie) can flip under a 1e-6 (fp32 summation order) or 1e-5
-    # (split-bf16) perturbation of the forward pass; one flip moves one gradient path by a few percent of a tensor's largest
-    # element.  So: every tensor must agree in the relative L2 norm, and the MEDIAN tensor must agree tightly (a systematic error
-    # would move all of them).
-    errs = {}
+    # Discrete events (a LeakyReLU sign or a max-pool arg-max sitting on a tie) can flip under a 1e-7 (fp32 summation order) or 1e-5
+    # (split-bf16 re-quantisation) perturbation of the forward pass; one flip moves one gradient path by a few percent of a tensor's
+    # largest element.  How often that happens on THIS input is measured, not assumed -- two CPU control runs of the oracle
+    # (oracle/bf16x3_ref.py):
+    #   noise[k]  what summation order alone does to gradient k in this math mode: the mode's products accumulated in fp64 vs in fp32;
+    #   model[k]  (bf16x3 only) what the split-bf16 products do to it: emulated device arithmetic vs the fp32 oracle.
+    # Every tensor must be within 1e-3 + 2 x noise[k] of the oracle run in its own arithmetic, and within 1e-3 + 2 x model[k] of the fp32 oracle.
+    def run(mode):
+        st2 = unet_ref.clone_state(st)
+        for v in st2.values():
+            if v.is_floating_point():
+                v.requires_grad_(False)
+        nm = steps_ref._train_state(st2)
+        with bf16x3_ref.math_mode(mode):
+            o_ = unet_ref.unet_forward(st2, x, True, masks, track_running=False)
+            return steps_ref._grads(losses_ref.med_sup_loss(o_, lab.long()), st2, nm)
+
+    def rel(a, b_, k):
+        return float((a[k].double() - b_[k].double()).norm() / max(1e-4, float(b_[k].double().norm())))
+
+    got = {}
     for k, p in m.named_parameters():
         assert p.grad is not None, k
-        errs[k] = float((p.grad.cpu().double() - rg[k].double()).norm() / max(1e-4, float(rg[k].double().norm())))
+        got[k] = p.grad.cpu()
+    own = rg if math == "f32" else run("bf16x3")
+    acc64 = run("f64acc" if math == "f32" else "bf16x3_f64acc")
+    bad = {}
+    for k in got:
+        noise = rel(acc64, own, k)
+        e_own = rel(got, own, k)
+        if not e_own < 1e-3 + 2.0 * noise:
+            bad[k] = ("vs own arithmetic", e_own, noise)
+        if math != "f32":
+            model, e_ref = rel(own, rg, k), rel(got, rg, k)
+            if not e_ref < 1e-3 + 2.0 * model:
+                bad[k] = ("vs fp32 oracle", e_ref, model)
     # (the per-kernel tests in test_gpu_kernels.py pin dgrad / wgrad / BN-backward / pool / upsample element-wise at 2e-4..5e-4;
-    #  this test guards the COMPOSITION: a routing or scaling mistake shows up as an O(1) error, a flip as O(1e-2))
-    # exact-fp32 products leave only summation-order noise (a flip needs a pre-activation within ~1e-6 of zero); the split-bf16 bounds
-    # allow for a handful of flips per tensor
-    tol, med_tol = (5e-3, 2e-3) if math == "f32" else (5e-2, 2.5e-2)
-    med = float(np.median([v for k, v in errs.items() if float(rg[k].abs().max()) > 1e-6]))
-    assert med < med_tol, f"median relative L2 gradient error {med}"
-    bad = {k: v for k, v in errs.items() if not v < tol}
-    assert not bad, f"relative gradient errors too large: {bad}"
+    #  this test guards the COMPOSITION: a routing or scaling mistake shows up as an O(1) error)
+    assert not bad, f"relative gradient errors beyond the controls: {bad}"
 
 
 def _fixture_masks(d, n, hw, prefix="mask"):

@@ -232,3 +232,46 @@ def test_cps_and_hpfg_traces(golden_dir):
     d = np.load(f"{golden_dir}/trace_hpfg.npz")
     r = R.replay_hpfg(d)
     assert np.abs(r["losses"] - d["losses"]).max() < 1e-4
+
+
+# ---- round-3 fixtures: reference-module traces at BASELINE-like sizes (oracle/make_golden_r3.py) ---------------------------------
+def _r3(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+
+
+@pytest.mark.parametrize("name,replay,keys,ncol", [
+    ("trace_mt224.npz", "replay_mt224", ("student_logits_last", "teacher_logits_last"), 3),
+    ("trace_cps96.npz", "replay_cps96", ("logits1_last", "logits2_last"), 3),
+    ("trace_hpfg224.npz", "replay_hpfg224", ("logits1_last", "logits2_last", "t_logits_last"), 5),
+])
+def test_r3_trace_oracle_and_error_model(name, replay, keys, ncol):
+    """(a) the fp32 oracle reproduces the reference's trace; (b) the SAME oracle with emulated split-bf16 convolutions (the device's
+    error model, oracle/bf16x3_ref.py) stays inside the flat 1e-3 of BASELINE.json on losses and logits at these sizes."""
+    from oracle import bf16x3_ref
+    from tests import trace_replay as R
+    d = _r3(name)
+    fn = getattr(R, replay)
+    nom = fn(d)
+    assert np.abs(nom["losses"][:, :ncol] - d["losses"][:, :ncol]).max() < 1e-4
+    for k in keys:
+        assert R.sub_err(nom[k], d, k) < 5e-4, k
+    with bf16x3_ref.math_mode("bf16x3"):
+        emu = fn(d)
+    assert np.abs(emu["losses"][:, :ncol] - d["losses"][:, :ncol]).max() < 1e-3
+    for k in keys:
+        assert R.sub_err(emu[k], d, k) < 1e-3, (k, R.sub_err(emu[k], d, k))
+
+
+def test_r3_gradients_oracle_vs_reference():
+    from tests import trace_replay as R
+    d = _r3("grads224.npz")
+    r = R.replay_grads224(d)
+    assert abs(r["loss"] - float(d["loss"])) < 1e-6
+    assert R.sub_err(r["logits"], d, "logits") < 2e-5
+    for k, g in r["grads"].items():
+        nrm = float(d[f"g:{k}:norm"])
+        flat = g.reshape(-1)
+        smp = flat[:: max(1, flat.numel() // 64)][:64].numpy()
+        assert np.abs(smp - d[f"g:{k}:sample"]).max() <= 2e-4 * nrm + 2e-6, k      # (+2e-6: biases in front of a train-mode BatchNorm carry rounding noise only)
+        assert abs(float(g.double().norm()) - nrm) <= 2e-4 * nrm + 2e-6, k

@@ -185,3 +185,137 @@ def control_drift(replay, d, keys, **kw):
         for k in keys:
             drift = max(drift, float((got[k] - nom[k]).abs().max()))
     return drift
+
+
+# ---- round-3 fixtures (oracle/make_golden_r3.py): BASELINE-like sizes, inputs and dropout masks regenerated from seeds -------------
+def _synth(seed, n, hw, in_ch, ncls, cell, want_sum, what):
+    from hpfg_amd.datasets.synthetic import synth_batch
+    x, lab = synth_batch(int(seed), int(n), int(hw), int(hw), in_ch, ncls, cell)
+    assert abs(float(x.double().sum()) - float(want_sum)) < 1e-6, f"synthetic input stream differs ({what})"
+    return x, lab
+
+
+def _masks_from_seed(seed, shapes, want_sums):
+    """Dropout keep-masks of one iteration: `shapes` = [(n, hw), ...] forwards in the reference's order, drawn from one seeded stream."""
+    torch.manual_seed(int(seed))
+    out = [unet_ref.draw_dropout_masks(n, hw, hw) for n, hw in shapes]
+    got = [float(m.sum()) for ms in out for m in ms]
+    assert got == [float(v) for v in want_sums], "torch CPU generator stream differs from the fixture's"
+    return out
+
+
+def mt224_inputs(d):
+    nl, nu, hw, first, iters, sl, su, sm = [int(v) for v in d["meta"]]
+    xl, yl = _synth(sl, nl, hw, 1, 4, 32, d["xl_sum"], "xl")
+    xu, _ = _synth(su, nu, hw, 1, 4, 32, d["xu_sum"], "xu")
+    assert int(yl.long().sum()) == int(d["yl_sum"])
+    masks = [_masks_from_seed(sm + j, [(nl + nu, hw)] * 2, d["mask_sums"][j]) for j in range(iters)]
+    return xl, yl, xu, masks, first
+
+
+def replay_mt224(d, seed=None):
+    xl, yl, xu, masks, first = mt224_inputs(d)
+    st = perturb(unet_ref.init_state(1337, 1, 4), seed)
+    ema, bufs = unet_ref.clone_state(st), {}
+    rows = []
+    for j, (ms, mt) in enumerate(masks):
+        cur = first + j
+        r = steps_ref.mean_teacher_step(st, ema, bufs, xl, yl.long(), xu, laws_ref.medical_lr(cur, 0.01, 30000), float(d["cons_w"]),
+                                        laws_ref.ema_alpha(cur, 0.99), 0.9, 1e-4, ms, mt)
+        rows.append([r["loss"], r["sup"], r["cons"]])
+    return {"losses": np.array(rows), "student_logits_last": r["logits"], "teacher_logits_last": r["t_logits"]}
+
+
+def cps96_inputs(d):
+    nl, nu, hw, first, iters, sl, su, sm = [int(v) for v in d["meta"]]
+    xl, yl = _synth(sl, nl, hw, 3, 2, 12, d["xl_sum"], "xl")
+    xu, _ = _synth(su, nu, hw, 3, 2, 12, d["xu_sum"], "xu")
+    masks = [_masks_from_seed(sm + j, [(nl + nu, hw)] * 2, d["mask_sums"][j]) for j in range(iters)]
+    return xl, yl, xu, masks, first
+
+
+def replay_cps96(d, seed=None):
+    xl, yl, xu, masks, first = cps96_inputs(d)
+    torch.manual_seed(1337)
+    sa, sb = unet_ref.init_state(None, 3, 2), unet_ref.init_state(None, 3, 2)
+    perturb(sa, seed)
+    perturb(sb, None if seed is None else seed + 10)
+    ba, bb, rows = {}, {}, []
+    for j, (m1, m2) in enumerate(masks):
+        lr = laws_ref.medical_lr(first + j, 0.01, 30000)
+        cw = 0.1 * laws_ref.sigmoid_rampup((first + j) // 150, 200.0)
+        r = steps_ref.cps_step(sa, sb, ba, bb, xl, yl.long(), xu, lr, lr, cw, 0.9, 1e-4, m1, m2)
+        rows.append([r["loss"], r["sup"], r["semi"]])
+    return {"losses": np.array(rows), "logits1_last": r["logits1"], "logits2_last": r["logits2"]}
+
+
+def hpfg224_inputs(d):
+    from hpfg_amd.utils import BoxMaskGenerator
+    nl, nu, hw, sl, sl1, su, sm, srng = [int(v) for v in d["meta"]]
+    xl, yl = _synth(sl, nl, hw, 1, 4, 32, d["xl_sum"], "xl")
+    xl1, yl1 = _synth(sl1, nl, hw, 1, 4, 32, d["xl1_sum"], "xl1")
+    xu, _ = _synth(su, nu, hw, 1, 4, 32, d["xu_sum"], "xu")
+    gen = BoxMaskGenerator(prop_range=(0.25, 0.5), n_boxes=4, random_aspect_ratio=True, prop_by_area=True, within_bounds=True, invert=True)
+    rng = np.random.RandomState(srng)
+    cms = [torch.tensor(gen.generate_params(nu, (hw, hw), rng=rng), dtype=torch.float) for _ in d["cur_itrs"]]
+    assert [float(c.sum()) for c in cms] == [float(v) for v in d["cutmix_sums"]], "CutMix mask stream differs from the fixture's"
+    masks = [_masks_from_seed(sm + j, [(nl + nu, hw)] * 3, d["mask_sums"][j]) for j in range(len(d["cur_itrs"]))]
+    return xl, yl, xl1, yl1, xu, cms, masks
+
+
+def replay_hpfg224(d, seed=None):
+    xl, yl, xl1, yl1, xu, cms, masks = hpfg224_inputs(d)
+    torch.manual_seed(1)
+    sa, sb = unet_ref.init_state(None, 1, 4, True), unet_ref.init_state(None, 1, 4, True)
+    perturb(sa, seed)
+    perturb(sb, None if seed is None else seed + 10)
+    se, ba, bb = unet_ref.clone_state(sb), {}, {}
+    rep = xu.shape[0] // xl.shape[0]
+    xl1r, yl1r = xl1.repeat(rep, 1, 1, 1), yl1.long().repeat(rep, 1, 1)
+    rows = []
+    for j, cur in enumerate(d["cur_itrs"]):
+        lr = laws_ref.medical_lr(int(cur), 0.01, 30000)
+        ma, mb, mt = masks[j]
+        r = steps_ref.hpfg_step(sa, sb, se, ba, bb, xl, yl.long(), xl1r, yl1r, xu, cms[j], int(cur), lr, lr, 0.1, 200.0, 0.99, 0.9, 5e-4, ma, mb, mt)
+        rows.append([r["loss"], r["sup"], r["semi"], r["pseudo_sup"], r["contrast"]])
+    return {"losses": np.array(rows), "logits1_last": r["logits1"], "logits2_last": r["logits2"], "t_logits_last": r["t_logits"]}
+
+
+def grads224_inputs(d):
+    n, hw, sx, sm = [int(v) for v in d["meta"]]
+    x, lab = _synth(sx, n, hw, 1, 4, 32, d["x_sum"], "x")
+    assert int(lab.long().sum()) == int(d["lab_sum"])
+    (masks,) = _masks_from_seed(sm, [(n, hw)], d["mask_sums"])
+    return x, lab, masks
+
+
+def replay_grads224(d):
+    from oracle import losses_ref
+    x, lab, masks = grads224_inputs(d)
+    st = unet_ref.init_state(1, 1, 4)
+    names = steps_ref._train_state(st)
+    o = unet_ref.unet_forward(st, x, True, masks)
+    loss = losses_ref.med_sup_loss(o, lab.long())
+    g = steps_ref._grads(loss, st, names)
+    return {"loss": float(loss.detach()), "logits": o.detach(), "grads": g}
+
+
+def sub_err(got: torch.Tensor, d, key: str) -> float:
+    """max |got - fixture| over the stored sub-sample (every 8th pixel) of a logits tensor, and its checksums per element."""
+    ref = torch.from_numpy(d[f"{key}_sub"])
+    e = float((got[:, :, ::8, ::8].double() - ref.double()).abs().max())
+    n = got.numel()
+    e_sum = abs(float(got.double().sum()) - float(d[f"{key}_sum"])) / n
+    e_abs = abs(float(got.double().abs().sum()) - float(d[f"{key}_abs"])) / n
+    return max(e, e_sum, e_abs)
+
+
+def emulation_drift(replay, d, keys, **kw):
+    """The error model's own effect on a trace: |oracle with emulated split-bf16 convolutions - nominal fp32 oracle| on the trace's final
+    tensors (oracle/bf16x3_ref.py).  This is the committed control of the bf16x3 tolerances: it perturbs every product exactly as the
+    device arithmetic does (same hi / lo operands, same three partial products), not by a hand-picked epsilon."""
+    from oracle import bf16x3_ref
+    nom = replay(d, **kw)
+    with bf16x3_ref.math_mode("bf16x3"):
+        emu = replay(d, **kw)
+    return max(float((emu[k] - nom[k]).abs().max()) for k in keys), emu
