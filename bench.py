@@ -1,43 +1,70 @@
 #!/usr/bin/env python
-"""Headline benchmark: labeled+unlabeled images/sec/node of the Mean-Teacher U-Net step (BASELINE.json configs[1]):
-U-Net(1->4 classes) at 224x224, 8 labelled + 8 unlabelled images per GPU, student forward+backward, train-mode teacher forward,
-CE+Dice+MSE loss, SGD, EMA -- every step of 2017_03_NIPS_Mean-Teacher_ACDC.py:82-113 inside the timed region, synthetic data.
+"""Headline benchmark: labeled+unlabeled images/sec/node of one step of the reference's drivers on the MI355X hot path, synthetic data.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-graph] [--no-cpu-baseline] [--math bf16x3|f32] [--sync-bn]
+    python bench.py [--workload mt|sup|hpfg|cps|ctct] [--gpus N] [--steps K] [--warmup W] [--math bf16x3|f32] [--no-graph]
+                    [--sync-bn] [--overlap] [--no-cpu-baseline] [--no-f32-line] [--no-probe]
 
-`python bench.py --gpus N` with N > 1 and no launcher environment starts `python -m torch.distributed.run --nproc-per-node N`
-on this file as a CHILD process (before anything here touches the GPU) and relays its JSON line; under a launcher (RANK /
-WORLD_SIZE set) it is one rank of the job.  One rank per GPU over RCCL, weak scaling (per-GPU batch fixed).
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (the longest launch of the step -- the fused backward kernel of
-decoder.up4's first conv; its forward conv under `forward_conv_of_the_same_layer` -- timed with HIP events both alone and inside eager steps), `step_roofline`, `f32_math` (the same step with exact-fp32 MFMA products, N=1 only) and
-`cpu_baseline` (the CPU oracle timed on this host's cores on a bounded sample).
+Workloads = BASELINE.json configs (the default, `mt`, is configs[1], the one the metric is quoted on):
+  sup   configs[0]  sup_ACDC.py:83-93                          U-Net 1->4, 8 x 224^2, SGD + cosine schedule
+  mt    configs[1]  2017_03_NIPS_Mean-Teacher_ACDC.py:82-113   U-Net 1->4, 8 + 8 x 224^2: student fwd+bwd, train-mode teacher fwd, CE/Dice/MSE, SGD, EMA
+  hpfg  configs[2]  main.py:125-212                            U-Net+ x 2 + EMA teacher, 16 + 16 x 224^2 per GPU, CutMix, Dense_Loss
+  cps   configs[3]  2021_06_CVPR_CPS_ACDC.py:95-120            U-Net 3->2 x 2, 32 + 32 x 96^2
+  ctct  configs[4]  2021_12_MIDL_CTCT_ACDC.py:117-151          U-Net + SegFormer-B0, 8 + 24 x 224^2
+Every statement of the loop body is inside the timed region; inputs are resident in HBM; one hipGraph per step at N = 1.
+
+`python bench.py --gpus N` with N > 1 and no launcher environment starts `python -m torch.distributed.run --nproc-per-node N` on this
+file as a CHILD process (before anything here touches the GPU) and relays its JSON line; under a launcher (RANK / WORLD_SIZE set) it is
+one rank of the job.  One rank per GPU over RCCL, weak scaling (per-GPU batch fixed).
+
+Prints ONE JSON line (rank 0): the driver's contract plus
+  step_roofline   the whole step against its algorithmic bytes / FLOPs,
+  roofline        the kernel family with the largest share of the step's kernel time, measured live: every conv / dgrad / wgrad /
+                  BatchNorm launch of the U-Net engines is bracketed by device time stamps (one-wave kernels storing s_memrealtime) inside
+                  a second captured hipGraph of the same step -- no host events, no eager steps -- and the families' times are summed per
+                  step; `longest_launch` is kept beside it,
+  f32_math        the same step with exact-fp32 MFMA products (N = 1, `mt` only),
+  cpu_baseline    the CPU oracle of the same step on this host's cores (bounded sample; all physical cores).
 """
 import argparse
+import faulthandler
 import json
 import os
 import subprocess
 import sys
 import time
 
-import faulthandler
-
-faulthandler.enable()      # a fault inside the HIP runtime still leaves the Python stack on stderr
+faulthandler.enable()      # a fault inside the HIP runtime still leaves the Python stacks on stderr
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic traffic / flop constants (derived from model/unet.py:61-117 at 224x224, 1ch -> 4 classes)
-IN_MB, OUT_MB, W_MB, LOSS_MB = 32.21, 26.79, 7.24, 2.5
-GFLOP_FWD_IMG = 4.517
-GFLOP_TRAIN_IMG = 13.54
+# ---- algorithmic traffic / flop constants (derived from model/unet.py:61-117) -----------------------------------
+# per image: IN = sum of conv-input bytes, OUT = sum of conv-output bytes (MB, fp32); W = parameters (MB); GF = forward GFLOP
+UNET = {224: dict(IN=32.21, OUT=26.79, GF=4.517), 96: dict(IN=5.99, OUT=4.85, GF=0.830)}
+W_UNET, W_PLUS = 7.24, 14.65
 DTYPE = {"bf16x3": "bf16x3 (fp32 storage; products as split-bf16 MFMA hi*hi+hi*lo+lo*hi, fp32 accumulate)",
          "f32": "f32 (fp32 storage, exact fp32-input MFMA)"}
+HBM_PEAK, MFMA_PEAK_TF = 8000.0, 2500.0      # GB/s; dense bf16 TFLOP/s (MI355X_MICROARCH.md)
 
 
-def algorithmic_bytes_mt(n_img):
-    train = n_img * (3 * IN_MB + 5 * OUT_MB) + 7 * W_MB
-    teacher = n_img * (IN_MB + OUT_MB) + W_MB
-    return (train + teacher + n_img * LOSS_MB) * 1e6
+def unet_bytes(size, n_train, n_nograd, n_loss, ncls, w_mb, trainable_nets=1, nograd_nets=0):
+    """train = N(3 IN + 5 OUT) + 7 W per trainable network, no-grad forward = N(IN + OUT) + W, loss = (12 C + 1) B / pixel / image."""
+    u = UNET[size]
+    loss_mb = (12 * ncls + 1) * size * size / 1e6
+    mb = trainable_nets * (n_train * (3 * u["IN"] + 5 * u["OUT"]) + 7 * w_mb) + nograd_nets * (n_nograd * (u["IN"] + u["OUT"]) + w_mb) + n_loss * loss_mb
+    return mb * 1e6
+
+
+def segformer_b0_bytes(n_img, size=224):
+    """Byte model of the SegFormer-B0 branch (no SURVEY figure exists): per transformer block and token the forward reads / writes about 26 C
+    floats (x, q, kv, attention out, projection + residual, fc1 4C, depthwise-GELU 4C + 4C, fc2 + residual), dims (32, 64, 160, 256) at
+    (H/4)^2 ... (H/32)^2 tokens, two blocks per stage; the head adds about 10 MB per image; training = 3 x forward; weights 3.7 M x 4 B x 7."""
+    dims, fwd = (32, 64, 160, 256), 0.0
+    for i, c in enumerate(dims):
+        tokens = (size // (4 << i)) ** 2
+        fwd += 2 * tokens * 26 * c * 4
+    fwd += 10e6
+    return n_img * 3 * fwd + 7 * 3.7e6 * 4
 
 
 def parse():
@@ -45,22 +72,19 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="mt", choices=["mt", "sup", "hpfg", "cps", "ctct"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-line", action="store_true", help="skip the secondary exact-fp32 measurement")
-    ap.add_argument("--workload", default="mt", choices=["mt"])
+    ap.add_argument("--no-probe", action="store_true", help="skip the per-kernel time stamps (roofline = step figures only)")
     ap.add_argument("--math", default=os.environ.get("HPFG_MATH", "bf16x3"), choices=["bf16x3", "f32"])
-    ap.add_argument("--lab", type=int, default=8)
-    ap.add_argument("--unlab", type=int, default=8)
-    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--lab", type=int, default=None, help="labelled images per GPU (default: the workload's BASELINE figure)")
+    ap.add_argument("--unlab", type=int, default=None)
     ap.add_argument("--force-sync", action="store_true", help="diagnostics: run the data-parallel code path (RCCL collectives) on one rank")
     ap.add_argument("--sync-bn", action="store_true", help="N > 1: all-reduce every BatchNorm statistic and the loss sums (R ranks == one process on the "
                     "global batch) instead of the default per-rank BatchNorm + averaged gradients (DDP semantics)")
-    ap.add_argument("--overlap", action="store_true",
-                    help="N > 1: bucketed gradient all-reduce overlapped with the encoder half of backward (a chain of three hipGraphs around two eager "
-                         "RCCL calls).  Default is ONE all-reduce between two hipGraphs: measured on one rank (nccl, this flag vs none) the chain costs "
-                         "130-250 us per step -- it cannot queue the decoder's weight gradients onto the side stream and pays two more graph "
-                         "launches -- which is more than the 7.26 MB all-reduce it would hide takes over xGMI")
+    ap.add_argument("--overlap", action="store_true", help="N > 1: bucketed gradient all-reduce overlapped with the encoder half of backward (a chain of "
+                    "hipGraphs around eager RCCL calls) instead of ONE all-reduce between two hipGraphs")
     ap.add_argument("--no-overlap", action="store_true", help="(the default; kept for older command lines)")
     return ap.parse_args()
 
@@ -78,29 +102,124 @@ def relaunch(a):
     raise SystemExit(r.returncode)
 
 
-def build_step(dev, a, math, dp):
-    from copy import deepcopy
-    from hpfg_amd.model import build_model
-    from hpfg_amd.train import MeanTeacherStep
-    from hpfg_amd.utils import loadyaml
-    import torch
-    args = loadyaml(os.path.join(ROOT, "config", "mean_teacher_unet_30k_224x224_ACDC.yaml"))
-    args.batch_size, args.unlabel_batch_size = a.lab, a.unlab
-    torch.manual_seed(args.seed)
-    model = build_model(args).to(dev)
-    model.math = math
-    ema = deepcopy(model)
-    for p in ema.parameters():
-        p.requires_grad = False
-    model.train()
-    ema.train()
-    return model, ema, MeanTeacherStep(model, ema, args, dp)
+# ---- workloads ----------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """One BASELINE config: models + step object + resident inputs + the algorithmic byte / flop figures of one step on one rank."""
+
+    def __init__(self, name, a, dev, math, dp, rank):
+        import numpy as np
+        import torch
+        from copy import deepcopy
+        from hpfg_amd.datasets.synthetic import synth_batch
+        from hpfg_amd.model import build_model
+        from hpfg_amd.train import CPSStep, CTCTStep, HPFGStep, MeanTeacherStep, SupervisedStep, batch_pair
+        from hpfg_amd.utils import loadyaml
+        self.name, self.dev = name, dev
+        cfg = {"mt": "mean_teacher_unet_30k_224x224_ACDC.yaml", "sup": "unet_30k_224x224_ACDC.yaml", "hpfg": "hpfg_unet_plus_30k_224x224_ACDC.yaml",
+               "cps": "cps_unet_30k_96x96_LIDC.yaml", "ctct": "ctct_unet_segformer_30k_224x224_ACDC.yaml"}[name]
+        args = loadyaml(os.path.join(ROOT, "config", cfg))
+        args.device = dev
+        lab0, unlab0 = {"mt": (8, 8), "sup": (8, 0), "hpfg": (16, 16), "cps": (32, 32), "ctct": (8, 24)}[name]
+        lab = lab0 if a.lab is None else a.lab
+        unlab = unlab0 if a.unlab is None else a.unlab
+        args.batch_size, args.unlabel_batch_size = lab, unlab
+        self.lab, self.unlab, self.n_img = lab, unlab, lab + unlab
+        torch.manual_seed(args.seed)
+
+        def mk(sub):
+            m = build_model(sub).to(dev)
+            if hasattr(m, "math"):
+                m.math = math
+            return m
+
+        def frozen(m):
+            e = deepcopy(m)
+            for p in e.parameters():
+                p.requires_grad = False
+            e.train()
+            return e
+
+        s1, s2 = 1234 + rank, 91234 + rank
+        if name == "sup":
+            self.size = 224
+            m = mk(args)
+            m.train()
+            self.models, self.step = [m], SupervisedStep(m, args, dp)
+            x, y = synth_batch(s1, lab, 224, 224, 1, 4, 32)
+            self.inputs = (x.to(dev), y.to(dev))
+            self.bytes = unet_bytes(224, lab, 0, lab, 4, W_UNET)
+            self.gflop = lab * 3 * UNET[224]["GF"]
+            self.desc = f"supervised_unet_224x224 (BASELINE configs[0]): U-Net 1ch->4cls, {lab} images per GPU, fwd+bwd + 0.5 CE + 0.5 Dice + SGD"
+        elif name == "mt":
+            self.size = 224
+            m = mk(args)
+            ema = frozen(m)
+            m.train()
+            self.models, self.step = [m, ema], MeanTeacherStep(m, ema, args, dp)
+            xl, yl = synth_batch(s1, lab, 224, 224, 1, 4, 32)
+            xu, _ = synth_batch(s2, unlab, 224, 224, 1, 4, 32)
+            xl, xu = batch_pair(xl.to(dev), xu.to(dev))      # back to back in HBM: the step's batch is a view, not a concat copy
+            self.inputs = (xl, yl.to(dev), xu)
+            n = self.n_img
+            self.bytes = unet_bytes(224, n, n, n, 4, W_UNET, 1, 1)
+            self.gflop = n * (3 * UNET[224]["GF"] + UNET[224]["GF"])
+            self.desc = (f"mean_teacher_unet_224x224 (BASELINE configs[1]): U-Net 1ch->4cls, {lab} labelled + {unlab} unlabelled per GPU, "
+                         "student fwd+bwd + train-mode teacher fwd + CE/Dice/MSE + SGD + EMA")
+        elif name == "hpfg":
+            self.size = 224
+            m1, m2 = mk(args.model1), mk(args.model2)
+            ema = frozen(m2)
+            m1.train(), m2.train()
+            st = HPFGStep(m1, m2, ema, args, dp)
+            self.models, self.step = [m1, m2, ema], st
+            xl, yl = synth_batch(s1, lab, 224, 224, 1, 4, 32)
+            xl1, yl1 = synth_batch(s1 + 7, lab, 224, 224, 1, 4, 32)
+            xu, _ = synth_batch(s2, unlab, 224, 224, 1, 4, 32)
+            rep = max(1, unlab // lab)
+            cm = st.make_cutmix_mask(unlab, (224, 224), rng=np.random.RandomState(1 + rank))
+            self.inputs = tuple(t.to(dev) for t in (xl, yl, xl1.repeat(rep, 1, 1, 1), yl1.repeat(rep, 1, 1), xu, cm))
+            n = self.n_img
+            self.bytes = unet_bytes(224, n, n, 2 * n, 4, W_PLUS, 2, 1)
+            self.gflop = n * (2 * 3 * UNET[224]["GF"] + UNET[224]["GF"]) + 1.0
+            self.desc = (f"hpfg_unet_plus_224x224 (BASELINE configs[2]): two U-Net+ students + EMA teacher, {lab} + {unlab} per GPU (every network sees "
+                         f"{n} images), CutMix pseudo-labels, Dense_Loss necks, SGD x 2, backbone EMA + teacher EMA")
+        elif name == "cps":
+            self.size = 96
+            m1, m2 = mk(args.model1), mk(args.model2)
+            m1.train(), m2.train()
+            self.models, self.step = [m1, m2], CPSStep(m1, m2, args, dp)
+            xl, yl = synth_batch(s1, lab, 96, 96, 3, 2, 12)
+            xu, _ = synth_batch(s2, unlab, 96, 96, 3, 2, 12)
+            xl, xu = batch_pair(xl.to(dev), xu.to(dev))
+            self.inputs = (xl, yl.to(dev), xu)
+            n = self.n_img
+            self.bytes = unet_bytes(96, n, 0, 2 * n, 2, W_UNET, 2, 0)
+            self.gflop = 2 * n * 3 * UNET[96]["GF"]
+            self.desc = f"cps_unet_96x96 (BASELINE configs[3]): twin U-Net 3ch->2cls cross pseudo supervision, {lab} + {unlab} per GPU, SGD x 2"
+        else:
+            self.size = 224
+            m1, m2 = mk(args.model1), mk(args.model2)
+            m1.train(), m2.train()
+            self.models, self.step = [m1, m2], CTCTStep(m1, m2, args, dp)
+            xl, yl = synth_batch(s1, lab, 224, 224, 1, 4, 32)
+            xu, _ = synth_batch(s2, unlab, 224, 224, 1, 4, 32)
+            xl, xu = batch_pair(xl.to(dev), xu.to(dev))
+            self.inputs = (xl, yl.to(dev), xu)
+            n = self.n_img
+            self.bytes = unet_bytes(224, n, 0, 2 * n, 4, W_UNET) + segformer_b0_bytes(n)
+            self.gflop = n * 3 * UNET[224]["GF"] + n * 3 * 1.6      # (SegFormer-B0 forward ~1.6 GFLOP at 224^2: approximate)
+            self.desc = (f"ctct_unet_segformer_224x224 (BASELINE configs[4]): U-Net + SegFormer-B0 cross teaching, {lab} + {unlab} per GPU, both networks "
+                         "fwd+bwd on all images, SGD + AdamW")
+
+    def unet_engines(self):
+        return [e for m in self.models for pool in getattr(m, "_engines", {}).values() for e in pool]
 
 
-def timed_run(step, inputs, a, dev, dp, use_graph, steps, warmup):
+def timed_run(wl, dp, use_graph, steps, warmup, dev):
     """W untimed + K timed steps bracketed by barrier + synchronize; returns (seconds, graph actually used, last iteration)."""
     import torch
     from hpfg_amd.train import GraphedStep
+    step, inputs = wl.step, wl.inputs
     runner, it = None, 0
     if use_graph:
         try:
@@ -136,6 +255,229 @@ def timed_run(step, inputs, a, dev, dp, use_graph, steps, warmup):
     return dt, use_graph, it
 
 
+# ---- per-kernel probe ------------------------------------------------------------------------------------------------------------------
+def layer_costs(eng, tag):
+    """(family, algorithmic bytes, flops) of one bracketed launch `tag` = "<pass>:<conv name>" of engine `eng`.
+    Bytes: the tensors the pass must move given what is stored: fwd = stored input + raw output + weights (a pooled
+    input is the full-resolution producer, a concat input the skip tensor + the quarter-resolution 1x1 output); dgrad = dA + z + dX;
+    wgrad = dA + z + stored input; fused backward = dA + z + stored input + dX.  FLOPs: 2 x taps x Cin x Cout per output pixel and pass."""
+    kind, name = tag.split(":", 1) if ":" in tag else (tag, "")
+    s = eng.specs.get(name)
+    if s is None or kind not in ("fwd", "dgrad", "wgrad", "fused_bwd"):
+        return {"bn_fin": "BatchNorm forward finalize", "bn_red": "BatchNorm backward reduction (+ max-pool backward)", "bn_bfin": "BatchNorm backward finalize",
+                "upbwd": "bilinear upsample backward", "slab_reduce": "weight-gradient slab reduction", "pack_weights": "weight packing",
+                "csum": "bias-gradient channel sums"}.get(kind, kind), 0.0, 0.0
+    N = eng.N
+    px = N * s.h * s.w
+    if name.startswith("decoder.up") and name.endswith("conv.conv_conv.0"):
+        x_b = px * (s.cin // 2) * 4 + px // 4 * (s.cin // 2) * 4           # skip + low-resolution 1x1 output
+    elif name.startswith("encoder.down") and name.endswith(".0"):
+        x_b = 4 * px * s.cin * 4                                           # the full-resolution producer behind MaxPool2d(2)
+    else:
+        x_b = px * s.cin * 4
+    o_b, w_b = px * s.cout * 4, s.taps * s.cin * s.cout * 4
+    fl = 2.0 * px * s.taps * s.cin * s.cout
+    if s.idx == 0:
+        cls = "first conv (1 / 3 input channels)"
+    elif s.taps == 1:
+        cls = "1x1 conv"
+    elif min(s.cin, s.cout) >= 32:
+        cls = "channel-rich 3x3 (>= 32 channels in and out)"
+    else:
+        cls = "thin 3x3 (< 32 channels in or out: the 224 x 224 / 112 x 112 layers and out_conv)"
+    if kind == "fwd":
+        return f"forward conv, {cls}", x_b + o_b + w_b, fl
+    if kind == "dgrad":
+        return f"input gradient (separate dgrad), {cls}", 2 * o_b + px * s.cin * 4 + w_b, fl
+    if kind == "wgrad":
+        return f"weight gradient (separate wgrad), {cls}", 2 * o_b + x_b, fl
+    dx = 0 if s.idx == 0 else px * s.cin * 4
+    return f"fused dgrad + wgrad, {cls}", 2 * o_b + x_b + dx + w_b, fl * (1 if s.idx == 0 else 2)
+
+
+def probe_families(wl, it, reps=6):
+    """Times of every bracketed launch of the step inside a captured hipGraph (see module docstring); returns (families, longest, calib_us)."""
+    import numpy as np
+    import torch
+    from hpfg_amd.engine import MarkLog
+    from hpfg_amd.train import GraphedStep
+    engines = wl.unet_engines()
+    if not engines:
+        return None
+    logs = {id(e): MarkLog(wl.dev) for e in engines}
+    for e in engines:
+        e.marks = logs[id(e)]
+
+    def reset():
+        for lg in logs.values():
+            lg.n, lg.spans = 0, []
+
+    try:
+        runner = GraphedStep(wl.step, list(wl.inputs), warmup=1, alias_inputs=True, before_capture=reset)
+        acc = {}
+        for r in range(reps):
+            runner.step(list(wl.inputs), it + 1 + r)
+            torch.cuda.synchronize(wl.dev)
+            if r < 2:
+                continue      # warm-up replays
+            for e in engines:
+                for i, (tag, us) in enumerate(logs[id(e)].read_us()):
+                    acc.setdefault((id(e), i, tag), []).append(us)
+    finally:
+        for e in engines:
+            e.marks = None
+    calib = float(np.median([np.mean(v) for (_, _, tag), v in acc.items() if tag == "calib"] or [0.0]))
+    eng_of = {id(e): e for e in engines}
+    fams, longest = {}, None
+    for (eid, _, tag), v in acc.items():
+        if tag == "calib":
+            continue
+        us = max(float(np.mean(v)) - calib, 0.0)
+        fam, b, fl = layer_costs(eng_of[eid], tag)
+        f = fams.setdefault(fam, dict(us=0.0, launches=0, bytes=0.0, flops=0.0))
+        f["us"] += us
+        f["launches"] += 1
+        f["bytes"] += b
+        f["flops"] += fl
+        if b > 0 and (longest is None or us > longest["us"]):
+            longest = dict(tag=tag, us=us, bytes=b, flops=fl, family=fam)
+    return fams, longest, calib
+
+
+def roofline_objects(wl, fams, longest, calib, math):
+    passes = 3.0 if math == "bf16x3" else 16.0      # bf16 MFMA-equivalents per product (exact-fp32 MFMA runs at 1/16 of the bf16 rate)
+    total = sum(f["us"] for f in fams.values())
+    conv = {k: f for k, f in fams.items() if f["bytes"] > 0}
+    name, top = max(conv.items(), key=lambda kv: kv[1]["us"])
+
+    def obj(label, us, b, fl, n=1):
+        gbps, tf = b / (us * 1e-6) / 1e9, fl * passes / (us * 1e-6) / 1e12
+        hbm_frac, mfma_frac = gbps / HBM_PEAK, tf / MFMA_PEAK_TF
+        bound = "hbm" if hbm_frac >= mfma_frac else "mfma"
+        return {"kernel": label, "bound": bound, "achieved": round(gbps if bound == "hbm" else tf, 1), "peak": HBM_PEAK if bound == "hbm" else MFMA_PEAK_TF,
+                "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(max(hbm_frac, mfma_frac), 4), "traffic": None,
+                "avg_launch_us": round(us / n, 2), "launches_per_step": n, "algorithmic_bytes_per_launch": int(b / n), "flops_per_launch": int(fl / n),
+                "hbm_frac": round(hbm_frac, 4), "mfma_frac": round(mfma_frac, 4)}
+    roof = obj(f"{name}: all {top['launches']} launches of the family in one step (every network of the step)", top["us"], top["bytes"], top["flops"],
+               top["launches"])
+    roof["share_of_bracketed_kernel_time"] = round(top["us"] / total, 4)
+    roof["timing"] = (f"device time stamps (s_memrealtime) around each launch inside a captured hipGraph of the step, minus the same bracket around nothing "
+                      f"({calib:.2f} us); bf16-MFMA passes per product: {passes:g}")
+    try:      # HBM bytes per launch of this family from the PMC passes committed under profiles/ (tools/family_traffic.py)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_family_traffic.json")))
+        if tj.get("workload") == wl.name and name in tj.get("families", {}):
+            roof["traffic"] = int(tj["families"][name]["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    roof["families"] = {k: {"us_per_step": round(f["us"], 1), "launches": f["launches"], "share": round(f["us"] / total, 4),
+                            **({"GBps": round(f["bytes"] / (f["us"] * 1e-6) / 1e9, 1), "TFLOPs_bf16_passes": round(f["flops"] * passes / (f["us"] * 1e-6) / 1e12, 1)}
+                               if f["bytes"] > 0 and f["us"] > 0 else {})}
+                        for k, f in sorted(fams.items(), key=lambda kv: -kv[1]["us"])}
+    if longest is not None:
+        roof["longest_launch"] = obj(f"{longest['tag']} ({longest['family']})", longest["us"], longest["bytes"], longest["flops"])
+    return roof
+
+
+# ---- CPU baseline ----------------------------------------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def physical_cores():
+    """(physical cores, logical CPUs) among the CPUs this process may run on (SMT siblings counted once)."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        return os.cpu_count() or 1, os.cpu_count() or 1
+    cores, cur = set(), {}
+
+    def flush():
+        if cur and int(cur.get("processor", -1)) in allowed:
+            cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [t.strip() for t in line.split(":", 1)]
+                cur[k] = v
+            else:
+                flush()
+                cur = {}
+        flush()
+    except OSError:
+        pass
+    return (len(cores) or len(allowed)), len(allowed)
+
+
+def cpu_baseline(name, lab, unlab, size):
+    """The CPU oracle (plain PyTorch restatement of the reference step, oracle/steps_ref.py) of the same workload on this host's cores,
+    SURVEY.md section 8(d): k = all physical cores, 1-3 warm-up and up to 10 timed steps within ~30 s, median."""
+    import numpy as np
+    import torch
+    from hpfg_amd.datasets.synthetic import synth_batch
+    from oracle import laws_ref, steps_ref, unet_ref
+    cores, avail = physical_cores()
+    torch.set_num_threads(cores)
+    lr = laws_ref.medical_lr(1, 0.01, 30000)
+    if name == "sup":
+        st, bufs = unet_ref.init_state(1, 1, 4), {}
+        x, y = synth_batch(1234, lab, size, size, 1, 4, 32)
+        fn = lambda k: steps_ref.supervised_step(st, bufs, x, y.long(), lr, 0.9, 5e-4)
+    elif name == "mt":
+        st = unet_ref.init_state(1337, 1, 4)
+        ema, bufs = unet_ref.clone_state(st), {}
+        xl, yl = synth_batch(1234, lab, size, size, 1, 4, 32)
+        xu, _ = synth_batch(91234, unlab, size, size, 1, 4, 32)
+        fn = lambda k: steps_ref.mean_teacher_step(st, ema, bufs, xl, yl.long(), xu, laws_ref.medical_lr(k, 0.01, 30000), 0.0, laws_ref.ema_alpha(k, 0.99))
+    elif name == "cps":
+        torch.manual_seed(1337)
+        sa, sb, ba, bb = unet_ref.init_state(None, 3, 2), unet_ref.init_state(None, 3, 2), {}, {}
+        xl, yl = synth_batch(1234, lab, size, size, 3, 2, 12)
+        xu, _ = synth_batch(91234, unlab, size, size, 3, 2, 12)
+        fn = lambda k: steps_ref.cps_step(sa, sb, ba, bb, xl, yl.long(), xu, lr, lr, 0.004)
+    elif name == "hpfg":
+        torch.manual_seed(1)
+        sa, sb = unet_ref.init_state(None, 1, 4, True), unet_ref.init_state(None, 1, 4, True)
+        se, ba, bb = unet_ref.clone_state(sb), {}, {}
+        xl, yl = synth_batch(1234, lab, size, size, 1, 4, 32)
+        xl1, yl1 = synth_batch(1241, lab, size, size, 1, 4, 32)
+        xu, _ = synth_batch(91234, unlab, size, size, 1, 4, 32)
+        rep = max(1, unlab // lab)
+        cm = torch.tensor(laws_ref.box_masks(unlab, (size, size), np.random.RandomState(1)), dtype=torch.float)
+        fn = lambda k: steps_ref.hpfg_step(sa, sb, se, ba, bb, xl, yl.long(), xl1.repeat(rep, 1, 1, 1), yl1.long().repeat(rep, 1, 1), xu, cm, 1000 + k, lr, lr,
+                                           0.1, 200.0, 0.99)
+    else:
+        from oracle import segformer_ref
+        s1, s2, b1, ad = unet_ref.init_state(1, 1, 4), segformer_ref.init_state(2, 1, 4), {}, {}
+        xl, yl = synth_batch(1234, lab, size, size, 1, 4, 32)
+        xu, _ = synth_batch(91234, unlab, size, size, 1, 4, 32)
+        fn = lambda k: steps_ref.ctct_step(s1, s2, b1, ad, xl, yl.long(), xu, 0.01, 8e-4, 0.004)
+    times, t_start, warm = [], time.perf_counter(), 0
+    for k in range(1, 14):
+        t0 = time.perf_counter()
+        fn(k)
+        dt = time.perf_counter() - t0
+        if k == 1 or (warm < 3 and time.perf_counter() - t_start < 8.0):
+            warm += 1          # (a 20-second step -- HPFG -- gets one warm-up, a 1-second step three)
+        else:
+            times.append(dt)
+        if times and time.perf_counter() - t_start > 30.0:
+            break
+    if not times:
+        times = [dt]
+    ts = sorted(times)
+    t = ts[len(ts) // 2]
+    return {"value": round((lab + unlab) / t, 2), "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(),
+            "affinity_cpus": avail, "sample": f"{warm} warm-up + {len(ts)} timed `{name}` steps of {lab}+{unlab} images at {size}x{size} (median), CPU oracle, "
+                                              f"torch CPU fp32, {cores} threads = all physical cores of this process's affinity mask"}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,7 +493,6 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from hpfg_amd import parallel
-    from hpfg_amd.datasets.synthetic import synth_batch
 
     dp = None
     if world > 1 or a.force_sync:
@@ -162,243 +503,63 @@ def main():
         dp.force_sync = bool(a.force_sync)
         dp.sync_bn = bool(a.sync_bn or (a.force_sync and os.environ.get("HPFG_BENCH_LOCAL_BN", "0") != "1"))
         dp.overlap = bool(a.overlap) and not a.no_overlap
-    model, ema, step = build_step(dev, a, a.math, dp)
-    xl, yl = synth_batch(1234 + rank, a.lab, a.size, a.size, 1, 4, 32)
-    xu, _ = synth_batch(91234 + rank, a.unlab, a.size, a.size, 1, 4, 32)
-    xl, yl, xu = xl.to(dev), yl.to(dev), xu.to(dev)
-    from hpfg_amd.train import batch_pair
-    xl, xu = batch_pair(xl, xu)          # labelled and unlabelled images back to back in HBM: the step's batch is a view, not a concat copy
+    wl = Workload(a.workload, a, dev, a.math, dp, rank)
 
-    # N > 1, default mode: two graphs around the gradient all-reduce (no RCCL node inside a hipGraph).  --sync-bn (collectives
-    # between the kernels of forward and backward) runs eager unless HPFG_DP_GRAPH=1 asks for a capture with RCCL nodes.
+    # N > 1, default mode: two graphs around the gradient all-reduce (no RCCL node inside a hipGraph).  --sync-bn (collectives between the
+    # kernels of forward and backward) runs eager.
     sync_mode = dp is not None and dp.sync_bn and (world > 1 or a.force_sync)
-    use_graph = (not a.no_graph) and (not sync_mode or os.environ.get("HPFG_DP_GRAPH", "0") == "1")
-    dt, use_graph, it = timed_run(step, (xl, yl, xu), a, dev, dp, use_graph, a.steps, a.warmup)
-    n_img = a.lab + a.unlab
+    use_graph = (not a.no_graph) and not sync_mode
+    dt, use_graph, it = timed_run(wl, dp, use_graph, a.steps, a.warmup, dev)
     ms = dt / a.steps * 1e3
-    value = n_img * world / (dt / a.steps)
+    value = wl.n_img * world / (dt / a.steps)
 
     roof = f32 = cpu = None
-    if rank == 0:
-        fwd = dominant_kernel_roofline(model, step, (xl, yl, xu), it, dev, eager_ok=dp is None)
-        roof = fused_bwd_roofline(model, step, (xl, yl, xu), it, dev, eager_ok=dp is None)
-        if roof is None:
-            roof = fwd
-        else:
-            roof["forward_conv_of_the_same_layer"] = fwd
-    if world == 1 and dp is None and not a.no_f32_line and a.math != "f32":
-        del step, model, ema
+    if rank == 0 and not a.no_probe and use_graph:
+        pw = wl
+        if dp is not None:      # the per-rank work is the same at every N (weak scaling): probe a private copy of the step without a process group
+            pw = Workload(a.workload, a, dev, a.math, None, rank)
+        try:
+            got = probe_families(pw, it)
+            if got is not None:
+                roof = roofline_objects(pw, *got, a.math)
+        except Exception as e:
+            print(f"[bench] per-kernel probe failed ({type(e).__name__}: {e})", file=sys.stderr)
+        if pw is not wl:
+            del pw
+    if world == 1 and dp is None and not a.no_f32_line and a.math != "f32" and a.workload == "mt":
+        del wl
         torch.cuda.empty_cache()
-        m2, e2, s2 = build_step(dev, a, "f32", None)
+        wl = Workload(a.workload, a, dev, "f32", None, rank)
         k2 = max(5, a.steps // 2)
-        dt2, g2, _ = timed_run(s2, (xl, yl, xu), a, dev, None, use_graph, k2, max(3, a.warmup // 2))
-        f32 = {"dtype": DTYPE["f32"], "value": round(n_img / (dt2 / k2), 2), "unit": "images/s", "ms_per_step": round(dt2 / k2 * 1e3, 4), "steps": k2,
+        dt2, g2, _ = timed_run(wl, None, use_graph, k2, max(3, a.warmup // 2), dev)
+        f32 = {"dtype": DTYPE["f32"], "value": round(wl.n_img / (dt2 / k2), 2), "unit": "images/s", "ms_per_step": round(dt2 / k2 * 1e3, 4), "steps": k2,
                "hipgraph": bool(g2), "note": "same step, HPFG_MATH=f32: every product exact fp32 (v_mfma_f32_16x16x4_f32); meets 1e-3 on every fixture"}
-        del m2, e2, s2
     if rank == 0 and world == 1 and not a.no_cpu_baseline:      # reported baseline: rank 0 at N=1 only
-        cpu = cpu_baseline(a.lab, a.unlab, a.size)
+        cpu = cpu_baseline(a.workload, wl.lab, wl.unlab, wl.size)
     if rank == 0:
-        step_bytes = algorithmic_bytes_mt(n_img)
         par = f"dp{world}"
         if world > 1:
             par += " (sync BatchNorm + loss sums: == one process on the global batch)" if (dp is not None and dp.sync_bn) else \
                 (" (per-rank BatchNorm, gradients averaged by bucketed all-reduces overlapped with backward)" if dp is not None and dp.overlap else
                  " (per-rank BatchNorm, gradients averaged by one all-reduce between two hipGraphs)")
+        step_roof = {"algorithmic_GB_per_step": round(wl.bytes / 1e9, 3), "achieved_GBps": round(wl.bytes / (dt / a.steps) / 1e9, 1),
+                     "frac_of_8TBps": round(wl.bytes / (dt / a.steps) / 8e12, 4), "algorithmic_GFLOP_per_step": round(wl.gflop, 1),
+                     "achieved_TFLOPs": round(wl.gflop / (dt / a.steps) / 1e3, 2)}
+        if roof is None:      # probe skipped / unavailable: the step as a whole is the only measured aggregate
+            roof = {"kernel": "whole step (per-kernel probe not run)", "bound": "hbm", "achieved": step_roof["achieved_GBps"], "peak": HBM_PEAK, "unit": "GB/s",
+                    "frac": step_roof["frac_of_8TBps"], "traffic": None}
+        metric = "labeled+unlabeled images/sec/node, U-Net 224x224 ACDC-shaped (Mean-Teacher step)" if a.workload == "mt" else \
+            f"labeled+unlabeled images/sec/node ({a.workload} step)"
         out = {
-            "metric": "labeled+unlabeled images/sec/node, U-Net 224x224 ACDC-shaped (Mean-Teacher step)", "value": round(value, 2),
-            "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4),
+            "metric": metric, "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[a.math], "data": "synthetic",
-            "config": {"workload": "mean_teacher_unet_224x224 (BASELINE configs[1]): U-Net 1ch->4cls, 8 labelled + 8 unlabelled per GPU, "
-                                   "student fwd+bwd + train-mode teacher fwd + CE/Dice/MSE + SGD + EMA",
-                       "per_gpu_batch": [a.lab, a.unlab], "size": a.size, "hipgraph": bool(use_graph), "sync_bn": bool(dp is not None and dp.sync_bn),
-                       "parallelism": par, "math": a.math},
-            "step_roofline": {"algorithmic_GB_per_step": round(step_bytes / 1e9, 3), "achieved_GBps": round(step_bytes / (dt / a.steps) / 1e9, 1),
-                              "frac_of_8TBps": round(step_bytes / (dt / a.steps) / 8e12, 4),
-                              "algorithmic_GFLOP_per_step": round(n_img * (GFLOP_TRAIN_IMG + GFLOP_FWD_IMG), 1),
-                              "achieved_TFLOPs": round(n_img * (GFLOP_TRAIN_IMG + GFLOP_FWD_IMG) / (dt / a.steps) / 1e3, 2)},
-            "roofline": roof, "f32_math": f32, "cpu_baseline": cpu,
+            "config": {"workload": wl.desc, "per_gpu_batch": [wl.lab, wl.unlab], "size": wl.size, "hipgraph": bool(use_graph),
+                       "sync_bn": bool(dp is not None and dp.sync_bn), "parallelism": par, "math": a.math},
+            "step_roofline": step_roof, "roofline": roof, "f32_math": f32, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dp is not None:
         dp.shutdown()
-
-
-def fused_bwd_roofline(model, step, inputs, it, dev, eager_ok=True):
-    """The longest launch of the step since round 2: the fused backward kernel of decoder.up4's first conv (32 -> 16 channels at 224x224):
-    input gradient + weight-gradient slabs from one staging of dZ.  Timed like dominant_kernel_roofline(): HIP events around the launch
-    inside eager steps (teacher stream idle during backward, so in-step == what the kernel trace shows), and 20 launches alone.
-    Algorithmic bytes per pixel: dA + z of the layer (2 x 16 ch), the skip tensor (16 ch), the low-res 1x1 output (16 ch at a quarter of
-    the pixels), dX written (32 ch) = 336 B.  None when the layer is not on the fused path (f32 math, HPFG_FUSED_BWD=0)."""
-    import ctypes as C
-    import torch
-    from hpfg_amd import _lib as L
-    eng = next(iter(model._engines.values()))[0]
-    name = "decoder.up4.conv.conv_conv.0"
-    if name not in eng.fused_grid or name not in eng._last_fused:
-        return None
-    s = eng.specs[name]
-    in_step_us = raw_us = bracket_us = None
-    if eager_ok:
-        eng.probe = ("fused_bwd:" + name, [], [])
-        for k in range(6):
-            step.step(*inputs, it + 1 + k)
-        torch.cuda.synchronize(dev)
-        ts = [e0.elapsed_time(e1) * 1e3 for (e0, e1) in eng.probe[1][len(eng.probe[1]) // 3:]]
-        tb = [e0.elapsed_time(e1) * 1e3 for (e0, e1) in eng.probe[2][len(eng.probe[2]) // 3:]]
-        eng.probe = None
-        if ts:
-            # an event pair costs a few microseconds by itself (two marker packets): the same bracket recorded around NOTHING, right in
-            # front of the launch, is subtracted -- what is left agrees with the kernel's duration in the rocprofv3 trace of the captured step
-            raw_us = sum(ts) / len(ts)
-            bracket_us = sum(tb) / len(tb) if tb else 0.0
-            in_step_us = raw_us - bracket_us
-    fa = eng._last_fused[name]
-    st = torch.cuda.current_stream(dev)
-    lib = L.load()
-    for _ in range(3):
-        L.check(lib.hpfg_fused_bwd(C.byref(fa), st.cuda_stream), "fused_bwd")
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
-    e0.record(st)
-    for _ in range(reps):
-        L.check(lib.hpfg_fused_bwd(C.byref(fa), st.cuda_stream), "fused_bwd")
-    e1.record(st)
-    e1.synchronize()
-    solo_us = e0.elapsed_time(e1) / reps * 1e3
-    us = in_step_us if in_step_us is not None else solo_us
-    n = eng.N
-    bytes_alg = n * s.h * s.w * (2 * 16 + 16 + 32) * 4 + n * (s.h // 2) * (s.w // 2) * 16 * 4
-    flops = n * s.h * s.w * 9 * 32 * 16 * 2 * 2
-    ach = bytes_alg / (us * 1e-6) / 1e9
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_fused_bwd_kernel.json")))
-        if n == 16 and s.h == 224:
-            traffic = int(tj["hbm_bytes_per_launch"])
-    except Exception:
-        traffic = None
-    return {"kernel": "fused_bwd_kernel<2 input x 1 output channel tiles, concat input, dZ source, 8 waves> @ decoder.up4.conv.conv_conv.0 (32->16ch, "
-                      "224x224): input gradient + weight-gradient slabs from one staging of dZ = k1*g + k2*z + k3 (BatchNorm / LeakyReLU backward on load)",
-            "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
-            "avg_launch_us": round(us, 2), "timing": ("in-step (HIP events around the launch inside eager steps, minus the same event bracket around nothing: "
-                                                      f"{raw_us:.2f} - {bracket_us:.2f} us)") if in_step_us is not None else "solo",
-            "solo_launch_us": round(solo_us, 2), "frac_solo": round(bytes_alg / (solo_us * 1e-6) / 8e12, 4),
-            "algorithmic_bytes_per_launch": bytes_alg, "flops_per_launch": flops, "achieved_TFLOPs": round(flops / (us * 1e-6) / 1e12, 2),
-            "note": "the longest launch of the step (backward of the layer whose forward was round 1's roofline kernel); no single kernel dominates "
-                    "(largest family 19 % of kernel time): step_roofline is the figure that matters"}
-
-
-def dominant_kernel_roofline(model, step, inputs, it, dev, eager_ok=True):
-    """The heaviest-traffic conv launch of the step (decoder.up4 first conv: 32ch->16ch at 224x224, reads the skip tensor + the
-    upsampled 1x1 output, writes 16ch), timed with HIP events on the stream it is launched on, two ways: (a) inside real steps --
-    the engine records events around that launch of the student's and of the teacher's forward while a few EAGER steps run (the
-    other network's kernels run concurrently on the second stream, as in the timed region) -- and (b) alone, 20 back-to-back
-    launches.  `achieved` / `frac` use (a): the in-step figure is the one the rocprofv3 kernel trace under profiles/ reproduces."""
-    import ctypes as C
-    import torch
-    from hpfg_amd import _lib as L
-    eng = next(iter(model._engines.values()))[0]
-    name = "decoder.up4.conv.conv_conv.0"
-    s = eng.specs[name]
-    in_step_us = None
-    if eager_ok:
-        engines = [e for m in (model, step.ema_model) for pool in m._engines.values() for e in pool]
-        for e in engines:
-            e.probe = (name, [], [])
-        for k in range(6):
-            step.step(*inputs, it + 1 + k)
-        torch.cuda.synchronize(dev)
-        ts = [e0.elapsed_time(e1) * 1e3 for e in engines for (e0, e1) in e.probe[1][len(e.probe[1]) // 3:]]     # first third = warm-up
-        tb = [e0.elapsed_time(e1) * 1e3 for e in engines for (e0, e1) in e.probe[2][len(e.probe[2]) // 3:]]     # the event bracket around nothing
-        for e in engines:
-            e.probe = None
-        if ts:
-            in_step_us = sum(ts) / len(ts) - (sum(tb) / len(tb) if tb else 0.0)
-    a0, a1 = eng.input_acts(name)
-    ca = L.ConvArgs()
-    ca.a0, ca.a1 = a0, a1
-    ca.math = eng.math
-    ca.wpk = L.ptr(eng.wpk16_f[name]) if eng.math == L.MATH_BF16X3 else L.ptr(eng.wpk_f[name])
-    ca.bias, ca.out = L.ptr(eng.bias_pad[name]), L.ptr(eng.z[name])
-    ca.stat_partials = L.ptr(eng.partials)
-    ca.out_pstride, ca.Cout, ca.CoutPad, ca.N, ca.H, ca.W, ca.taps = s.cout, s.cout, s.cout_pad, eng.N, s.h, s.w, 9
-    st = torch.cuda.current_stream(dev)
-    lib = L.load()
-    for _ in range(3):
-        L.check(lib.hpfg_conv_fwd(C.byref(ca), st.cuda_stream), "conv")
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
-    e0.record(st)
-    for _ in range(reps):
-        L.check(lib.hpfg_conv_fwd(C.byref(ca), st.cuda_stream), "conv")
-    e1.record(st)
-    e1.synchronize()
-    solo_us = e0.elapsed_time(e1) / reps * 1e3
-    us = in_step_us if in_step_us is not None else solo_us
-    n = eng.N
-    # algorithmic bytes of this launch: skip 16ch@224 + 1x1 output 16ch@112 read, 16ch@224 written, weights
-    bytes_alg = n * (s.h * s.w * 16 + (s.h // 2) * (s.w // 2) * 16 + s.h * s.w * 16) * 4 + 9 * 32 * 16 * 4
-    flops = n * s.h * s.w * 9 * 32 * 16 * 2
-    ach = bytes_alg / (us * 1e-6) / 1e9
-    traffic = None
-    try:      # HBM bytes of this launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, see the file)
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_dominant_kernel.json")))
-        if n == 16 and s.h == 224 and eng.math == L.MATH_BF16X3:
-            traffic = int(tj["hbm_bytes_per_launch"])
-    except Exception:
-        traffic = None
-    kname = "conv_thin_kernel" if eng.math == L.MATH_BF16X3 else "conv_mfma_kernel"
-    return {"kernel": kname + "<16x16 tile, 16 output channels, 3x3, CAT loader> @ decoder.up4.conv.conv_conv.0 (32->16ch, 224x224, skip concat + "
-                      "bilinear upsample + BN + LeakyReLU fused on load, BN partial sums in the epilogue)",
-            "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
-            "avg_launch_us": round(us, 2),
-            "timing": "in-step (HIP events around the launch inside eager steps, net of the same event bracket around nothing)" if in_step_us is not None else "solo",
-            "solo_launch_us": round(solo_us, 2), "frac_solo": round(bytes_alg / (solo_us * 1e-6) / 8e12, 4),
-            "algorithmic_bytes_per_launch": bytes_alg, "flops_per_launch": flops, "achieved_TFLOPs": round(flops / (us * 1e-6) / 1e12, 2),
-            "note": "no single kernel dominates the step (largest template instance ~7 % of kernel time): step_roofline is the figure that matters"}
-
-
-def _cpu_model():
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
-
-
-def cpu_baseline(n_lab, n_unlab, size):
-    """CPU oracle (plain PyTorch restatement of the reference step, oracle/steps_ref.py) on this host's cores, SURVEY.md section 8(d)
-    protocol: 3 warm-up + 10 timed Mean-Teacher steps, median."""
-    import torch
-    from hpfg_amd.datasets.synthetic import synth_batch
-    from oracle import laws_ref, steps_ref, unet_ref
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))      # a 1-GPU box shares its host: 16 cores is this job's CPU share
-    torch.set_num_threads(cores)
-    st = unet_ref.init_state(1337, 1, 4)
-    ema = unet_ref.clone_state(st)
-    xl, yl = synth_batch(1234, n_lab, size, size, 1, 4, 32)
-    xu, _ = synth_batch(91234, n_unlab, size, size, 1, 4, 32)
-    bufs = {}
-    times = []
-    warm, timed = 3, 10
-    for k in range(1, warm + timed + 1):
-        t0 = time.perf_counter()
-        steps_ref.mean_teacher_step(st, ema, bufs, xl, yl.long(), xu, laws_ref.medical_lr(k, 0.01, 30000), 0.0, laws_ref.ema_alpha(k, 0.99))
-        times.append(time.perf_counter() - t0)
-        if k > warm and sum(times[warm:]) > 40.0:      # bound the sample on a slow host
-            break
-    ts = sorted(times[warm:])
-    t = ts[len(ts) // 2]
-    return {"value": round((n_lab + n_unlab) / t, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(), "affinity_cores": avail,
-            "sample": f"{warm} warm-up + {len(ts)} timed Mean-Teacher steps of {n_lab}+{n_unlab} images at {size}x{size}, median, torch CPU fp32, "
-                      f"{torch.get_num_threads()} threads"}
 
 
 if __name__ == "__main__":

@@ -74,6 +74,41 @@ def build_specs(in_ch: int, ncls: int, H: int, W: int) -> Dict[str, ConvSpec]:
     return specs
 
 
+class MarkLog:
+    """Device time stamps around selected launches (bench.py's per-kernel timings).  A stamp is a one-wave kernel that stores s_memrealtime
+    (100 MHz) into a slot of `buf` (hpfg_timestamp); stamps are ordinary stream work, so they are captured into a hipGraph with the launches
+    they bracket and every replay refreshes them -- no host events, no eager steps.  `spans`: (tag, first slot, last slot) in capture
+    order; a ("calib", ...) span brackets nothing: its length (one stamp kernel plus one kernel boundary) is what a bracket costs by itself."""
+
+    def __init__(self, dev: torch.device, capacity: int = 2048):
+        self.buf = torch.zeros(capacity, dtype=torch.int64, device=dev)
+        self.spans: List[tuple] = []
+        self.n = 0
+        self.lib = L.load()
+
+    def stamp(self, stream: int) -> int:
+        k = self.n
+        if k >= self.buf.numel():
+            raise RuntimeError("MarkLog: out of slots")
+        self.n += 1
+        L.check(self.lib.hpfg_timestamp(self.buf.data_ptr() + 8 * k, stream), "timestamp")
+        return k
+
+    def bracket(self, tag: str, stream: int, launch):
+        a = self.stamp(stream)
+        launch()
+        self.spans.append((tag, a, self.stamp(stream)))
+
+    def calib(self, stream: int):
+        a = self.stamp(stream)
+        self.spans.append(("calib", a, self.stamp(stream)))
+
+    def read_us(self) -> List[tuple]:
+        """[(tag, microseconds)] of the last execution (synchronises)."""
+        t = self.buf[: self.n].cpu().numpy()
+        return [(tag, float(int(t[b]) - int(t[a])) / 100.0) for tag, a, b in self.spans]
+
+
 class UNetEngine:
     """Forward/backward schedule for one (module, N, H, W).  ``params``: name -> tensor views (flat buffers of the module)."""
 
@@ -135,11 +170,17 @@ class UNetEngine:
         self.ext_masks: Dict[str, torch.Tensor] = {}   # conv name -> uint8 NHWC keep-mask (parity tests replaying torch's masks)
         self.allreduce = None    # callable(tensor) -> in-place sum across ranks (data parallel), set by hpfg_amd.parallel
         self._skip_fin, self._fin_done = os.environ.get("HPFG_SKIP_FINALIZE", "0") == "1", {}
-        self.probe = None        # bench.py: (conv name, [(event, event), ...]) -- HIP events around that layer's forward launch (eager steps only)
+        self.marks: Optional[MarkLog] = None      # bench.py: device time stamps around every conv / dgrad / wgrad / BatchNorm launch
 
     # ---------------------------------------------------------------------------------------------------------
     def _stream(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def _run(self, tag: str, launch, stream: Optional[int] = None):
+        """launch() -- bracketed by device time stamps on its stream when a MarkLog is attached."""
+        if self.marks is None:
+            return launch()
+        return self.marks.bracket(tag, self._stream() if stream is None else stream, launch)
 
     def layer_seed(self, s: ConvSpec) -> int:
         return (self.base_seed * 0x9E3779B1 + 0x85EBCA6B * (s.idx + 1)) & 0xFFFFFFFF
@@ -229,9 +270,9 @@ class UNetEngine:
         host, dev = self._pack_table(self.math, with_dgrad)
         if counters is not None:
             assert counters.dtype == torch.int64 and counters.is_contiguous() and counters.device == self.dev
-        L.check(self.lib.hpfg_pack_weights_bump(dev.data_ptr(), host, len(self.packed), L.ptr(counters) if counters is not None else None,
-                                                counters.numel() if counters is not None else 0, L.ptr(self.seed_dev), int(seed_add), self._stream()),
-                "pack_weights")
+        self._run("pack_weights", lambda: L.check(self.lib.hpfg_pack_weights_bump(
+            dev.data_ptr(), host, len(self.packed), L.ptr(counters) if counters is not None else None,
+            counters.numel() if counters is not None else 0, L.ptr(self.seed_dev), int(seed_add), self._stream()), "pack_weights"))
 
     def _finalize_bn(self, s: ConvSpec, nblk: int, track: bool):
         if self._skip_fin and self._fin_done.get(s.name):      # timing experiment only (HPFG_SKIP_FINALIZE=1): stale tables
@@ -249,8 +290,9 @@ class UNetEngine:
             L.check(self.lib.hpfg_bn_fwd_finalize(None, 0, L.ptr(sums), count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), BN_MOMENTUM, BN_EPS,
                                                   L.ptr(self.bn[s.name]), s.cout, st), "bn_fwd_finalize")
         else:
-            L.check(self.lib.hpfg_bn_fwd_finalize(L.ptr(self.partials), nblk, None, count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), BN_MOMENTUM,
-                                                  BN_EPS, L.ptr(self.bn[s.name]), s.cout, st), "bn_fwd_finalize")
+            self._run("bn_fin:" + s.name, lambda: L.check(self.lib.hpfg_bn_fwd_finalize(
+                L.ptr(self.partials), nblk, None, count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), BN_MOMENTUM, BN_EPS, L.ptr(self.bn[s.name]), s.cout, st),
+                "bn_fwd_finalize"))
 
     def _fwd_begin(self, x: torch.Tensor, train: bool, dropout: Optional[bool], seed_step: Optional[int], needs_grad: bool) -> torch.Tensor:
         assert x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (self.N, self.in_ch, self.H, self.W), (x.shape, x.dtype, x.device)
@@ -263,6 +305,8 @@ class UNetEngine:
             self.seed_dev.fill_(int(seed_step) & 0x7FFFFFFF)
         counters, self.bump_counters = self.bump_counters, None
         self.pack(with_dgrad=bool(train and needs_grad), counters=counters, seed_add=1 if seed_step == SEED_BUMP else 0)
+        if self.marks is not None:
+            self.marks.calib(self._stream())
         return torch.empty(self.N, self.H, self.W, self.ncls, dtype=torch.float32, device=self.dev)
 
     def _conv_args(self, s: ConvSpec, out: torch.Tensor, want_stats: bool) -> L.ConvArgs:
@@ -293,25 +337,13 @@ class UNetEngine:
         nblk = self.lib.hpfg_conv_stat_blocks(self.N, s.h, s.w)
         if s.idx == 0:
             a0, _ = self.input_acts(s.name)
-            L.check(self.lib.hpfg_conv3x3_first_fwd(C.byref(a0), L.ptr(self.params[f"{s.name}.weight"]), L.ptr(self.params[f"{s.name}.bias"]),
-                                                    L.ptr(out), L.ptr(self.partials) if want_stats else None, self.N, s.h, s.w, s.cin, s.cout, st),
-                    "conv3x3_first_fwd")
+            self._run("fwd:" + s.name, lambda: L.check(self.lib.hpfg_conv3x3_first_fwd(
+                C.byref(a0), L.ptr(self.params[f"{s.name}.weight"]), L.ptr(self.params[f"{s.name}.bias"]), L.ptr(out),
+                L.ptr(self.partials) if want_stats else None, self.N, s.h, s.w, s.cin, s.cout, st), "conv3x3_first_fwd"))
             nblk = self.lib.hpfg_conv_first_rows(self.N, s.h, s.w)
         else:
             ca = self._conv_args(s, out, want_stats)
-            probe = self.probe is not None and self.probe[0] == s.name
-            if probe:
-                if len(self.probe) > 2:          # calibration: the same event bracket around nothing (see _fused_bwd)
-                    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    b0.record(torch.cuda.current_stream(self.dev))
-                    b1.record(torch.cuda.current_stream(self.dev))
-                    self.probe[2].append((b0, b1))
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(torch.cuda.current_stream(self.dev))
-            L.check(self.lib.hpfg_conv_fwd(C.byref(ca), st), f"conv_fwd[{s.name}]")
-            if probe:
-                e1.record(torch.cuda.current_stream(self.dev))
-                self.probe[1].append((e0, e1))
+            self._run("fwd:" + s.name, lambda: L.check(self.lib.hpfg_conv_fwd(C.byref(ca), st), f"conv_fwd[{s.name}]"))
             if want_stats:
                 nblk = self.lib.hpfg_conv_stat_rows(C.byref(ca))
         if s.bn:
@@ -428,11 +460,12 @@ class UNetEngine:
             nblk = fused
         elif pooled_grad is not None:
             nblk = self.lib.hpfg_bn_bwd_pool_blocks(self.N, s.h // 2, s.w // 2, s.cout)
-            L.check(self.lib.hpfg_bn_bwd_reduce_pool(C.byref(g), L.ptr(pooled_grad), s.cout, self.N, s.h // 2, s.w // 2, L.ptr(self.partials), st),
-                    f"bn_bwd_reduce_pool[{s.name}]")
+            self._run("bn_red:" + s.name, lambda: L.check(self.lib.hpfg_bn_bwd_reduce_pool(
+                C.byref(g), L.ptr(pooled_grad), s.cout, self.N, s.h // 2, s.w // 2, L.ptr(self.partials), st), f"bn_bwd_reduce_pool[{s.name}]"))
         else:
             nblk = self.lib.hpfg_bn_bwd_blocks(self.N, s.h, s.w, s.cout)
-            L.check(self.lib.hpfg_bn_bwd_reduce(C.byref(g), self.N, s.h, s.w, L.ptr(self.partials), st), f"bn_bwd_reduce[{s.name}]")
+            self._run("bn_red:" + s.name, lambda: L.check(self.lib.hpfg_bn_bwd_reduce(C.byref(g), self.N, s.h, s.w, L.ptr(self.partials), st),
+                                                           f"bn_bwd_reduce[{s.name}]"))
         count = float(self.N * s.h * s.w * self.world)
         gam = self.params[f"{s.bn}.weight"]
         dg, db = self.grads[f"{s.bn}.weight"], self.grads[f"{s.bn}.bias"]
@@ -446,8 +479,8 @@ class UNetEngine:
             L.check(self.lib.hpfg_bn_bwd_finalize(None, 0, L.ptr(sums), count, L.ptr(gam), L.ptr(self.bn[s.name]), L.ptr(dg), L.ptr(db), s.cout,
                                                   1.0 / self.world, st), "bn_bwd_finalize")      # global sums on every rank: the SUM all-reduce of the gradients restores them
         else:
-            L.check(self.lib.hpfg_bn_bwd_finalize(L.ptr(self.partials), nblk, None, count, L.ptr(gam), L.ptr(self.bn[s.name]), L.ptr(dg), L.ptr(db),
-                                                  s.cout, 1.0, st), "bn_bwd_finalize")
+            self._run("bn_bfin:" + s.name, lambda: L.check(self.lib.hpfg_bn_bwd_finalize(
+                L.ptr(self.partials), nblk, None, count, L.ptr(gam), L.ptr(self.bn[s.name]), L.ptr(dg), L.ptr(db), s.cout, 1.0, st), "bn_bwd_finalize"))
         return g
 
     def _wgrad_dgrad(self, s: ConvSpec, g: L.Act, dgrad_out: torch.Tensor, stats_for: Optional[str] = None, out2: Optional[torch.Tensor] = None):
@@ -485,20 +518,7 @@ class UNetEngine:
             ca.bwd_stats, ca.bwd_of, ca.stat_partials = 1, self._act_dz(stats_for, out, s.cin), L.ptr(self.partials)
             self._fused_rows[stats_for] = rows
         self._last_fused[s.name] = fa      # (bench.py re-launches it alone)
-        probe = self.probe is not None and self.probe[0] == "fused_bwd:" + s.name
-        if probe:
-            cur = torch.cuda.current_stream(self.dev)
-            if len(self.probe) > 2:          # calibration: the same bracket around nothing, right in front (what two event records cost by themselves)
-                b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                b0.record(cur)
-                b1.record(cur)
-                self.probe[2].append((b0, b1))
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(cur)
-        L.check(self.lib.hpfg_fused_bwd(C.byref(fa), self._stream()), f"fused_bwd[{s.name}]")
-        if probe:
-            e1.record(cur)
-            self.probe[1].append((e0, e1))
+        self._run("fused_bwd:" + s.name, lambda: L.check(self.lib.hpfg_fused_bwd(C.byref(fa), self._stream()), f"fused_bwd[{s.name}]"))
 
     def _wgrad(self, s: ConvSpec, g: L.Act, on_side: bool = False):
         """Weight gradient of layer s.  It is off the critical chain of backward (nothing downstream consumes it before the final
@@ -523,7 +543,7 @@ class UNetEngine:
         wa.N, wa.H, wa.W, wa.taps = self.N, s.h, s.w, s.taps
         wa.S = self.lib.hpfg_wgrad_splits(self.N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps)
         wa.math = self.math
-        L.check(self.lib.hpfg_wgrad(C.byref(wa), stream), f"wgrad[{s.name}]")
+        self._run("wgrad:" + s.name, lambda: L.check(self.lib.hpfg_wgrad(C.byref(wa), stream), f"wgrad[{s.name}]"), stream)
 
     def _dgrad(self, s: ConvSpec, g: L.Act, out: torch.Tensor, stats_for: Optional[str] = None, out2: Optional[torch.Tensor] = None):
         """out [N,h,w,cin] = conv-transpose of dZ with this layer's weights.
@@ -547,7 +567,7 @@ class UNetEngine:
             if rows <= 0 or rows * 2 * s.cin > self.partials.numel():
                 raise RuntimeError(f"dgrad[{s.name}]: {rows} rows of backward sums do not fit the partials workspace")
             self._fused_rows[stats_for] = rows
-        L.check(self.lib.hpfg_conv_fwd(C.byref(ca), self._stream()), f"dgrad[{s.name}]")
+        self._run("dgrad:" + s.name, lambda: L.check(self.lib.hpfg_conv_fwd(C.byref(ca), self._stream()), f"dgrad[{s.name}]"))
 
     def _slab_reduce(self, lo: int, hi: int, stream=None):
         """Sum the weight-gradient slabs of descriptors [lo, hi) into the gradient buffer (one launch)."""
@@ -555,8 +575,8 @@ class UNetEngine:
             return
         sz = C.sizeof(L.SlabDesc)
         host = (L.SlabDesc * (hi - lo)).from_buffer(self._slab_host, lo * sz)
-        L.check(self.lib.hpfg_slab_reduce_multi(self._slab_dev.data_ptr() + lo * sz, host, hi - lo, stream if stream is not None else self._stream()),
-                "slab_reduce_multi")
+        st_ = stream if stream is not None else self._stream()
+        self._run("slab_reduce", lambda: L.check(self.lib.hpfg_slab_reduce_multi(self._slab_dev.data_ptr() + lo * sz, host, hi - lo, st_), "slab_reduce_multi"), st_)
 
     def backward(self, dlogits: torch.Tensor, dfeat4: Optional[torch.Tensor] = None, bucket_cb=None):
         """dlogits: [N,H,W,ncls] contiguous.  dfeat4: optional gradient w.r.t. the activated bottleneck [N,h,w,256].
@@ -581,8 +601,10 @@ class UNetEngine:
         # ---- out_conv
         s = sp["decoder.out_conv"]
         g = self._act_plain(dlogits, self.ncls, s.h, s.w)
-        L.check(self.lib.hpfg_channel_sum_partials(L.ptr(dlogits), self.ncls, N * s.h * s.w, self.ncls, L.ptr(self.csum_part[s.name]), st),
-                "channel_sum_partials")
+        if self.marks is not None:
+            self.marks.calib(st)          # (what a bracket costs by itself, measured where backward starts)
+        self._run("csum:" + s.name, lambda: L.check(self.lib.hpfg_channel_sum_partials(
+            L.ptr(dlogits), self.ncls, N * s.h * s.w, self.ncls, L.ptr(self.csum_part[s.name]), st), "channel_sum_partials"))
         self._wgrad_dgrad(s, g, self.dA["decoder.up4.conv.conv_conv.4"], "decoder.up4.conv.conv_conv.4")
         # ---- decoder blocks, last to first
         for k in range(4, 0, -1):
@@ -598,8 +620,9 @@ class UNetEngine:
             else:
                 self._wgrad_dgrad(s1, g1, self.dcat[k])            # [dSkip | dUp]
                 dup, dup_ps = self.dcat[k].view(-1)[c2:], 2 * c2   # channel offset c2, pixel stride 2*c2
-            L.check(self.lib.hpfg_upsample2x_bwd_sums(L.ptr(dup), dup_ps, L.ptr(self.dU[k]), N, su.h, su.w, c2, L.ptr(self.csum_part[su.name]), st),
-                    "upsample2x_bwd")                            # + per-workgroup channel sums of dU: the 1x1 conv's bias gradient
+            self._run("upbwd:" + su.name, lambda: L.check(self.lib.hpfg_upsample2x_bwd_sums(
+                L.ptr(dup), dup_ps, L.ptr(self.dU[k]), N, su.h, su.w, c2, L.ptr(self.csum_part[su.name]), st),
+                "upsample2x_bwd"))                               # + per-workgroup channel sums of dU: the 1x1 conv's bias gradient
             gu = self._act_plain(self.dU[k], c2, su.h, su.w)
             prev = enc_prefix(4) + ".4" if k == 1 else f"decoder.up{k - 1}.conv.conv_conv.4"
             # the 1x1 conv is the only consumer of the block output below (the bottleneck also feeds the dense head of UNet_Plus)

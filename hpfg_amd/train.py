@@ -712,9 +712,10 @@ class GraphedStep:
     Host scalars are copied to the device eagerly in front of every replay (StepScalars ring); dropout masks change per replay
     through the engines' device seed word."""
 
-    def __init__(self, step_obj, example_inputs, warmup: int = 3, alias_inputs: bool = False):
+    def __init__(self, step_obj, example_inputs, warmup: int = 3, alias_inputs: bool = False, before_capture=None):
         """alias_inputs: the graph reads ``example_inputs`` themselves (the caller refills those tensors in place, or they never
-        change) instead of private copies that every step() would have to refresh with one copy kernel per input."""
+        change) instead of private copies that every step() would have to refresh with one copy kernel per input.
+        before_capture: optional callable run between the eager warm-up steps and the capture (bench.py resets its time-stamp logs there)."""
         self.s = step_obj
         self.alias = bool(alias_inputs)
         self.static = list(example_inputs) if self.alias else [t.clone() for t in example_inputs]
@@ -730,6 +731,8 @@ class GraphedStep:
                 self.s.after()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if before_capture is not None:
+            before_capture()
         self._freeze_seed_updates(True)
         # thread_local: another thread's HIP calls (the RCCL watchdog polling its events) must not invalidate this capture
         dp = getattr(step_obj, "dp", None)

@@ -94,45 +94,24 @@ def test_backward_all_parameter_gradients(n, hw, in_ch, ncls, seed, math):
     rl = losses_ref.med_sup_loss(ro, lab.long())
     rg = steps_ref._grads(rl, st, names)
     assert abs(float(loss) - float(rl)) < 1e-4
-    # Discrete events (a LeakyReLU sign or a max-pool arg-max sitting on a tie) can flip under a 1e-7 (fp32 summation order) or 1e-5
-    # (split-bf16 re-quantisation) perturbation of the forward pass; one flip moves one gradient path by a few percent of a tensor's
-    # largest element.  How often that happens on THIS input is measured, not assumed -- two CPU control runs of the oracle
-    # (oracle/bf16x3_ref.py):
-    #   noise[k]  what summation order alone does to gradient k in this math mode: the mode's products accumulated in fp64 vs in fp32;
-    #   model[k]  (bf16x3 only) what the split-bf16 products do to it: emulated device arithmetic vs the fp32 oracle.
-    # Every tensor must be within 1e-3 + 2 x noise[k] of the oracle run in its own arithmetic, and within 1e-3 + 2 x model[k] of the fp32 oracle.
-    def run(mode):
-        st2 = unet_ref.clone_state(st)
-        for v in st2.values():
-            if v.is_floating_point():
-                v.requires_grad_(False)
-        nm = steps_ref._train_state(st2)
-        with bf16x3_ref.math_mode(mode):
-            o_ = unet_ref.unet_forward(st2, x, True, masks, track_running=False)
-            return steps_ref._grads(losses_ref.med_sup_loss(o_, lab.long()), st2, nm)
-
-    def rel(a, b_, k):
-        return float((a[k].double() - b_[k].double()).norm() / max(1e-4, float(b_[k].double().norm())))
-
+    # Discrete events (a LeakyReLU sign or a max-pool arg-max within rounding noise of a tie) fall either way in any correct implementation,
+    # and one flip moves every upstream gradient by 1e-3 ... 1e-1 on inputs this small.  What they cost HERE is measured by a committed
+    # control, tests/trace_replay.py::grad_ensemble: the oracle in this math mode's own arithmetic, re-run from weights perturbed at the
+    # mode's noise level.  The device's gradients must sit within 1e-3 + 2x the ensemble's spread of the fp32 oracle: the worst tensor
+    # against the ensemble's worst, the median tensor against the ensemble's largest median (a routing / scaling mistake is O(1)).
+    from tests import trace_replay as R
+    st0 = {k: v.detach().clone() for k, v in st.items()}
+    nominal, ens = R.grad_ensemble(st0, x, lab, masks, math)
+    live = [k for k in rg if float(rg[k].double().norm()) > 1e-6]          # (biases in front of a train-mode BatchNorm: rounding noise only)
     got = {}
     for k, p in m.named_parameters():
         assert p.grad is not None, k
         got[k] = p.grad.cpu()
-    own = rg if math == "f32" else run("bf16x3")
-    acc64 = run("f64acc" if math == "f32" else "bf16x3_f64acc")
-    bad = {}
-    for k in got:
-        noise = rel(acc64, own, k)
-        e_own = rel(got, own, k)
-        if not e_own < 1e-3 + 2.0 * noise:
-            bad[k] = ("vs own arithmetic", e_own, noise)
-        if math != "f32":
-            model, e_ref = rel(own, rg, k), rel(got, rg, k)
-            if not e_ref < 1e-3 + 2.0 * model:
-                bad[k] = ("vs fp32 oracle", e_ref, model)
-    # (the per-kernel tests in test_gpu_kernels.py pin dgrad / wgrad / BN-backward / pool / upsample element-wise at 2e-4..5e-4;
-    #  this test guards the COMPOSITION: a routing or scaling mistake shows up as an O(1) error)
-    assert not bad, f"relative gradient errors beyond the controls: {bad}"
+    err = {k: R.rel_l2(got[k], rg[k]) for k in live}
+    runs = [[R.rel_l2(e[k], rg[k]) for k in live] for e in ens + [nominal]]
+    ctl_max, ctl_med = max(max(r) for r in runs), max(float(np.median(r)) for r in runs)
+    e_max, e_med = max(err.values()), float(np.median(list(err.values())))
+    assert e_max < 1e-3 + 2.0 * ctl_max and e_med < 1e-3 + 2.0 * ctl_med, (e_max, ctl_max, e_med, ctl_med, max(err, key=err.get))
 
 
 def _fixture_masks(d, n, hw, prefix="mask"):

@@ -319,3 +319,39 @@ def emulation_drift(replay, d, keys, **kw):
     with bf16x3_ref.math_mode("bf16x3"):
         emu = replay(d, **kw)
     return max(float((emu[k] - nom[k]).abs().max()) for k in keys), emu
+
+
+# ---- controls of the gradient bounds ---------------------------------------------------------------------------------------------------
+def grad_ensemble(st, x, lab, masks, math: str, k_runs: int = 8, ncls_loss=None):
+    """Control runs of one train-mode forward + backward (0.5 CE + 0.5 Dice) of the oracle, for the bounds of the device's gradients.
+
+    A LeakyReLU sign or a max-pool arg-max that sits within rounding noise of a tie may fall either way in any correct implementation;
+    one such flip moves every upstream weight gradient by 1e-3 ... 1e-1 (relative L2) on a 16..64-pixel input and averages out on
+    224 x 224 ones.  How much, on THIS input, is measured by an ensemble: the oracle in the math mode's own arithmetic
+    ("f32": fp32 products; "bf16x3": the emulated split-bf16 products of oracle/bf16x3_ref.py) re-run `k_runs` times from conv weights
+    perturbed at the mode's noise level -- relative 1e-6 for exact fp32 (summation order, fp32-vs-fp64 BatchNorm statistics: about ten
+    roundings), 2^-18 for split-bf16 (half an ulp of the lo word: what re-quantisation of an operand moves) -- plus once with fp64
+    accumulation.  Returns (nominal gradients of that arithmetic, [ensemble gradients])."""
+    from oracle import bf16x3_ref, losses_ref
+
+    def run(mode, seed, eps):
+        st2 = unet_ref.clone_state(st)
+        if seed is not None:
+            g = torch.Generator().manual_seed(4000 + seed)
+            for n_ in st2:
+                if n_.endswith(".weight") and st2[n_].dim() == 4:
+                    r = 2 * torch.rand(st2[n_].shape, generator=g, dtype=torch.float64) - 1
+                    st2[n_] = (st2[n_].double() * (1 + eps * r)).float()
+        names = steps_ref._train_state(st2)
+        with bf16x3_ref.math_mode(mode):
+            o = unet_ref.unet_forward(st2, x, True, masks, track_running=False)
+            return steps_ref._grads(losses_ref.med_sup_loss(o, lab.long()), st2, names)
+
+    mode, eps = ("f32", 1e-6) if math == "f32" else ("bf16x3", 2.0 ** -18)
+    nominal = run(mode, None, 0.0)
+    ens = [run(mode + "_f64acc" if mode == "bf16x3" else "f64acc", None, 0.0)] + [run(mode, s, eps) for s in range(k_runs)]
+    return nominal, ens
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor, floor: float = 1e-4) -> float:
+    return float((a.double() - b.double()).norm() / max(floor, float(b.double().norm())))
