@@ -145,11 +145,19 @@ class _StepBase:
                             u.record_stream(cur)
             self._pending_join = False
 
+    def _join_backward(self, stream):
+        """A network whose forward ran on `stream` back-propagates there too (autograd runs a node on the stream of its forward).  Its
+        backward node hands autograd no gradient tensors (they are written in place into the flat buffer), so autograd has nothing to
+        synchronise that stream with: the step joins it explicitly before anything reads the gradients -- and, inside a capture, before
+        the capture ends (an unjoined forked stream is what made hipStreamEndCapture of the HPFG step fault)."""
+        if stream is not None and self.overlap and os.environ.get("HPFG_STUDENT_OVERLAP", "1") == "1":
+            torch.cuda.current_stream(self.dev).wait_stream(stream)
+
     def _attach(self, model, alone: bool = False):
         """alone: the only trainable network of the step -- its backward may fork its off-chain weight gradients onto a side stream
         (UNetEngine.backward); with two networks training on two streams that extra fork is not taken (see engine.py)."""
         model.dp = self.dp
-        if alone:
+        if alone or os.environ.get("HPFG_DEFER_ALL", "0") == "1":      # (HPFG_DEFER_ALL: also for the networks of a two-network step, A/B runs)
             model.defer_wgrad = True
         if any(p.requires_grad for p in model.parameters()):
             model.direct_grads = True          # one zero_grad + one backward per step: write gradients in place (no memset, no add)
@@ -520,6 +528,7 @@ class CPSStep(_StepBase):
         self.optimizer1.zero_grad()
         self.optimizer2.zero_grad()
         loss.backward()
+        self._join_backward(self.side)
         self._reduce_grads(self.model1, self.model2)
         for o in (self.optimizer1, self.optimizer2):
             o.step(push_lr=False) if hasattr(o, "push_lr") else o.step()         # FusedSGD reads its lr from the device scalars
@@ -608,6 +617,7 @@ class HPFGStep(_StepBase):
         self.optimizer1.zero_grad()
         self.optimizer2.zero_grad()
         loss.backward()
+        self._join_backward(getattr(self, "side2", None))
         self._reduce_grads(self.model1, self.model2)
         self.optimizer1.step(push_lr=False)
         self.optimizer2.step(push_lr=False)
@@ -687,6 +697,7 @@ class S4CVNetStep(_StepBase):
         self.optimizer1.zero_grad()
         self.optimizer2.zero_grad()
         loss.backward()
+        self._join_backward(getattr(self, "side2", None))
         self._reduce_grads(self.model1, self.model2)
         self.optimizer1.step(push_lr=False)
         self.optimizer2.step(push_lr=False)
@@ -717,6 +728,12 @@ class GraphedStep:
         change) instead of private copies that every step() would have to refresh with one copy kernel per input.
         before_capture: optional callable run between the eager warm-up steps and the capture (bench.py resets its time-stamp logs there)."""
         self.s = step_obj
+        dp0 = getattr(step_obj, "dp", None)
+        if dp0 is not None and getattr(dp0, "sync_bn", True) and (dp0.world_size > 1 or dp0.force_sync):
+            # all-reduced BatchNorm statistics = a collective between the kernels of every layer: those never sit inside a captured region
+            # (RCCL's watchdog thread polls its events while a capture is open; losing that race aborted the process)
+            raise RuntimeError("GraphedStep: a step with collectives between its kernels (data parallel with sync_bn=True) is not captured into a "
+                               "hipGraph; run it eager, or use sync_bn=False (per-rank BatchNorm: collectives only between graphs)")
         self.alias = bool(alias_inputs)
         self.static = list(example_inputs) if self.alias else [t.clone() for t in example_inputs]
         self.graph = torch.cuda.CUDAGraph()
