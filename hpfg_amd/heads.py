@@ -148,5 +148,29 @@ class _NTXent(torch.autograd.Function):
         return dx.reshape(shape), None, None
 
 
-def ntxent(a: torch.Tensor, b: torch.Tensor, temperature: float) -> torch.Tensor:
-    return _NTXent.apply(a, b.detach(), temperature)
+class _GatherRows(torch.autograd.Function):
+    """all-gather of feature rows over the data-parallel group (rank-major); backward hands back this rank's rows of the gradient.
+    Every rank then evaluates the SAME global-batch loss, and the SUM all-reduce of the parameter gradients counts each row once."""
+
+    @staticmethod
+    def forward(ctx, x, dp):
+        import torch.distributed as dist
+        x = x.contiguous()
+        parts = [torch.empty_like(x) for _ in range(dp.world_size)]
+        dist.all_gather(parts, x, group=dp.group)
+        ctx.rank, ctx.n = dp.rank, x.shape[0]
+        return torch.cat(parts, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n].contiguous(), None
+
+
+def ntxent(a: torch.Tensor, b: torch.Tensor, temperature: float, dp=None) -> torch.Tensor:
+    """dp (a DataParallelContext in the global-batch mode, sync_bn=True, with more than one rank): the contrast runs over the features of the
+    WHOLE global batch, as Dense_Loss(batch_size + unlabel_batch_size) does in the single-process reference (main.py:89,172) -- two small
+    all-gathers ([N/R, 128] and [N/R, 2048] rows) per call; without it (per-rank mode) each rank contrasts its own batch."""
+    b = b.detach()
+    if dp is not None and getattr(dp, "sync_bn", True) and dp.world_size > 1:
+        a, b = _GatherRows.apply(a, dp), _GatherRows.apply(b, dp)
+    return _NTXent.apply(a, b, temperature)

@@ -225,14 +225,24 @@ class SupervisedStep(_StepBase):
     def host_scalars(self, cur_itrs):
         self.sc.host[S_LR1] = self._lr(self.optimizer)
 
-    def device_step(self, img, label):
+    def device_fwd_bwd(self, img, label):
         out = self.model(img)
         res = seg_loss(out, label, coef=self.sc.view(S_COEF_A, 8), dp=self.dp)
         self.optimizer.zero_grad()
         self._loss_backward(res)
-        self._reduce_grads(self.model)
-        self.optimizer.step(push_lr=False)
         return {"loss": res[0].detach(), "logits": out.detach(), "parts": res.detach()}
+
+    def exchange(self):
+        self._reduce_grads(self.model)
+
+    def device_update(self):
+        self.optimizer.step(push_lr=False)
+
+    def device_step(self, img, label):
+        r = self.device_fwd_bwd(img, label)
+        self.exchange()
+        self.device_update()
+        return r
 
     def after(self):
         self.lr_scheduler.step()
@@ -503,7 +513,8 @@ class CPSStep(_StepBase):
         h[S_COEF_A:S_COEF_A + 5] = torch.tensor([0.5, 0.5, 0.5 * w, 0.5 * w, 0.0])
         return w
 
-    def device_step(self, label_img, target_label, unlabel_img):
+    def device_fwd_bwd(self, label_img, target_label, unlabel_img):
+        """Everything up to (not including) the gradient exchange."""
         nl = label_img.shape[0]
         x = cat_batch(label_img, unlabel_img)
         if self.overlap and os.environ.get("HPFG_STUDENT_OVERLAP", "1") == "1":
@@ -529,10 +540,20 @@ class CPSStep(_StepBase):
         self.optimizer2.zero_grad()
         loss.backward()
         self._join_backward(self.side)
+        return {"loss": loss.detach(), "parts1": r1.detach(), "parts2": r2.detach(), "logits1": o1.detach(), "logits2": o2.detach()}
+
+    def exchange(self):
         self._reduce_grads(self.model1, self.model2)
+
+    def device_update(self):
         for o in (self.optimizer1, self.optimizer2):
             o.step(push_lr=False) if hasattr(o, "push_lr") else o.step()         # FusedSGD reads its lr from the device scalars
-        return {"loss": loss.detach(), "parts1": r1.detach(), "parts2": r2.detach(), "logits1": o1.detach(), "logits2": o2.detach()}
+
+    def device_step(self, label_img, target_label, unlabel_img):
+        r = self.device_fwd_bwd(label_img, target_label, unlabel_img)
+        self.exchange()
+        self.device_update()
+        return r
 
     def after(self):
         self.lr_scheduler1.step()
@@ -561,6 +582,7 @@ class HPFGStep(_StepBase):
         self.optimizer2._lr_dev = self.sc.view(S_LR2)
         self._set_grad_scale(self.optimizer1, self.optimizer2)
         self.dense_loss = Dense_Loss(args.batch_size + args.unlabel_batch_size, self.dev)
+        self.dense_loss.dp = dp      # global-batch mode: NT-Xent over the gathered features of all ranks (main.py:172 contrasts the whole batch)
         self.mask_generator = BoxMaskGenerator(prop_range=(0.25, 0.5), n_boxes=4, random_aspect_ratio=True, prop_by_area=True,
                                                within_bounds=True, invert=True)          # main.py:94-115
         self._w = 0.0
@@ -584,7 +606,7 @@ class HPFGStep(_StepBase):
         m = self.mask_generator.generate_params(n_masks=n, mask_shape=shape, rng=rng)
         return torch.tensor(m, dtype=torch.float)
 
-    def device_step(self, label_img, target_label, label_img1, target_label1, img_unlabel, cutmix_mask):
+    def device_fwd_bwd(self, label_img, target_label, label_img1, target_label1, img_unlabel, cutmix_mask):
         """label_img1/target_label1 are already repeated to the unlabelled batch size (main.py:142-143)."""
         nl = label_img.shape[0]
         mix_un = cutmix_blend(label_img1, img_unlabel, cutmix_mask)
@@ -618,14 +640,24 @@ class HPFGStep(_StepBase):
         self.optimizer2.zero_grad()
         loss.backward()
         self._join_backward(getattr(self, "side2", None))
+        return {"loss": loss.detach(), "parts1": r1.detach(), "parts2": r2.detach(), "contrast": contrast.detach(),
+                "logits1": o1.detach(), "logits2": o2.detach(), "t_logits": ot}
+
+    def exchange(self):
         self._reduce_grads(self.model1, self.model2)
+
+    def device_update(self):
         self.optimizer1.step(push_lr=False)
         self.optimizer2.step(push_lr=False)
         a = self.sc.view(S_ALPHA)
         update_ema_variables_backbone(self.model1, self.model2, self.args.ema_decay, 0, alpha_dev=a)
         update_ema_variables(self.model2, self.ema_model, self.args.ema_decay, 0, alpha_dev=a)
-        return {"loss": loss.detach(), "parts1": r1.detach(), "parts2": r2.detach(), "contrast": contrast.detach(),
-                "logits1": o1.detach(), "logits2": o2.detach(), "t_logits": ot}
+
+    def device_step(self, label_img, target_label, label_img1, target_label1, img_unlabel, cutmix_mask):
+        r = self.device_fwd_bwd(label_img, target_label, label_img1, target_label1, img_unlabel, cutmix_mask)
+        self.exchange()
+        self.device_update()
+        return r
 
     def after(self):
         self.lr_scheduler1.step()
@@ -670,7 +702,7 @@ class S4CVNetStep(_StepBase):
     def draw_noise(self, unlabel_img):
         return torch.randn_like(unlabel_img)          # :109, clamped inside noise_add
 
-    def device_step(self, label_img, target_label, unlabel_img, noise):
+    def device_fwd_bwd(self, label_img, target_label, unlabel_img, noise):
         nl = label_img.shape[0]
         x = cat_batch(label_img, unlabel_img)
         ot = self._teacher_forward(self.ema_model, noise_add(unlabel_img, noise))
@@ -698,11 +730,21 @@ class S4CVNetStep(_StepBase):
         self.optimizer2.zero_grad()
         loss.backward()
         self._join_backward(getattr(self, "side2", None))
+        return {"loss": loss.detach(), "parts1": r1.detach(), "parts2": r2.detach(), "logits1": o1.detach(), "logits2": o2.detach(), "t_logits": ot}
+
+    def exchange(self):
         self._reduce_grads(self.model1, self.model2)
+
+    def device_update(self):
         self.optimizer1.step(push_lr=False)
         self.optimizer2.step(push_lr=False)
         update_ema_variables(self.model2, self.ema_model, self.args.ema_decay, 0, alpha_dev=self.sc.view(S_ALPHA))
-        return {"loss": loss.detach(), "parts1": r1.detach(), "parts2": r2.detach(), "logits1": o1.detach(), "logits2": o2.detach(), "t_logits": ot}
+
+    def device_step(self, label_img, target_label, unlabel_img, noise):
+        r = self.device_fwd_bwd(label_img, target_label, unlabel_img, noise)
+        self.exchange()
+        self.device_update()
+        return r
 
     def after(self):
         self.lr_scheduler1.step()
@@ -753,8 +795,10 @@ class GraphedStep:
         self._freeze_seed_updates(True)
         # thread_local: another thread's HIP calls (the RCCL watchdog polling its events) must not invalidate this capture
         dp = getattr(step_obj, "dp", None)
-        self.split = bool(dp is not None and not getattr(dp, "sync_bn", True) and (dp.world_size > 1 or dp.force_sync)
-                          and hasattr(step_obj, "device_fwd_bwd"))
+        self.split = bool(dp is not None and not getattr(dp, "sync_bn", True) and (dp.world_size > 1 or dp.force_sync))
+        if self.split and not hasattr(step_obj, "device_fwd_bwd"):
+            raise RuntimeError(f"GraphedStep: {type(step_obj).__name__} has no device_fwd_bwd / exchange / device_update split, so its gradient "
+                               "exchange would be captured into the graph; run it eager under data parallel")
         if self.split:
             # per-rank BatchNorm (DDP semantics): the only collectives of the step are the gradient all-reduces.  The work between
             # them is captured as a CHAIN of hipGraphs and the RCCL calls are issued eagerly in between, on a side stream -- no
@@ -763,7 +807,10 @@ class GraphedStep:
             # being captured and begins the next one in the same memory pool.
             self.graph_b = torch.cuda.CUDAGraph()
             self.graphs, self.bucket_after = [self.graph], []
-            overlap = bool(getattr(dp, "overlap", False)) and os.environ.get("HPFG_DP_CHAIN", "1") == "1"
+            # the bucket chain ends one graph and begins the next in the middle of backward: only legal while no second stream is forked
+            # there, i.e. for steps with one trainable network (two students back-propagate on two streams: one exchange after both)
+            overlap = (bool(getattr(dp, "overlap", False)) and os.environ.get("HPFG_DP_CHAIN", "1") == "1"
+                       and sum(1 for m in self._models() if any(p.requires_grad for p in m.parameters())) == 1)
             if overlap:
                 # the boundary runs on autograd's device thread: ending a capture from another thread than the one that began it
                 # needs the relaxed mode (which also tolerates the RCCL watchdog's event queries)

@@ -152,10 +152,11 @@ class Dense_Loss(nn.Module):
     def __init__(self, batch_size: int = 32, device=None, temperature: float = 0.7):
         super().__init__()
         self.batch_size, self.temperature = batch_size, temperature
+        self.dp = None      # data parallel, global-batch mode: the step sets its DataParallelContext and the contrast spans all ranks' features
 
     def contrastive_loss(self, a, b):
         from ..heads import ntxent
-        return ntxent(a, b, self.temperature)
+        return ntxent(a, b, self.temperature, self.dp)
 
     def forward(self, x, y):
         return 0.5 * (self.contrastive_loss(x[0], y[0].detach()) + self.contrastive_loss(x[1], y[1].detach()))

@@ -1,7 +1,14 @@
-"""GPU, TWO ranks on one device (gloo; fresh child processes): the data-parallel contract through the REAL engine --
-"R ranks on shards == one process on the global batch" in the --sync-bn mode: BatchNorm sums of every layer (student and train-mode
-teacher, forward and backward), the loss sums and the gradient buckets (all-reduced from inside backward on a side stream) cross the
-ranks; losses, student and teacher parameters and running statistics after two Mean-Teacher steps equal the single-process run at 1e-5."""
+"""GPU, TWO ranks on one device (gloo between fresh child processes; the box has one GPU): the data-parallel contract through the REAL engine.
+
+  * global-batch mode (sync_bn = True): "R ranks on shards == one process on the global batch" -- BatchNorm sums of every layer (students
+    and train-mode teacher, forward and backward), the loss sums, the gathered Dense_Loss features and the gradient exchange (bucketed from
+    inside backward, or one all-reduce after it) cross the ranks; losses, parameters and running statistics after two steps equal the
+    single-process run at 1e-5.  Mean-Teacher (one trainable network), CPS (two networks through one _reduce_grads) and HPFG (two U-Net+
+    students + teacher on three streams, CutMix, Dense_Loss: BASELINE configs[2] is "DDP over 2/4/8").
+  * per-rank BatchNorm (sync_bn = False, what `bench.py --gpus N` times): after ONE step from identical weights the parameters equal the MEAN
+    of the two single-process runs on the shards (SGD's first step is linear in the gradient), and the chain of hipGraphs around the eager
+    exchange (both overlap settings) equals the eager run.
+"""
 import os
 import socket
 import subprocess
@@ -15,6 +22,7 @@ from tests.helpers import maxerr
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = torch.device("cuda:0")
 
 
 def _free_port():
@@ -25,15 +33,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_two_ranks_equal_the_global_batch(tmp_path, overlap):
-    out = str(tmp_path / "res")
+def _two_ranks(tmp_path, tag, **env_kw):
+    out = str(tmp_path / tag)
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", HPFG_TEST_OVERLAP="1" if overlap else "0")
-        procs.append(subprocess.Popen([sys.executable, "-m", "tests.dp_rank_worker", out], cwd=ROOT, env=env))
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", **{k: str(v) for k, v in env_kw.items()})
+        procs.append(subprocess.Popen([sys.executable, "-X", "faulthandler", "-m", "tests.dp_rank_worker", out], cwd=ROOT, env=env))
     try:
         for p in procs:
             assert p.wait(timeout=300) == 0
@@ -41,11 +48,47 @@ def test_two_ranks_equal_the_global_batch(tmp_path, overlap):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    ref_l, ref_p, ref_e, ref_rv = W.run(torch.device("cuda:0"), None, 0, 1)
-    r0 = torch.load(f"{out}.rank0")
-    r1 = torch.load(f"{out}.rank1")
-    for (l, p, e, rv) in (r0, r1):
-        assert maxerr(l, ref_l) < 1e-5, (l, ref_l)                       # loss parts are normalised by the GLOBAL counts on every rank
-        assert maxerr(p, ref_p) < 1e-5 and maxerr(e, ref_e) < 1e-5      # parameters identical on all ranks and equal to the global run
-        assert maxerr(rv, ref_rv) < 1e-5
-    assert torch.equal(r0[1], r1[1])
+    return torch.load(f"{out}.rank0"), torch.load(f"{out}.rank1")
+
+
+@pytest.mark.parametrize("step,overlap", [("mt", True), ("mt", False), ("cps", True), ("cps", False), ("hpfg", True), ("hpfg", False)])
+def test_two_ranks_equal_the_global_batch(tmp_path, step, overlap):
+    r0, r1 = _two_ranks(tmp_path, f"{step}{int(overlap)}", HPFG_TEST_STEP=step, HPFG_TEST_OVERLAP=int(overlap), HPFG_TEST_SYNC_BN=1)
+    ref = W.run(DEV, None, 0, 1, step=step)
+    for got in (r0, r1):
+        assert maxerr(got[0], ref[0]) < 1e-5, (got[0], ref[0])          # loss parts are normalised by the GLOBAL counts on every rank
+        for a, b in zip(got[1:], ref[1:]):
+            assert maxerr(a, b) < 1e-5                                   # parameters (both students, teacher) / running statistics
+    assert torch.equal(r0[1], r1[1]) and torch.equal(r0[2], r1[2])
+
+
+@pytest.mark.parametrize("step", ["mt", "cps", "hpfg"])
+def test_per_rank_batchnorm_mode_averages_the_shard_gradients(tmp_path, step):
+    """sync_bn = False: every rank is the single-GPU run on its own shard up to the gradient, which is averaged.  One SGD step from the
+    same weights is linear in the gradient, so the parameters must equal the mean of the two single-process shard runs; the BatchNorm
+    running statistics stay each rank's own."""
+    r0, r1 = _two_ranks(tmp_path, f"ddp_{step}", HPFG_TEST_STEP=step, HPFG_TEST_OVERLAP=0, HPFG_TEST_SYNC_BN=0, HPFG_TEST_STEPS=1)
+    s0 = W.run(DEV, None, 0, 1, steps=1, step=step, shard=(0, 2))
+    s1 = W.run(DEV, None, 0, 1, steps=1, step=step, shard=(1, 2))
+    assert torch.equal(r0[1], r1[1])                                     # the ranks stay in lockstep
+    assert maxerr(r0[1], 0.5 * (s0[1] + s1[1])) < 2e-6
+    if step != "mt":
+        assert torch.equal(r0[2], r1[2])
+        if step == "cps":
+            assert maxerr(r0[2], 0.5 * (s0[2] + s1[2])) < 2e-6          # (HPFG: model2 is also pulled towards model1 by the backbone EMA -- still linear)
+        else:
+            assert maxerr(r0[2], 0.5 * (s0[2] + s1[2])) < 2e-6
+    assert maxerr(r0[0], s0[0]) < 1e-6 and maxerr(r1[0], s1[0]) < 1e-6   # per-rank losses ARE the shard runs' losses
+
+
+@pytest.mark.parametrize("step,overlap", [("mt", True), ("mt", False), ("cps", False), ("hpfg", False)])
+def test_per_rank_mode_graph_chain_equals_eager(tmp_path, step, overlap):
+    """What bench.py runs for N > 1: [forward + loss + backward] | eager gradient exchange | [SGD + EMA] as hipGraphs (with the bucket
+    chain for the one-network step when overlap is on) -- same parameters as the eager two-rank run of the same two iterations."""
+    common = dict(HPFG_TEST_STEP=step, HPFG_TEST_OVERLAP=int(overlap), HPFG_TEST_SYNC_BN=0, HPFG_TEST_STEPS=2)
+    g0, g1 = _two_ranks(tmp_path, f"g_{step}{int(overlap)}", HPFG_TEST_GRAPH=1, **common)
+    e0, e1 = _two_ranks(tmp_path, f"e_{step}{int(overlap)}", HPFG_TEST_GRAPH=0, HPFG_TEST_FIXED=1, **common)
+    assert torch.equal(g0[1], g1[1])
+    for a, b in zip(g0[1:], e0[1:]):
+        assert maxerr(a, b) < 1e-6
+    assert maxerr(g0[0][-1], e0[0][-1]) < 1e-6
