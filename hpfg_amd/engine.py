@@ -158,8 +158,9 @@ class UNetEngine:
         # thin 3x3 layers (16-pixel-aligned, <= 64 input / 32 output channels, split-bf16 math): ONE kernel produces the input gradient, the
         # weight-gradient slabs and the backward sums of the layer below from a single staging of dZ (hpfg_fused_bwd)
         self.fused_bwd = os.environ.get("HPFG_FUSED_BWD", "1") == "1"
-        # set by the model (UNet.defer_wgrad, which the single-network step objects switch on): with two trainable networks back-propagating on
-        # two streams the extra fork inside each of them made the hipGraph capture of the HPFG step crash and the CTCT graph slower
+        # set by the model (UNet.defer_wgrad, which the single-network step objects switch on).  Not with two trainable networks
+        # back-propagating on two streams: the fork below would then leave a FORKED stream, and an event wait between two non-origin
+        # streams of a capture makes hipStreamEndCapture fault on ROCm 7.2 (tools/nested_fork_probe.py reproduces it without this code)
         self.defer_wgrad = False
         self._deferred = None
         self.fused_grid: Dict[str, int] = {}

@@ -155,9 +155,13 @@ class _StepBase:
 
     def _attach(self, model, alone: bool = False):
         """alone: the only trainable network of the step -- its backward may fork its off-chain weight gradients onto a side stream
-        (UNetEngine.backward); with two networks training on two streams that extra fork is not taken (see engine.py)."""
+        (UNetEngine.backward).  Not with two networks training on two streams: the second network's backward runs on a FORKED stream, and
+        an event wait between two non-origin streams of a capture makes hipStreamEndCapture fault on this stack (ROCm 7.2; 15-line
+        reproduction without any of this repository's code: tools/nested_fork_probe.py -- origin -> A, origin -> B, B waits for A, both
+        joined: segmentation fault in capture_end; every fork / join against the origin stream itself is fine).  So inside a capture every
+        side stream forks from and joins into the stream the capture began on, and nothing else."""
         model.dp = self.dp
-        if alone or os.environ.get("HPFG_DEFER_ALL", "0") == "1":      # (HPFG_DEFER_ALL: also for the networks of a two-network step, A/B runs)
+        if alone:
             model.defer_wgrad = True
         if any(p.requires_grad for p in model.parameters()):
             model.direct_grads = True          # one zero_grad + one backward per step: write gradients in place (no memset, no add)
