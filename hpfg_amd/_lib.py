@@ -44,6 +44,11 @@ class WgradArgs(C.Structure):
                 ("W", C.c_int32), ("taps", C.c_int32), ("S", C.c_int32), ("math", C.c_int32), ("defer_reduce", C.c_int32)]
 
 
+class PeerX(C.Structure):
+    _fields_ = [("mbox", C.c_void_p * 8), ("epoch", C.c_void_p), ("err", C.c_void_p), ("world", C.c_int32), ("rank", C.c_int32),
+                ("slot", C.c_int32), ("cap", C.c_int32), ("slot_bytes", C.c_int64)]
+
+
 class FusedBwdArgs(C.Structure):
     _fields_ = [("d", ConvArgs), ("xa0", Act), ("xa1", Act), ("slab", C.c_void_p), ("Cin", C.c_int32), ("CinPad", C.c_int32),
                 ("Cout", C.c_int32), ("CoutPad", C.c_int32)]
@@ -105,6 +110,16 @@ PROTOTYPES = {
     "hpfg_wgrad": (_i, [C.POINTER(WgradArgs), _p]),
     "hpfg_fused_bwd": (_i, [C.POINTER(FusedBwdArgs), _p]),
     "hpfg_fused_bwd_grid": (_i, [C.POINTER(FusedBwdArgs)]),
+    "hpfg_peer_slot_bytes": (_l, [_i, _i]),
+    "hpfg_peer_alloc": (_i, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "hpfg_peer_free": (_i, [_p]),
+    "hpfg_peer_handle": (_i, [_p, C.c_char_p]),
+    "hpfg_peer_open": (_i, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "hpfg_peer_close": (_i, [_p]),
+    "hpfg_word_add": (_i, [_p, _i, _p]),
+    "hpfg_bn_fwd_finalize_x": (_i, [_p, _i, C.POINTER(PeerX), _d, _p, _p, _p, _p, _f, _f, _p, _i, _p]),
+    "hpfg_bn_bwd_finalize_x": (_i, [_p, _i, C.POINTER(PeerX), _d, _p, _p, _p, _p, _i, _f, _p]),
+    "hpfg_seg_loss_partials_x": (_i, [C.POINTER(LossArgs), C.POINTER(PeerX), _p]),
     "hpfg_slab_reduce_multi": (_i, [_p, C.POINTER(SlabDesc), _i, _p]),
     "hpfg_wgrad_splits": (_i, [_i, _i, _i, _i, _i, _i]),
     "hpfg_wgrad_slab_floats": (_l, [_i, _i, _i, _i, _i, _i]),

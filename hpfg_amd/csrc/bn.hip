@@ -11,7 +11,9 @@
 //           k1 = gamma*rstd, k2 = -gamma*rstd^2*m2, k3 = gamma*rstd*(mean*rstd*m2 - m1)  so that dz = k1*g + k2*z + k3,
 //           which the dgrad / wgrad loaders evaluate on the fly (HPFG_ACT_DZ).
 // Data parallel: hpfg_reduce_partials gives fp64 [2][C] sums to all-reduce; finalize then takes `sums` instead of partials.
+#include <string.h>
 #include "common.h"
+#include "peer.h"
 
 namespace {
 
@@ -78,7 +80,7 @@ struct HpfgBnFinalizeArgs {
   float* bn;
 };
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(HpfgBnFinalizeArgs q, int nblk, const double* __restrict__ sums, double count, float momentum,
-                                                              float eps, int C) {
+                                                              float eps, int C, HpfgPeerX px) {
   __shared__ double sh[8];
   const float* __restrict__ partials = q.partials;
   const float* __restrict__ gamma = q.gamma;
@@ -97,6 +99,13 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(HpfgBnFinalizeArgs
     sum_partials(partials, nblk, C, c, s1, s2, sh);
   }
   if (threadIdx.x == 0) {
+    if (px.world > 1) {          // data parallel, global-batch mode: add the ranks' sums of this channel (peer mailbox, rank order)
+      const int idx[2] = {c, C + c};
+      double v[2] = {s1, s2};
+      hpfg_peer_allreduce<2>(px, idx, v);
+      s1 = v[0];
+      s2 = v[1];
+    }
     double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(HpfgAct s, cons
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, const double* __restrict__ sums,
                                                               double count, const float* __restrict__ gamma, float* __restrict__ bn,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int C, float pscale) {
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int C, float pscale, HpfgPeerX px) {
   __shared__ double sh[8];
   const int c = blockIdx.x;
   const double mean = bn[HPFG_BN_MEAN * C + c], rstd = bn[HPFG_BN_RSTD * C + c], ga = gamma[c];
@@ -264,6 +273,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     sum_partials(partials, nblk, C, c, sg, sgx, sh);
   }
   if (threadIdx.x == 0) {
+    if (px.world > 1) {
+      const int idx[2] = {c, C + c};
+      double v[2] = {sg, sgx};
+      hpfg_peer_allreduce<2>(px, idx, v);
+      sg = v[0];
+      sgx = v[1];
+    }
     double m1 = sg / count, m2 = sgx / count;
     bn[HPFG_BN_K1 * C + c] = (float)(ga * rstd);
     bn[HPFG_BN_K2 * C + c] = (float)(-ga * rstd * rstd * m2);
@@ -301,7 +317,30 @@ extern "C" int hpfg_bn_fwd_finalize(const float* partials, int nblk, const doubl
   HPFG_ARG_CHECK((partials && nblk > 0) || sums, "bn_fwd_finalize: need partials or sums");
   HPFG_ARG_CHECK(gamma && beta && bn && C > 0 && count > 0, "bn_fwd_finalize: bad args");
   const HpfgBnFinalizeArgs q{partials, gamma, beta, running_mean, running_var, bn};
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, q, nblk, sums, count, momentum, eps, C);
+  HpfgPeerX none;
+  memset(&none, 0, sizeof(none));
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, q, nblk, sums, count, momentum, eps, C, none);
+  return hpfg_launch_status("bn_fwd_finalize_kernel");
+}
+
+static int check_px(const HpfgPeerX* px, int C, const char* who) {
+  HPFG_ARG_CHECK(px, "%s: null exchange descriptor", who);
+  if (px->world <= 1) return 0;
+  HPFG_ARG_CHECK(px->world <= HPFG_PEER_MAX_RANKS && px->rank >= 0 && px->rank < px->world && px->epoch && px->slot >= 0 && 2 * C <= px->cap &&
+                     px->slot_bytes == hpfg_peer_slot_bytes(px->world, px->cap),
+                 "%s: bad exchange descriptor (world %d rank %d cap %d for 2 x %d values)", who, px->world, px->rank, px->cap, C);
+  for (int r = 0; r < px->world; ++r) HPFG_ARG_CHECK(px->mbox[r], "%s: mailbox of rank %d not mapped", who, r);
+  return 0;
+}
+
+extern "C" long hpfg_peer_slot_bytes(int world, int cap) { return (long)2 * world * cap * (long)(sizeof(double) + sizeof(uint32_t)); }
+
+extern "C" int hpfg_bn_fwd_finalize_x(const float* partials, int nblk, const HpfgPeerX* px, double count, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, float momentum, float eps, float* bn, int C, void* stream) {
+  HPFG_ARG_CHECK(partials && nblk > 0 && gamma && beta && bn && C > 0 && count > 0, "bn_fwd_finalize_x: bad args");
+  if (int rc = check_px(px, C, "bn_fwd_finalize_x")) return rc;
+  const HpfgBnFinalizeArgs q{partials, gamma, beta, running_mean, running_var, bn};
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, q, nblk, nullptr, count, momentum, eps, C, *px);
   return hpfg_launch_status("bn_fwd_finalize_kernel");
 }
 
@@ -352,7 +391,18 @@ extern "C" int hpfg_bn_bwd_finalize(const float* partials, int nblk, const doubl
                                     float* dgamma, float* dbeta, int C, float param_grad_scale, void* stream) {
   HPFG_ARG_CHECK((partials && nblk > 0) || sums, "bn_bwd_finalize: need partials or sums");
   HPFG_ARG_CHECK(gamma && bn && C > 0 && count > 0, "bn_bwd_finalize: bad args");
+  HpfgPeerX none;
+  memset(&none, 0, sizeof(none));
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nblk, sums, count, gamma, bn, dgamma, dbeta, C,
-                     param_grad_scale);
+                     param_grad_scale, none);
+  return hpfg_launch_status("bn_bwd_finalize_kernel");
+}
+
+extern "C" int hpfg_bn_bwd_finalize_x(const float* partials, int nblk, const HpfgPeerX* px, double count, const float* gamma, float* bn, float* dgamma,
+                                      float* dbeta, int C, float param_grad_scale, void* stream) {
+  HPFG_ARG_CHECK(partials && nblk > 0 && gamma && bn && C > 0 && count > 0, "bn_bwd_finalize_x: bad args");
+  if (int rc = check_px(px, C, "bn_bwd_finalize_x")) return rc;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nblk, nullptr, count, gamma, bn, dgamma, dbeta, C,
+                     param_grad_scale, *px);
   return hpfg_launch_status("bn_bwd_finalize_kernel");
 }

@@ -717,13 +717,9 @@ int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
     // on 256->128 @28; a 128-wide slice (two channel tiles per wave, shallow B ring) is slower again.
     const char* f = getenv("HPFG_SMALL_BN");
     const int force = f ? atoi(f) : 0;
-    // a layer whose 64-wide slices give fewer workgroups than `few` (the 14 x 14 layers: 64 tiles x Cout / 64 = 128 ... 256 workgroups for
-    // 256 CUs, one wave per SIMD) takes 32-wide slices instead: twice the workgroups, two waves per SIMD
-    static const long few = getenv("HPFG_FEW_WG") ? atol(getenv("HPFG_FEW_WG")) : 0;
-    const long wg64 = (long)a.N * ((a.H + 3) / 4) * ((a.W + 15) / 16) * (cp / 64);
     if (force != 999) {
       if (cp % 128 == 0 && force == 128) return launch_cfg<Cfg<4, 16, 1, 4, 2, TAPS, 32>, KIND>(a, st, rows_only);
-      if (cp % 64 == 0 && force != 32 && !(few > 0 && wg64 < few)) return launch_cfg<Cfg<4, 16, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only);
+      if (cp % 64 == 0 && force != 32) return launch_cfg<Cfg<4, 16, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only);
       if (cp % 32 == 0) return launch_cfg<Cfg<4, 16, 2, 2, 1, TAPS, 32>, KIND>(a, st, rows_only);
       return launch_cfg<Cfg<4, 16, 4, 1, 1, TAPS, 32>, KIND>(a, st, rows_only);
     }

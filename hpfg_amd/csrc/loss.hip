@@ -11,7 +11,9 @@
 // Dice is a ratio of batch-wide sums, so the op is two-phase: (1) partial sums -> sums (all-reduce them across ranks for
 // data parallel), finalize -> scalars; (2) backward re-reads the logits and writes dlogits from the global sums.
 // Nothing here synchronises with the host; the reference's per-class dice.item() (diceloss.py:189) has no counterpart.
+#include <string.h>
 #include "common.h"
+#include "peer.h"
 
 namespace {
 
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void loss_partials_kernel(HpfgLossArgs a, long
   if (tid < NS) a.partials[(long)blockIdx.x * NS + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
-__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ sums) {
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ sums, HpfgPeerX px) {
   __shared__ double sh[4];
   const int i = blockIdx.x;
   double v = 0.0;
@@ -149,7 +151,14 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0) sums[i] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+  if (threadIdx.x == 0) {
+    double t[1] = {sh[0] + sh[1] + sh[2] + sh[3]};
+    if (px.world > 1) {          // data parallel, global-batch mode: the ranks' sums of this term (peer mailbox, rank order)
+      const int idx[1] = {i};
+      hpfg_peer_allreduce<1>(px, idx, t);
+    }
+    sums[i] = (float)t[0];
+  }
 }
 
 __device__ inline float dice_of(const float* s, int base, int C) {
@@ -275,15 +284,30 @@ static int check_loss(const HpfgLossArgs* a) {
   return 0;
 }
 
-extern "C" int hpfg_seg_loss_partials(const HpfgLossArgs* a, void* stream) {
+static int loss_partials_impl(const HpfgLossArgs* a, const HpfgPeerX* px, void* stream) {
   if (int rc = check_loss(a)) return rc;
   HPFG_ARG_CHECK(a->partials, "seg_loss_partials: workspace missing");
   int nblk = hpfg_loss_blocks(a->N, a->H, a->W);
   if (a->C == 4) hipLaunchKernelGGL(loss_partials_kernel<4>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a, (long)a->H * a->W);
   else if (a->C == 3) hipLaunchKernelGGL(loss_partials_kernel<3>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a, (long)a->H * a->W);
   else hipLaunchKernelGGL(loss_partials_kernel<2>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a, (long)a->H * a->W);
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(NS), dim3(256), 0, (hipStream_t)stream, a->partials, nblk, a->sums);
+  HpfgPeerX none;
+  memset(&none, 0, sizeof(none));
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(NS), dim3(256), 0, (hipStream_t)stream, a->partials, nblk, a->sums, px ? *px : none);
   return hpfg_launch_status("loss_partials_kernel");
+}
+
+extern "C" int hpfg_seg_loss_partials(const HpfgLossArgs* a, void* stream) { return loss_partials_impl(a, nullptr, stream); }
+
+extern "C" int hpfg_seg_loss_partials_x(const HpfgLossArgs* a, const HpfgPeerX* px, void* stream) {
+  HPFG_ARG_CHECK(px, "seg_loss_partials_x: null exchange descriptor");
+  if (px->world > 1) {
+    HPFG_ARG_CHECK(px->world <= HPFG_PEER_MAX_RANKS && px->rank >= 0 && px->rank < px->world && px->epoch && px->slot >= 0 && NS <= px->cap &&
+                       px->slot_bytes == hpfg_peer_slot_bytes(px->world, px->cap),
+                   "seg_loss_partials_x: bad exchange descriptor");
+    for (int r = 0; r < px->world; ++r) HPFG_ARG_CHECK(px->mbox[r], "seg_loss_partials_x: mailbox of rank %d not mapped", r);
+  }
+  return loss_partials_impl(a, px, stream);
 }
 
 extern "C" int hpfg_seg_loss_finalize(const HpfgLossArgs* a, void* stream) {

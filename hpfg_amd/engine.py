@@ -170,6 +170,10 @@ class UNetEngine:
         self.math = L.MATH_F32      # L.MATH_BF16X3 selects the split-bf16 matrix-core kernels for conv forward / dgrad
         self.ext_masks: Dict[str, torch.Tensor] = {}   # conv name -> uint8 NHWC keep-mask (parity tests replaying torch's masks)
         self.allreduce = None    # callable(tensor) -> in-place sum across ranks (data parallel), set by hpfg_amd.parallel
+        # peer mailbox exchange (hpfg_amd.parallel.DataParallelContext.enable_peer_exchange): the finalize kernels add the ranks' sums
+        # themselves -- no collective between the kernels.  peer = the context, peer_base = first of this engine's 2 x 18 mailbox slots,
+        # xepoch = device word counting this engine's train-mode forwards (the epoch of every slot use of that forward / its backward)
+        self.peer, self.peer_base, self.xepoch = None, 0, None
         self._skip_fin, self._fin_done = os.environ.get("HPFG_SKIP_FINALIZE", "0") == "1", {}
         self.marks: Optional[MarkLog] = None      # bench.py: device time stamps around every conv / dgrad / wgrad / BatchNorm launch
 
@@ -182,6 +186,11 @@ class UNetEngine:
         if self.marks is None:
             return launch()
         return self.marks.bracket(tag, self._stream() if stream is None else stream, launch)
+
+    def _bn_index(self, s: ConvSpec) -> int:
+        if not hasattr(self, "_bn_idx"):
+            self._bn_idx = {t.name: i for i, t in enumerate(t for t in self.order if t.bn)}
+        return self._bn_idx[s.name]
 
     def layer_seed(self, s: ConvSpec) -> int:
         return (self.base_seed * 0x9E3779B1 + 0x85EBCA6B * (s.idx + 1)) & 0xFFFFFFFF
@@ -284,7 +293,12 @@ class UNetEngine:
         g, b = self.params[f"{s.bn}.weight"], self.params[f"{s.bn}.bias"]
         rm = self.buffers[f"{s.bn}.running_mean"] if track else None
         rv = self.buffers[f"{s.bn}.running_var"] if track else None
-        if self.world > 1 or self.force_sync:
+        if self.peer is not None and (self.world > 1 or self.force_sync):
+            px = self.peer.peer_desc(self.peer_base + 2 * self._bn_index(s), self.xepoch)
+            self._run("bn_fin:" + s.name, lambda: L.check(self.lib.hpfg_bn_fwd_finalize_x(
+                L.ptr(self.partials), nblk, C.byref(px), count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), BN_MOMENTUM, BN_EPS, L.ptr(self.bn[s.name]),
+                s.cout, st), "bn_fwd_finalize_x"))
+        elif self.world > 1 or self.force_sync:
             sums = self.sums[: 2 * s.cout_pad]
             L.check(self.lib.hpfg_reduce_partials(L.ptr(self.partials), nblk, s.cout_pad, L.ptr(sums), st), "reduce_partials")
             self.allreduce(sums)
@@ -308,6 +322,8 @@ class UNetEngine:
         self.pack(with_dgrad=bool(train and needs_grad), counters=counters, seed_add=1 if seed_step == SEED_BUMP else 0)
         if self.marks is not None:
             self.marks.calib(self._stream())
+        if train and self.peer is not None and (self.world > 1 or self.force_sync):
+            self.peer.bump(self.xepoch, self._stream())      # the epoch of this forward's (and its backward's) mailbox exchanges
         return torch.empty(self.N, self.H, self.W, self.ncls, dtype=torch.float32, device=self.dev)
 
     def _conv_args(self, s: ConvSpec, out: torch.Tensor, want_stats: bool) -> L.ConvArgs:
@@ -473,7 +489,12 @@ class UNetEngine:
         if self._skip_fin and self._fin_done.get("b:" + s.name):
             return g
         self._fin_done["b:" + s.name] = True
-        if self.world > 1 or self.force_sync:
+        if self.peer is not None and (self.world > 1 or self.force_sync):
+            px = self.peer.peer_desc(self.peer_base + 2 * self._bn_index(s) + 1, self.xepoch)
+            self._run("bn_bfin:" + s.name, lambda: L.check(self.lib.hpfg_bn_bwd_finalize_x(
+                L.ptr(self.partials), nblk, C.byref(px), count, L.ptr(gam), L.ptr(self.bn[s.name]), L.ptr(dg), L.ptr(db), s.cout, 1.0 / self.world, st),
+                "bn_bwd_finalize_x"))
+        elif self.world > 1 or self.force_sync:
             sums = self.sums[: 2 * s.cout]
             L.check(self.lib.hpfg_reduce_partials(L.ptr(self.partials), nblk, s.cout, L.ptr(sums), st), "reduce_partials")
             self.allreduce(sums)

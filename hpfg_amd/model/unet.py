@@ -306,6 +306,9 @@ class UNet(nn.Module):
         if self.dp is not None and getattr(self.dp, "sync_bn", True):
             eng.world, eng.allreduce = self.dp.world_size, self.dp.allreduce_sum
             eng.force_sync = bool(getattr(self.dp, "force_sync", False))
+            if getattr(self.dp, "p2p", False) and eng.peer is None:      # BatchNorm sums cross the ranks inside the finalize kernels (peer mailboxes)
+                eng.peer, eng.peer_base = self.dp, self.dp.alloc_slots(2 * 18)
+                eng.xepoch = torch.zeros(1, dtype=torch.int32, device=x.device)
         return eng
 
     def _accumulate_grads(self, eng: E.UNetEngine):

@@ -13,10 +13,16 @@ The reference is single-process / single-device (main.py:44 says so); sharding i
      twice per model and step.
 EMA, SGD and the LR/ramp-up scalars stay per rank (parameters are bit-identical after the reduced step).
 
+The ~90 small exchanges of (1) and (2) per step are latency-bound as collectives (tens of microseconds of launch + ring latency each,
+and no collective may sit inside a captured hipGraph: RCCL's watchdog thread polls its events during a capture).  With
+`enable_peer_exchange()` they are not collectives at all: the kernels that finalize a BatchNorm layer / reduce the loss sums write
+their per-channel sums into every peer's MAILBOX (fine-grained device memory mapped through hipIpc: xGMI stores between the GPUs of a
+node) and add the peers' values from their own mailbox in rank order (csrc/peer.h) -- no host code between the kernels, so the whole
+forward + loss + backward stays one hipGraph and only the gradient all-reduce (3) is an RCCL call, between two graphs.
+
 `sync_bn=False` selects the usual DistributedDataParallel semantics instead: BatchNorm statistics and the loss are per rank
 (every rank sees exactly what the single-GPU reference run sees: its own 8+8 batch), and the only exchange is the gradient
-all-reduce, averaged over ranks.  That removes the ~90 latency-bound 2*C-element collectives per step, which cannot be captured
-into a hipGraph here (the RCCL watchdog rejects stream capture) and bound the multi-GPU step; bench.py uses it for N > 1.
+all-reduce, averaged over ranks; bench.py uses it for N > 1 unless --sync-bn is given.
 """
 from __future__ import annotations
 
@@ -39,6 +45,16 @@ class DataParallelContext:
         self.bucket_hook = None     # GraphedStep sets it while capturing: a bucket boundary then ends one hipGraph and starts the next
         self._side = None
         self._pending = False
+        # peer mailbox exchange (enable_peer_exchange): BatchNorm / loss sums cross the ranks inside the kernels
+        self.p2p = False
+        self._mbox = None            # this rank's mailbox (raw device pointer), _peers[r] = rank r's mailbox as mapped here
+        self._peers = []
+        self._slots_used = 0
+        self.peer_cap = 512          # payload values per rank in a slot: [2][C <= 256]
+        self.peer_slots = 0
+        self.peer_err = None         # device int32 word: set by a kernel whose poll for a peer's value expired
+        self.loss_slot = -1
+        self.loss_epoch = None
 
     @property
     def active(self) -> bool:
@@ -85,7 +101,83 @@ class DataParallelContext:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
+    # ---- peer mailbox exchange ----------------------------------------------------------------------------------------------------------
+    def enable_peer_exchange(self, n_slots: int = 256):
+        """Allocate this rank's mailbox, exchange the IPC handles over the process group and map every peer's mailbox.  Collective: all
+        ranks call it, once, before the first forward.  With one rank it only switches the code path on (the kernels skip the exchange)."""
+        import ctypes as C
+        from . import _lib as L
+        if self.p2p:
+            return
+        if self.world_size > 8:
+            raise RuntimeError("peer mailbox exchange serves one node (<= 8 ranks)")
+        if self.device is None or self.device.type != "cuda":
+            raise RuntimeError("peer mailbox exchange needs CUDA (HIP) devices")
+        lib = L.load()
+        self.peer_slots = n_slots
+        self._slot_bytes = lib.hpfg_peer_slot_bytes(self.world_size, self.peer_cap)
+        self.peer_err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.loss_epoch = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._peers = [None] * self.world_size
+        if self.world_size > 1:
+            torch.cuda.set_device(self.device)
+            ptr = C.c_void_p()
+            L.check(lib.hpfg_peer_alloc(self._slot_bytes * n_slots, C.byref(ptr)), "peer_alloc")
+            self._mbox = ptr.value
+            h = C.create_string_buffer(64)
+            L.check(lib.hpfg_peer_handle(self._mbox, h), "peer_handle")
+            handles = [None] * self.world_size
+            dist.all_gather_object(handles, bytes(h.raw), group=self.group)
+            for r, hr in enumerate(handles):
+                if r == self.rank:
+                    self._peers[r] = self._mbox
+                    continue
+                q = C.c_void_p()
+                L.check(lib.hpfg_peer_open(C.create_string_buffer(hr, 64), C.byref(q)), f"peer_open[{r}]")
+                self._peers[r] = q.value
+            dist.barrier(group=self.group)          # every mailbox is mapped everywhere before any kernel stores into one
+        self.p2p = True
+        self.loss_slot = self.alloc_slots(1)
+
+    def alloc_slots(self, n: int) -> int:
+        """First of n consecutive mailbox slots (the same numbers on every rank: engines are built in the same order everywhere)."""
+        base = self._slots_used
+        self._slots_used += n
+        if self._slots_used > self.peer_slots:
+            raise RuntimeError(f"peer mailbox: out of slots ({self._slots_used} > {self.peer_slots})")
+        return base
+
+    def peer_desc(self, slot: int, epoch: torch.Tensor):
+        """HpfgPeerX for one exchange: `epoch` = the device int32 word that counts the uses of `slot` (bumped BEFORE the exchanging kernel)."""
+        from . import _lib as L
+        px = L.PeerX()
+        px.world, px.rank, px.slot, px.cap, px.slot_bytes = self.world_size, self.rank, slot, self.peer_cap, self._slot_bytes
+        px.epoch, px.err = epoch.data_ptr(), self.peer_err.data_ptr()
+        for r in range(self.world_size):
+            px.mbox[r] = self._peers[r]
+        return px
+
+    def bump(self, epoch: torch.Tensor, stream: int):
+        from . import _lib as L
+        L.check(L.load().hpfg_word_add(epoch.data_ptr(), 1, stream), "word_add")
+
+    def check_peer_errors(self):
+        """Raise if a kernel gave up waiting for a peer's value (synchronises)."""
+        if self.p2p and self.peer_err is not None and int(self.peer_err.item()) != 0:
+            raise RuntimeError("peer mailbox exchange: a poll for a peer's value expired (a rank is missing or far behind)")
+
     def shutdown(self):
+        if self.p2p and self.world_size > 1 and self._mbox is not None:
+            from . import _lib as L
+            lib = L.load()
+            torch.cuda.synchronize(self.device)
+            if dist.is_initialized():
+                dist.barrier(group=self.group)      # nobody unmaps a mailbox a peer's kernel may still store into
+            for r, q in enumerate(self._peers):
+                if r != self.rank and q:
+                    lib.hpfg_peer_close(q)
+            lib.hpfg_peer_free(self._mbox)
+            self._mbox, self._peers, self.p2p = None, [], False
         if dist.is_initialized():
             dist.destroy_process_group()
 

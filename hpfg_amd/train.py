@@ -775,11 +775,13 @@ class GraphedStep:
         before_capture: optional callable run between the eager warm-up steps and the capture (bench.py resets its time-stamp logs there)."""
         self.s = step_obj
         dp0 = getattr(step_obj, "dp", None)
-        if dp0 is not None and getattr(dp0, "sync_bn", True) and (dp0.world_size > 1 or dp0.force_sync):
+        host_gather = isinstance(step_obj, HPFGStep)      # (its Dense_Loss all-gathers the neck features with a host-launched collective)
+        if dp0 is not None and getattr(dp0, "sync_bn", True) and (dp0.world_size > 1 or dp0.force_sync) and (not getattr(dp0, "p2p", False) or host_gather):
             # all-reduced BatchNorm statistics = a collective between the kernels of every layer: those never sit inside a captured region
             # (RCCL's watchdog thread polls its events while a capture is open; losing that race aborted the process)
             raise RuntimeError("GraphedStep: a step with collectives between its kernels (data parallel with sync_bn=True) is not captured into a "
-                               "hipGraph; run it eager, or use sync_bn=False (per-rank BatchNorm: collectives only between graphs)")
+                               "hipGraph; run it eager, enable the peer mailbox exchange (DataParallelContext.enable_peer_exchange: the sums then cross "
+                               "the ranks inside the kernels), or use sync_bn=False (per-rank BatchNorm: collectives only between graphs)")
         self.alias = bool(alias_inputs)
         self.static = list(example_inputs) if self.alias else [t.clone() for t in example_inputs]
         self.graph = torch.cuda.CUDAGraph()
@@ -799,7 +801,9 @@ class GraphedStep:
         self._freeze_seed_updates(True)
         # thread_local: another thread's HIP calls (the RCCL watchdog polling its events) must not invalidate this capture
         dp = getattr(step_obj, "dp", None)
-        self.split = bool(dp is not None and not getattr(dp, "sync_bn", True) and (dp.world_size > 1 or dp.force_sync))
+        # data parallel: the gradient exchange is never captured -- [forward + loss + backward] | eager all-reduce(s) | [update] as a chain of
+        # graphs, in the per-rank BatchNorm mode and (BatchNorm / loss sums exchanged by the kernels through peer mailboxes) the global-batch mode
+        self.split = bool(dp is not None and (dp.world_size > 1 or dp.force_sync))
         if self.split and not hasattr(step_obj, "device_fwd_bwd"):
             raise RuntimeError(f"GraphedStep: {type(step_obj).__name__} has no device_fwd_bwd / exchange / device_update split, so its gradient "
                                "exchange would be captured into the graph; run it eager under data parallel")

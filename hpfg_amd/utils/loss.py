@@ -67,9 +67,14 @@ class _SegLossFn(torch.autograd.Function):
                 raise ValueError("cons_mask needs a consistency target and one weight per unlabelled pixel")
             a.cons_mask = L.ptr(cm)
         st = torch.cuda.current_stream(dev).cuda_stream
-        L.check(lib.hpfg_seg_loss_partials(C.byref(a), st), "seg_loss_partials")
-        if dp is not None and (dp.world_size > 1 or dp.force_sync):
-            dp.allreduce_sum(sums)
+        if dp is not None and getattr(dp, "p2p", False) and (dp.world_size > 1 or dp.force_sync):
+            dp.bump(dp.loss_epoch, st)          # the ranks' loss sums are added by the reduction kernel itself (peer mailboxes)
+            px = dp.peer_desc(dp.loss_slot, dp.loss_epoch)
+            L.check(lib.hpfg_seg_loss_partials_x(C.byref(a), C.byref(px), st), "seg_loss_partials_x")
+        else:
+            L.check(lib.hpfg_seg_loss_partials(C.byref(a), st), "seg_loss_partials")
+            if dp is not None and (dp.world_size > 1 or dp.force_sync):
+                dp.allreduce_sum(sums)
         L.check(lib.hpfg_seg_loss_finalize(C.byref(a), st), "seg_loss_finalize")
         ctx.args, ctx.keep = a, (x, t, labels0, labels1, coef, sums, cm)
         ctx.shape = (N, H, W, Cc)

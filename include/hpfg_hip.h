@@ -197,6 +197,37 @@ int hpfg_upsample2x_bwd(const float* dUp, int dup_pstride, float* dU, int N, int
 int hpfg_upsample2x_bwd_sums(const float* dUp, int dup_pstride, float* dU, int N, int Hl, int Wl, int C, float* csum_partials, void* stream);
 int hpfg_upsample2x_bwd_blocks(int N, int Hl, int Wl, int C);
 
+/* ---- data parallel: peer mailbox exchange (csrc/peer.h) ------------------------------------------------------------------------
+ * The reference is single-device (main.py:44); under data parallel in the global-batch mode every BatchNorm layer's sums and the loss sums
+ * must be added over the ranks between two kernels of the step.  Instead of ~90 latency-bound collectives per step, the kernel that
+ * produces a sum exchanges it itself: it stores the value into every peer's mailbox (IPC-mapped fine-grained memory: xGMI between the
+ * GPUs of a node), then reads the peers' values from its own mailbox and adds them in rank order.  No host code between the kernels,
+ * so the step stays capturable into a hipGraph. */
+#define HPFG_PEER_MAX_RANKS 8
+#define HPFG_PEER_HANDLE_BYTES 64
+#define HPFG_PEER_MAX_SPINS (1L << 22)      /* bounded poll (a few seconds): on expiry *err = 1 and the kernel carries on */
+typedef struct HpfgPeerX {
+  void* mbox[HPFG_PEER_MAX_RANKS];   /* mbox[r] = rank r's mailbox as mapped in this process (mbox[rank] = its own); unused entries NULL */
+  const int32_t* epoch;              /* device word: the use count of `slot` (consecutive integers >= 1, the same on every rank) */
+  int32_t* err;                      /* device word set to 1 when a poll expires (or NULL) */
+  int32_t world, rank;               /* world <= 1: no exchange (the struct may be all zero) */
+  int32_t slot, cap;                 /* slot index; cap = payload values per rank and parity in a slot */
+  int64_t slot_bytes;                /* hpfg_peer_slot_bytes(world, cap) */
+} HpfgPeerX;
+long hpfg_peer_slot_bytes(int world, int cap);
+int hpfg_peer_alloc(size_t bytes, void** ptr);                       /* zero-filled fine-grained device memory */
+int hpfg_peer_free(void* ptr);
+int hpfg_peer_handle(void* ptr, unsigned char* handle64);            /* HPFG_PEER_HANDLE_BYTES to send to the peers */
+int hpfg_peer_open(const unsigned char* handle64, void** ptr);       /* map a peer's mailbox */
+int hpfg_peer_close(void* ptr);
+int hpfg_word_add(int32_t* word, int v, void* stream);               /* *word = (*word + v) & 0x7fffffff: the epoch bump, stream-ordered */
+/* hpfg_bn_fwd_finalize / hpfg_bn_bwd_finalize / hpfg_seg_loss_partials with the cross-rank SUM of the per-channel (per-term) sums done by the
+ * kernel itself (px->world > 1); `count` / the loss counts are the GLOBAL ones, param_grad_scale = 1 / world as with all-reduced sums */
+int hpfg_bn_fwd_finalize_x(const float* partials, int nblk, const HpfgPeerX* px, double count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* bn, int C, void* stream);
+int hpfg_bn_bwd_finalize_x(const float* partials, int nblk, const HpfgPeerX* px, double count, const float* gamma, float* bn, float* dgamma,
+                           float* dbeta, int C, float param_grad_scale, void* stream);
+
 /* ---- losses (main.py:164-197, medloss.py:44-56, diceloss.py:155-191, Mean-Teacher :103-106) -------------- */
 typedef struct HpfgLossArgs {
   const float* logits;      /* [N,H,W,C] student logits (NHWC) */
@@ -220,6 +251,7 @@ typedef struct HpfgLossArgs {
 #define HPFG_LOSS_NSUM 32
 int hpfg_loss_blocks(int N, int H, int W);
 int hpfg_seg_loss_partials(const HpfgLossArgs* a, void* stream);   /* softmax + CE/Dice/MSE partial sums */
+int hpfg_seg_loss_partials_x(const HpfgLossArgs* a, const HpfgPeerX* px, void* stream);   /* + the cross-rank sum of `sums` (peer mailbox) */
 int hpfg_seg_loss_finalize(const HpfgLossArgs* a, void* stream);   /* sums -> loss scalars (device) */
 int hpfg_seg_loss_bwd(const HpfgLossArgs* a, const float* grad_scale_dev /* NULL = 1 */, void* stream);   /* dlogits */
 /* pseudo-labels: argmax over classes of teacher logits, optionally CutMix-blended with labels (main.py:177-178) */

@@ -6,7 +6,9 @@ Runs steps of the REAL engine on this rank's shard of a fixed global batch and s
     HPFG_TEST_SYNC_BN  1 | 0                  global-batch mode (all-reduced BatchNorm statistics, loss sums, gathered contrast features) or
                                               per-rank BatchNorm with averaged gradients (what `bench.py --gpus N` times)
     HPFG_TEST_OVERLAP  1 | 0                  gradient buckets all-reduced from inside backward on a side stream, or one exchange after it
-    HPFG_TEST_GRAPH    1 | 0                  (sync_bn = 0) the step as a chain of hipGraphs around the eager exchange, as bench.py runs it
+    HPFG_TEST_GRAPH    1 | 0                  the step as a chain of hipGraphs around the eager gradient exchange, as bench.py runs it
+    HPFG_TEST_P2P      1 | 0                  (sync_bn = 1) BatchNorm / loss sums exchanged by the kernels through peer mailboxes (hipIpc) instead of
+                                              host-launched collectives
 """
 import os
 import sys
@@ -66,7 +68,7 @@ def _frozen(m):
     return e
 
 
-def run(dev, dp, rank, world, steps=2, overlap=True, step="mt", sync_bn=True, graph=False, shard=None, fixed=False):
+def run(dev, dp, rank, world, steps=2, overlap=True, step="mt", sync_bn=True, graph=False, shard=None, fixed=False, p2p=False):
     """shard: (rank, world) of the data this process sees when it runs WITHOUT a process group (the per-shard reference runs of the
     sync_bn = 0 test); with dp the shard is the rank's.  fixed: the same dropout masks and the step's own consistency law in every
     iteration -- what a captured graph replays (graph=True implies it: one eager warm-up step, the capture, one replay = 2 iterations)."""
@@ -77,6 +79,8 @@ def run(dev, dp, rank, world, steps=2, overlap=True, step="mt", sync_bn=True, gr
     reset_dropout_streams()
     if dp is not None:
         dp.sync_bn, dp.overlap = sync_bn, overlap
+        if p2p:
+            dp.enable_peer_exchange()
     xl, yl, xu = global_batch()
     srank, sworld = (rank, world) if shard is None else shard
     kl, ku = N_LAB // sworld, N_UNL // sworld
@@ -136,6 +140,8 @@ def run(dev, dp, rank, world, steps=2, overlap=True, step="mt", sync_bn=True, gr
             kk = (k - first + 1) if fixed else k          # the graphed run counts its iterations 1, 2
             losses.append(outs(st.step(*inputs, kk, **kw)).clone())
     torch.cuda.synchronize()
+    if dp is not None:
+        dp.check_peer_errors()
     return (torch.stack(losses),) + tuple(saved())
 
 
@@ -147,7 +153,8 @@ def main():
     try:
         res = run(dev, dp, dp.rank, dp.world_size, steps=int(os.environ.get("HPFG_TEST_STEPS", "2")), overlap=os.environ.get("HPFG_TEST_OVERLAP", "1") == "1",
                   step=os.environ.get("HPFG_TEST_STEP", "mt"), sync_bn=os.environ.get("HPFG_TEST_SYNC_BN", "1") == "1",
-                  graph=os.environ.get("HPFG_TEST_GRAPH", "0") == "1", fixed=os.environ.get("HPFG_TEST_FIXED", "0") == "1")
+                  graph=os.environ.get("HPFG_TEST_GRAPH", "0") == "1", fixed=os.environ.get("HPFG_TEST_FIXED", "0") == "1",
+                  p2p=os.environ.get("HPFG_TEST_P2P", "0") == "1")
         torch.save(res, f"{out}.rank{dp.rank}")
     finally:
         dp.shutdown()

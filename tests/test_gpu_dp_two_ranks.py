@@ -5,6 +5,8 @@
     inside backward, or one all-reduce after it) cross the ranks; losses, parameters and running statistics after two steps equal the
     single-process run at 1e-5.  Mean-Teacher (one trainable network), CPS (two networks through one _reduce_grads) and HPFG (two U-Net+
     students + teacher on three streams, CutMix, Dense_Loss: BASELINE configs[2] is "DDP over 2/4/8").
+    The same with the PEER MAILBOX exchange (p2p: the BatchNorm / loss sums cross the ranks inside the finalize kernels over hipIpc-mapped
+    memory, no collective between kernels), eager and -- only possible that way -- captured into the chain of hipGraphs.
   * per-rank BatchNorm (sync_bn = False, what `bench.py --gpus N` times): after ONE step from identical weights the parameters equal the MEAN
     of the two single-process runs on the shards (SGD's first step is linear in the gradient), and the chain of hipGraphs around the eager
     exchange (both overlap settings) equals the eager run.
@@ -51,9 +53,10 @@ def _two_ranks(tmp_path, tag, **env_kw):
     return torch.load(f"{out}.rank0"), torch.load(f"{out}.rank1")
 
 
-@pytest.mark.parametrize("step,overlap", [("mt", True), ("mt", False), ("cps", True), ("cps", False), ("hpfg", True), ("hpfg", False)])
-def test_two_ranks_equal_the_global_batch(tmp_path, step, overlap):
-    r0, r1 = _two_ranks(tmp_path, f"{step}{int(overlap)}", HPFG_TEST_STEP=step, HPFG_TEST_OVERLAP=int(overlap), HPFG_TEST_SYNC_BN=1)
+@pytest.mark.parametrize("step,overlap,p2p", [("mt", True, 0), ("mt", False, 0), ("cps", True, 0), ("cps", False, 0), ("hpfg", True, 0), ("hpfg", False, 0),
+                                              ("mt", True, 1), ("cps", False, 1), ("hpfg", True, 1)])
+def test_two_ranks_equal_the_global_batch(tmp_path, step, overlap, p2p):
+    r0, r1 = _two_ranks(tmp_path, f"{step}{int(overlap)}{p2p}", HPFG_TEST_STEP=step, HPFG_TEST_OVERLAP=int(overlap), HPFG_TEST_SYNC_BN=1, HPFG_TEST_P2P=p2p)
     ref = W.run(DEV, None, 0, 1, step=step)
     for got in (r0, r1):
         assert maxerr(got[0], ref[0]) < 1e-5, (got[0], ref[0])          # loss parts are normalised by the GLOBAL counts on every rank
@@ -88,6 +91,19 @@ def test_per_rank_mode_graph_chain_equals_eager(tmp_path, step, overlap):
     common = dict(HPFG_TEST_STEP=step, HPFG_TEST_OVERLAP=int(overlap), HPFG_TEST_SYNC_BN=0, HPFG_TEST_STEPS=2)
     g0, g1 = _two_ranks(tmp_path, f"g_{step}{int(overlap)}", HPFG_TEST_GRAPH=1, **common)
     e0, e1 = _two_ranks(tmp_path, f"e_{step}{int(overlap)}", HPFG_TEST_GRAPH=0, HPFG_TEST_FIXED=1, **common)
+    assert torch.equal(g0[1], g1[1])
+    for a, b in zip(g0[1:], e0[1:]):
+        assert maxerr(a, b) < 1e-6
+    assert maxerr(g0[0][-1], e0[0][-1]) < 1e-6
+
+
+@pytest.mark.parametrize("step,overlap", [("mt", True), ("cps", False)])
+def test_global_batch_mode_with_peer_mailboxes_captures_into_graphs(tmp_path, step, overlap):
+    """sync_bn = True with the peer mailbox exchange: no host code between the kernels of forward + loss + backward, so the step runs as
+    hipGraphs around the eager gradient all-reduce -- and equals the eager two-rank run of the same two iterations."""
+    common = dict(HPFG_TEST_STEP=step, HPFG_TEST_OVERLAP=int(overlap), HPFG_TEST_SYNC_BN=1, HPFG_TEST_P2P=1, HPFG_TEST_STEPS=2)
+    g0, g1 = _two_ranks(tmp_path, f"pg_{step}", HPFG_TEST_GRAPH=1, **common)
+    e0, e1 = _two_ranks(tmp_path, f"pe_{step}", HPFG_TEST_GRAPH=0, HPFG_TEST_FIXED=1, **common)
     assert torch.equal(g0[1], g1[1])
     for a, b in zip(g0[1:], e0[1:]):
         assert maxerr(a, b) < 1e-6
