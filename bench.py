@@ -86,6 +86,8 @@ def parse():
     ap.add_argument("--overlap", action="store_true", help="N > 1: bucketed gradient all-reduce overlapped with the encoder half of backward (a chain of "
                     "hipGraphs around eager RCCL calls) instead of ONE all-reduce between two hipGraphs")
     ap.add_argument("--no-overlap", action="store_true", help="(the default; kept for older command lines)")
+    ap.add_argument("--no-p2p", action="store_true", help="--sync-bn: exchange the BatchNorm / loss sums with host-launched RCCL all-reduces (eager step) instead "
+                    "of the peer mailboxes the finalize kernels write themselves (hipIpc over xGMI; the step stays a chain of hipGraphs)")
     return ap.parse_args()
 
 
@@ -513,12 +515,15 @@ def main():
         dp.force_sync = bool(a.force_sync)
         dp.sync_bn = bool(a.sync_bn or (a.force_sync and os.environ.get("HPFG_BENCH_LOCAL_BN", "0") != "1"))
         dp.overlap = bool(a.overlap) and not a.no_overlap
+        if dp.sync_bn and not a.no_p2p:
+            dp.enable_peer_exchange()
     wl = Workload(a.workload, a, dev, a.math, dp, rank)
 
-    # N > 1, default mode: two graphs around the gradient all-reduce (no RCCL node inside a hipGraph).  --sync-bn (collectives between the
-    # kernels of forward and backward) runs eager.
+    # N > 1: graphs around the gradient all-reduce (no RCCL node inside a hipGraph).  --sync-bn exchanges the BatchNorm / loss sums inside the
+    # kernels (peer mailboxes) and captures as well; with --no-p2p (collectives between the kernels), and for the HPFG step (its Dense_Loss
+    # all-gathers the neck features with a host-launched collective), the global-batch mode runs eager.
     sync_mode = dp is not None and dp.sync_bn and (world > 1 or a.force_sync)
-    use_graph = (not a.no_graph) and not sync_mode
+    use_graph = (not a.no_graph) and (not sync_mode or (dp.p2p and a.workload != "hpfg"))
     dt, use_graph, it = timed_run(wl, dp, use_graph, a.steps, a.warmup, dev)
     ms = dt / a.steps * 1e3
     value = wl.n_img * world / (dt / a.steps)
@@ -549,7 +554,8 @@ def main():
     if rank == 0:
         par = f"dp{world}"
         if world > 1:
-            par += " (sync BatchNorm + loss sums: == one process on the global batch)" if (dp is not None and dp.sync_bn) else \
+            par += (" (global-batch mode: BatchNorm + loss sums exchanged " + ("by the finalize kernels through peer mailboxes over xGMI" if dp.p2p else
+                    "by RCCL all-reduces between the kernels") + "; == one process on the global batch)") if (dp is not None and dp.sync_bn) else \
                 (" (per-rank BatchNorm, gradients averaged by bucketed all-reduces overlapped with backward)" if dp is not None and dp.overlap else
                  " (per-rank BatchNorm, gradients averaged by one all-reduce between two hipGraphs)")
         step_roof = {"algorithmic_GB_per_step": round(wl.bytes / 1e9, 3), "achieved_GBps": round(wl.bytes / (dt / a.steps) / 1e9, 1),
