@@ -26,7 +26,17 @@ with open(os.path.join(dst, f"{prefix}_step_traffic.txt"), "w") as f:
     f.write(f"# python tools/step_traffic.py gpurun_out/{tag}/pmc_fetch gpurun_out/{tag}/pmc_write   (bench.py --no-graph --steps 2; FETCH_SIZE doubled per MI355X_MICROARCH.md)\n")
     f.write(subprocess.run([sys.executable, "tools/step_traffic.py", os.path.join(src, "pmc_fetch"), os.path.join(src, "pmc_write")], check=True,
                            capture_output=True, text=True).stdout)
-shutil.copy(os.path.join(src, "other_configs.txt"), os.path.join(dst, f"{prefix}_other_configs.txt"))
-line = [ln for ln in open(os.path.join(src, "ctct.txt")) if ln.startswith("{")][-1]
-json.dump(json.loads(line), open(os.path.join(dst, f"{prefix}_ctct_bench.json"), "w"), indent=1)
-print("collected", sorted(os.listdir(dst))[-12:])
+lines = []
+for w in ("sup", "hpfg", "cps", "ctct"):
+    fn = os.path.join(src, f"bench_{w}.json")
+    if os.path.exists(fn):
+        ls = [ln for ln in open(fn) if ln.startswith("{")]
+        if ls:
+            shutil.copy(fn, os.path.join(dst, f"{prefix}_bench_{w}.json"))
+            d = json.loads(ls[-1])
+            lines.append(f"{w}: {d['ms_per_step']} ms/step = {d['value']} img/s; step roofline {d['step_roofline']['frac_of_8TBps']} of 8 TB/s; "
+                         f"dominant family: {d['roofline']['kernel'][:80]} ({d['roofline']['bound']} {d['roofline']['frac']})")
+open(os.path.join(dst, f"{prefix}_other_configs.txt"), "w").write("\n".join(lines) + "\n")
+subprocess.run([sys.executable, "tools/family_traffic.py", os.path.join(src, "pmc_fetch"), os.path.join(src, "pmc_write"),
+                os.path.join(dst, f"{prefix}_family_traffic.json"), "mt"], check=True)
+print("collected", sorted(os.listdir(dst))[-14:])

@@ -12,12 +12,11 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 if [ -n "$PROFILE_MAX_MS" ]; then
   python3 -c "import json,sys; d=[json.loads(l) for l in open('$OUT/bench.json') if l.startswith('{')][0]; print('ms_per_step', d['ms_per_step']); sys.exit(0 if d['ms_per_step'] <= float('$PROFILE_MAX_MS') else 9)" || exit 9
 fi
-python tools/time_other_configs.py > $OUT/other_configs.txt 2>&1
-python tools/bench_ctct.py > $OUT/ctct.txt 2>&1
+for w in sup hpfg cps ctct; do python bench.py --workload $w --steps 20 --warmup 5 > $OUT/bench_$w.json 2> $OUT/bench_$w.err || echo "bench $w failed"; done
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o mt -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f32-line > $OUT/trace.log 2>&1 || exit 2
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o mt -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f32-line --no-probe > $OUT/trace.log 2>&1 || exit 2
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-f32-line > $OUT/pmc_fetch.log 2>&1 || exit 3
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-f32-line > $OUT/pmc_write.log 2>&1 || exit 4
-STEPS=5 GRAPH=0 rocprofv3 --kernel-trace --stats -d $OUT/trace_ctct -o c -- python3 $GRAFT_REPO_ROOT/tools/bench_ctct.py > $OUT/trace_ctct.log 2>&1 || exit 5
-rocprofv3 --kernel-trace --stats -d $OUT/trace_hpfg -o h -- python3 $GRAFT_REPO_ROOT/tools/hpfg_step_probe.py > $OUT/trace_hpfg.log 2>&1 || exit 6
+rocprofv3 --kernel-trace --stats -d $OUT/trace_ctct -o c -- python3 $GRAFT_REPO_ROOT/bench.py --workload ctct --steps 10 --warmup 3 --no-cpu-baseline --no-probe > $OUT/trace_ctct.log 2>&1 || exit 5
+rocprofv3 --kernel-trace --stats -d $OUT/trace_hpfg -o h -- python3 $GRAFT_REPO_ROOT/bench.py --workload hpfg --steps 10 --warmup 3 --no-cpu-baseline --no-probe > $OUT/trace_hpfg.log 2>&1 || exit 6
 echo profile_round done
