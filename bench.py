@@ -2,7 +2,7 @@
 """Headline benchmark: labeled+unlabeled images/sec/node of one step of the reference's drivers on the MI355X hot path, synthetic data.
 
     python bench.py [--workload mt|sup|hpfg|cps|ctct] [--gpus N] [--steps K] [--warmup W] [--math bf16x3|f32] [--no-graph]
-                    [--sync-bn] [--overlap] [--no-cpu-baseline] [--no-f32-line] [--no-probe]
+                    [--sync-bn] [--overlap] [--rccl] [--no-cpu-baseline] [--no-f32-line] [--no-probe]
 
 Workloads = BASELINE.json configs (the default, `mt`, is configs[1], the one the metric is quoted on):
   sup   configs[0]  sup_ACDC.py:83-93                          U-Net 1->4, 8 x 224^2, SGD + cosine schedule
@@ -14,7 +14,8 @@ Every statement of the loop body is inside the timed region; inputs are resident
 
 `python bench.py --gpus N` with N > 1 and no launcher environment starts `python -m torch.distributed.run --nproc-per-node N` on this
 file as a CHILD process (before anything here touches the GPU) and relays its JSON line; under a launcher (RANK / WORLD_SIZE set) it is
-one rank of the job.  One rank per GPU over RCCL, weak scaling (per-GPU batch fixed).
+one rank of the job.  One rank per GPU (process group over RCCL), weak scaling (per-GPU batch fixed); the per-step gradient exchange runs
+through IPC-mapped peer windows over xGMI inside the step's hipGraph (after a self-test on the node; `--rccl`: an RCCL all-reduce between two graphs).
 
 Prints ONE JSON line (rank 0): the driver's contract plus
   step_roofline   the whole step against its algorithmic bytes / FLOPs,
@@ -86,6 +87,8 @@ def parse():
     ap.add_argument("--overlap", action="store_true", help="N > 1: bucketed gradient all-reduce overlapped with the encoder half of backward (a chain of "
                     "hipGraphs around eager RCCL calls) instead of ONE all-reduce between two hipGraphs")
     ap.add_argument("--no-overlap", action="store_true", help="(the default; kept for older command lines)")
+    ap.add_argument("--rccl", action="store_true", help="N > 1: the gradient all-reduce as an RCCL call between two hipGraphs instead of the peer-window "
+                    "exchange captured inside the step's one graph (the fallback bench.py takes by itself when the peer windows fail their self-test)")
     ap.add_argument("--no-p2p", action="store_true", help="--sync-bn: exchange the BatchNorm / loss sums with host-launched RCCL all-reduces (eager step) instead "
                     "of the peer mailboxes the finalize kernels write themselves (hipIpc over xGMI; the step stays a chain of hipGraphs)")
     return ap.parse_args()
@@ -518,6 +521,20 @@ def main():
         if dp.sync_bn and not a.no_p2p:
             dp.enable_peer_exchange()
     wl = Workload(a.workload, a, dev, a.math, dp, rank)
+    exchange = None
+    if dp is not None and world > 1:
+        # N > 1 default: the flat gradients cross the ranks through IPC-mapped peer windows (xGMI pushes: csrc/peer.hip) as kernels of the
+        # captured step -- one hipGraph per step, as at N = 1.  The path is tried on the actual devices first; RCCL between two graphs otherwise.
+        exchange = "RCCL all-reduce between two hipGraphs"
+        if not a.rccl and not dp.overlap:
+            nmax = max([int(m.flat_grads.numel()) if hasattr(m, "flat_grads") and not hasattr(m, "_hpfg_generic_flat") else
+                        sum(p.numel() for p in m.parameters() if p.requires_grad) for m in wl.models if any(p.requires_grad for p in m.parameters())] or [0])
+            if nmax and dp.enable_peer_grads(nmax):
+                exchange = "peer-window all-reduce over xGMI (push / reduce / gather kernels inside the step's hipGraph)"
+            elif rank == 0:
+                print("[bench] peer-window gradient exchange unavailable on this node; using RCCL", file=sys.stderr)
+        elif dp.overlap:
+            exchange = "bucketed RCCL all-reduces overlapped with backward (chain of hipGraphs)"
 
     # N > 1: graphs around the gradient all-reduce (no RCCL node inside a hipGraph).  --sync-bn exchanges the BatchNorm / loss sums inside the
     # kernels (peer mailboxes) and captures as well; with --no-p2p (collectives between the kernels), and for the HPFG step (its Dense_Loss
@@ -556,8 +573,8 @@ def main():
         if world > 1:
             par += (" (global-batch mode: BatchNorm + loss sums exchanged " + ("by the finalize kernels through peer mailboxes over xGMI" if dp.p2p else
                     "by RCCL all-reduces between the kernels") + "; == one process on the global batch)") if (dp is not None and dp.sync_bn) else \
-                (" (per-rank BatchNorm, gradients averaged by bucketed all-reduces overlapped with backward)" if dp is not None and dp.overlap else
-                 " (per-rank BatchNorm, gradients averaged by one all-reduce between two hipGraphs)")
+                " (per-rank BatchNorm, gradients averaged)"
+            par += f"; gradient exchange: {exchange}"
         step_roof = {"algorithmic_GB_per_step": round(wl.bytes / 1e9, 3), "achieved_GBps": round(wl.bytes / (dt / a.steps) / 1e9, 1),
                      "frac_of_8TBps": round(wl.bytes / (dt / a.steps) / 8e12, 4), "algorithmic_GFLOP_per_step": round(wl.gflop, 1),
                      "achieved_TFLOPs": round(wl.gflop / (dt / a.steps) / 1e3, 2)}

@@ -49,6 +49,11 @@ class PeerX(C.Structure):
                 ("slot", C.c_int32), ("cap", C.c_int32), ("slot_bytes", C.c_int64)]
 
 
+class PeerBuf(C.Structure):
+    _fields_ = [("win", C.c_void_p * 8), ("epoch", C.c_void_p), ("err", C.c_void_p), ("world", C.c_int32), ("rank", C.c_int32),
+                ("slice", C.c_int64), ("n", C.c_int64)]
+
+
 class FusedBwdArgs(C.Structure):
     _fields_ = [("d", ConvArgs), ("xa0", Act), ("xa1", Act), ("slab", C.c_void_p), ("Cin", C.c_int32), ("CinPad", C.c_int32),
                 ("Cout", C.c_int32), ("CoutPad", C.c_int32)]
@@ -117,6 +122,9 @@ PROTOTYPES = {
     "hpfg_peer_open": (_i, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "hpfg_peer_close": (_i, [_p]),
     "hpfg_word_add": (_i, [_p, _i, _p]),
+    "hpfg_peer_buf_slice": (_l, [_i, _l]),
+    "hpfg_peer_buf_bytes": (_l, [_i, _l]),
+    "hpfg_peer_allreduce_f32": (_i, [C.POINTER(PeerBuf), _p, _p]),
     "hpfg_bn_fwd_finalize_x": (_i, [_p, _i, C.POINTER(PeerX), _d, _p, _p, _p, _p, _f, _f, _p, _i, _p]),
     "hpfg_bn_bwd_finalize_x": (_i, [_p, _i, C.POINTER(PeerX), _d, _p, _p, _p, _p, _i, _f, _p]),
     "hpfg_seg_loss_partials_x": (_i, [C.POINTER(LossArgs), C.POINTER(PeerX), _p]),

@@ -149,9 +149,6 @@ class UNetEngine:
         self._bwd_alloc = False
         self.x: Optional[torch.Tensor] = None
         self.world = 1
-        # 0: wgrad on the main stream.  1: on a second stream, forked before the layer's dgrad (measured -7%: two heavy kernels
-        # contend).  2: forked AFTER the layer's dgrad is queued, so that it overlaps the light BatchNorm-backward kernels of the next layer.
-        self.wgrad_overlap = int(os.environ.get("HPFG_WGRAD_OVERLAP", "0"))
         # BatchNorm-backward sums of the layer below from the dgrad epilogue (bf16x3 kernels) instead of a streaming pass of their own
         self.fuse_bwd_stats = int(os.environ.get("HPFG_FUSE_BWD_STATS", "1"))      # 2: also the register-starved 32-channel instantiation
         self._fused_rows: Dict[str, int] = {}
@@ -390,7 +387,7 @@ class UNetEngine:
 
     # ---------------------------------------------------------------------------------------------------------
     def _alloc_bwd(self):
-        key = (self.math, self.fused_bwd, self.wgrad_overlap)      # what the slab layout depends on
+        key = (self.math, self.fused_bwd)      # what the slab layout depends on
         if self._bwd_alloc and self._bwd_alloc_key == key:
             return
         self._bwd_alloc_key = key
@@ -423,7 +420,7 @@ class UNetEngine:
         # one slab region per layer; all of them are summed by ONE launch at the end of backward()
         sizes = [self.lib.hpfg_wgrad_slab_floats(N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps) for s in self.order]
         self.fused_grid = {}
-        if self.fused_bwd and self.math == L.MATH_BF16X3 and self.wgrad_overlap in (0, 3):
+        if self.fused_bwd and self.math == L.MATH_BF16X3:
             for i, s in enumerate(self.order):
                 if s.taps != 9:
                     continue
@@ -512,9 +509,6 @@ class UNetEngine:
         if self._deferred is not None:      # decoder half: the weight gradient is queued for the side stream (see backward())
             self._dgrad(s, g, dgrad_out, stats_for, out2)
             self._deferred.append((s, g))
-        elif self.wgrad_overlap == 2:
-            self._dgrad(s, g, dgrad_out, stats_for, out2)
-            self._wgrad(s, g)
         else:
             self._wgrad(s, g)
             self._dgrad(s, g, dgrad_out, stats_for, out2)
@@ -545,18 +539,8 @@ class UNetEngine:
     def _wgrad(self, s: ConvSpec, g: L.Act, on_side: bool = False):
         """Weight gradient of layer s.  It is off the critical chain of backward (nothing downstream consumes it before the final
         slab reduction), so it is issued on a second HIP stream forked behind the kernels recorded so far and joined at the end."""
-        main = torch.cuda.current_stream(self.dev)
-        # 3: only the layers whose grids do not fill the chip (<= 56 x 56: a few hundred workgroups each for dgrad and wgrad) share it
-        if on_side:
-            stream = self._side.cuda_stream      # (the caller forked it)
-        elif self.wgrad_overlap in (1, 2) or (self.wgrad_overlap == 3 and s.taps == 9 and s.h <= 56):
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.dev)
-            self._side.wait_stream(main)
-            self._side_used = True
-            stream = self._side.cuda_stream
-        else:
-            stream = main.cuda_stream
+        # on_side: one of the deferred batches, on the side stream the caller (backward / flush) forked
+        stream = self._side.cuda_stream if on_side else torch.cuda.current_stream(self.dev).cuda_stream
         wa = L.WgradArgs()
         wa.a0, wa.a1 = self.input_acts(s.name)
         wa.g = g
@@ -617,9 +601,9 @@ class UNetEngine:
         # ONE fork for the decoder's separate weight gradients (the channel-rich layers and the 1x1 convs; the thin layers' are fused with their
         # dgrad): they are queued while the decoder half back-propagates and run on the side stream beside the encoder half -- everything they
         # read (dA, z, the BatchNorm tables of their layers) stays in place until the next forward.  A fork / join per layer cost more than it
-        # returned (HPFG_WGRAD_OVERLAP); this is one of each.  Not with the data-parallel buckets: the decoder's gradients must be final at the
+        # returned (round 1; removed); this is one of each.  Not with the data-parallel buckets: the decoder's gradients must be final at the
         # bucket boundary.
-        self._deferred = [] if (self.defer_wgrad and bucket_cb is None and self.wgrad_overlap == 0) else None
+        self._deferred = [] if (self.defer_wgrad and bucket_cb is None) else None
         # ---- out_conv
         s = sp["decoder.out_conv"]
         g = self._act_plain(dlogits, self.ncls, s.h, s.w)

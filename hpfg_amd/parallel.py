@@ -20,6 +20,13 @@ their per-channel sums into every peer's MAILBOX (fine-grained device memory map
 node) and add the peers' values from their own mailbox in rank order (csrc/peer.h) -- no host code between the kernels, so the whole
 forward + loss + backward stays one hipGraph and only the gradient all-reduce (3) is an RCCL call, between two graphs.
 
+The gradient exchange (3) has a second form that needs no RCCL call at all (`enable_peer_grads()`): the same IPC-mapped windows carry the
+flat gradient.  xGMI is point to point, so instead of a ring every rank owns one slice: each rank PUSHES its copy of slice p into rank p's
+window (7 links busy at once), the owner adds the R contributions in rank order and pushes the sum into every rank's window, and each rank
+copies the result back (csrc/peer.hip: hpfg_peer_allreduce_f32 -- three launches behind epoch flags).  No host code, so under data parallel
+the whole step -- forward, loss, backward, exchange, SGD + EMA -- is ONE hipGraph, as on one GPU.  `enable_peer_grads()` tests the path on
+the actual devices and reports whether every rank passed; bench.py falls back to the RCCL exchange between two graphs if not.
+
 `sync_bn=False` selects the usual DistributedDataParallel semantics instead: BatchNorm statistics and the loss are per rank
 (every rank sees exactly what the single-GPU reference run sees: its own 8+8 batch), and the only exchange is the gradient
 all-reduce, averaged over ranks; bench.py uses it for N > 1 unless --sync-bn is given.
@@ -55,6 +62,12 @@ class DataParallelContext:
         self.peer_err = None         # device int32 word: set by a kernel whose poll for a peer's value expired
         self.loss_slot = -1
         self.loss_epoch = None
+        # peer gradient exchange (enable_peer_grads): the flat gradient crosses the ranks through IPC windows, inside the captured step
+        self.p2p_grads = False
+        self._gwin = None            # this rank's window, _gpeers[r] = rank r's window as mapped here
+        self._gpeers = []
+        self.grad_floats = 0
+        self.grad_epoch = None
 
     @property
     def active(self) -> bool:
@@ -139,6 +152,97 @@ class DataParallelContext:
         self.p2p = True
         self.loss_slot = self.alloc_slots(1)
 
+    def enable_peer_grads(self, max_floats: int) -> bool:
+        """Allocate and map the gradient windows (buffers of up to `max_floats` fp32 values), run one all-reduce through them and return
+        whether EVERY rank got the right sums.  Collective: all ranks call it, once, with the same size.  On False nothing is enabled (the
+        caller keeps the RCCL exchange); a failure to map a peer's memory counts as False, not as an error."""
+        import ctypes as C
+        from . import _lib as L
+        if self.p2p_grads:
+            return True
+        if self.world_size > 8 or self.device is None or self.device.type != "cuda":
+            return False
+        lib = L.load()
+        torch.cuda.set_device(self.device)
+        if self.peer_err is None:
+            self.peer_err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.grad_epoch = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.grad_floats = int(max_floats)
+        if self.world_size == 1:
+            self.p2p_grads = True
+            return True
+        ok = 1
+        self._gpeers = [None] * self.world_size
+        try:
+            ptr = C.c_void_p()
+            L.check(lib.hpfg_peer_alloc(lib.hpfg_peer_buf_bytes(self.world_size, self.grad_floats), C.byref(ptr)), "peer_alloc(grads)")
+            self._gwin = ptr.value
+            h = C.create_string_buffer(64)
+            L.check(lib.hpfg_peer_handle(self._gwin, h), "peer_handle(grads)")
+            mine = bytes(h.raw)
+        except Exception:
+            ok, mine = 0, b""
+        handles = [None] * self.world_size
+        dist.all_gather_object(handles, mine, group=self.group)          # (also the point where a rank that could not allocate tells the others)
+        if ok and all(len(hr) == 64 for hr in handles):
+            for r, hr in enumerate(handles):
+                if r == self.rank:
+                    self._gpeers[r] = self._gwin
+                    continue
+                q = C.c_void_p()
+                if lib.hpfg_peer_open(C.create_string_buffer(hr, 64), C.byref(q)) != 0:
+                    ok = 0
+                    break
+                self._gpeers[r] = q.value
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)          # (everything is mapped everywhere, or nobody starts)
+        if int(flag.item()) == 1:
+            self.p2p_grads = True
+            n = min(self.grad_floats, 262147)
+            t = (torch.arange(n, device=self.device, dtype=torch.float32) % 97.0) * float(self.rank + 1)
+            want = (torch.arange(n, device=self.device, dtype=torch.float32) % 97.0) * float(self.world_size * (self.world_size + 1) // 2)
+            for _ in range(2):          # twice: the second use of the flags is the one every later step repeats
+                got = self.peer_allreduce_sum(t.clone())
+            torch.cuda.synchronize(self.device)
+            good = bool(torch.equal(got, want)) and int(self.peer_err.item()) == 0
+            flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            self.p2p_grads = int(flag.item()) == 1
+        if not self.p2p_grads:
+            self.peer_err.zero_()
+            self._close_grad_windows()
+        return self.p2p_grads
+
+    def peer_allreduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        """SUM over ranks of the contiguous fp32 tensor t, in place, through the peer windows: kernels on the current stream only."""
+        import ctypes as C
+        from . import _lib as L
+        if self.world_size == 1:
+            return t
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() <= self.grad_floats):
+            raise RuntimeError(f"peer_allreduce_sum: needs a contiguous fp32 device tensor of at most {self.grad_floats} values (got {tuple(t.shape)}, {t.dtype})")
+        lib = L.load()
+        pb = L.PeerBuf()
+        pb.world, pb.rank, pb.n = self.world_size, self.rank, t.numel()
+        pb.slice = lib.hpfg_peer_buf_slice(self.world_size, t.numel())
+        pb.epoch, pb.err = self.grad_epoch.data_ptr(), self.peer_err.data_ptr()
+        for r in range(self.world_size):
+            pb.win[r] = self._gpeers[r]
+        L.check(lib.hpfg_peer_allreduce_f32(C.byref(pb), t.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream), "peer_allreduce_f32")
+        return t
+
+    def _close_grad_windows(self):
+        from . import _lib as L
+        lib = L.load()
+        for r, q in enumerate(self._gpeers):
+            if r != self.rank and q:
+                lib.hpfg_peer_close(q)
+        if self._gwin is not None:
+            lib.hpfg_peer_free(self._gwin)
+        self._gwin, self._gpeers = None, []
+
     def alloc_slots(self, n: int) -> int:
         """First of n consecutive mailbox slots (the same numbers on every rank: engines are built in the same order everywhere)."""
         base = self._slots_used
@@ -163,10 +267,16 @@ class DataParallelContext:
 
     def check_peer_errors(self):
         """Raise if a kernel gave up waiting for a peer's value (synchronises)."""
-        if self.p2p and self.peer_err is not None and int(self.peer_err.item()) != 0:
+        if (self.p2p or self.p2p_grads) and self.peer_err is not None and int(self.peer_err.item()) != 0:
             raise RuntimeError("peer mailbox exchange: a poll for a peer's value expired (a rank is missing or far behind)")
 
     def shutdown(self):
+        if self.p2p_grads and self.world_size > 1 and self._gwin is not None:
+            torch.cuda.synchronize(self.device)
+            if dist.is_initialized():
+                dist.barrier(group=self.group)      # nobody unmaps a window a peer's kernel may still store into
+            self._close_grad_windows()
+            self.p2p_grads = False
         if self.p2p and self.world_size > 1 and self._mbox is not None:
             from . import _lib as L
             lib = L.load()

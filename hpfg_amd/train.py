@@ -187,16 +187,18 @@ class _StepBase:
 
     def _reduce_grads(self, *models):
         if self.dp is not None and (self.dp.world_size > 1 or self.dp.force_sync):
+            p2p = getattr(self.dp, "p2p_grads", False)      # the exchange as kernels on this stream (peer windows): capturable, no RCCL call
+            red = self.dp.peer_allreduce_sum if p2p else self.dp.allreduce_sum
             for m in models:
                 if getattr(m, "_buckets_launched", False):      # the engine's backward already handed both buckets to the side stream
                     m._buckets_launched = False
                     self.dp.join_buckets()
                 elif hasattr(m, "flat_grads") and not hasattr(m, "_hpfg_generic_flat"):
-                    self.dp.allreduce_sum(m.flat_grads)
+                    red(m.flat_grads)
                 else:                      # a model whose gradients live in per-parameter tensors (SegFormer): one flattened exchange of the
                     gs = [p.grad for p in m.parameters() if p.grad is not None]      # SUM; the 1/world of the per-rank-BatchNorm mode is the
                     flat = torch.cat([g.reshape(-1) for g in gs])                    # optimizer's grad_scale (FusedSGD / FusedAdamW), as for the U-Nets
-                    self.dp.allreduce_sum(flat)
+                    red(flat)
                     o = 0
                     for g in gs:
                         g.copy_(flat[o:o + g.numel()].view_as(g))
@@ -803,7 +805,8 @@ class GraphedStep:
         dp = getattr(step_obj, "dp", None)
         # data parallel: the gradient exchange is never captured -- [forward + loss + backward] | eager all-reduce(s) | [update] as a chain of
         # graphs, in the per-rank BatchNorm mode and (BatchNorm / loss sums exchanged by the kernels through peer mailboxes) the global-batch mode
-        self.split = bool(dp is not None and (dp.world_size > 1 or dp.force_sync))
+        # (with the peer-window gradient exchange there is no host-launched collective left: one graph, as on one GPU)
+        self.split = bool(dp is not None and (dp.world_size > 1 or dp.force_sync) and not getattr(dp, "p2p_grads", False))
         if self.split and not hasattr(step_obj, "device_fwd_bwd"):
             raise RuntimeError(f"GraphedStep: {type(step_obj).__name__} has no device_fwd_bwd / exchange / device_update split, so its gradient "
                                "exchange would be captured into the graph; run it eager under data parallel")

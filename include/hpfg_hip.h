@@ -228,6 +228,25 @@ int hpfg_bn_fwd_finalize_x(const float* partials, int nblk, const HpfgPeerX* px,
 int hpfg_bn_bwd_finalize_x(const float* partials, int nblk, const HpfgPeerX* px, double count, const float* gamma, float* bn, float* dgamma,
                            float* dbeta, int C, float param_grad_scale, void* stream);
 
+/* Gradient all-reduce over the same kind of IPC-mapped memory: what DistributedDataParallel's bucketed NCCL all-reduce would be if the reference
+ * ran on more than one card (main.py:44: it does not).  xGMI is point to point, so the exchange is not a ring: every rank owns one slice of the
+ * buffer; (1) push: each rank stores its copy of slice p into rank p's window (all links busy at once), (2) reduce: the owner adds the
+ * contributions in rank order and stores the reduced slice into every rank's window, (3) gather: each rank copies the reduced buffer back.
+ * Flags carry the epoch (consecutive use counts, bumped by the call itself); polls are bounded like the mailbox polls.  Three launches + the
+ * epoch bump on `stream`, no host code: the whole training step stays ONE hipGraph under data parallel.  Every rank receives bit-identical
+ * sums (each slice is reduced once).  Window layout: 256 bytes of flags, world x slice floats of inbox, world x slice floats of result. */
+typedef struct HpfgPeerBuf {
+  void* win[HPFG_PEER_MAX_RANKS];    /* win[r] = rank r's window as mapped in this process */
+  int32_t* epoch;                    /* device word counting the calls (the same sequence on every rank) */
+  int32_t* err;                      /* device word set to 1 when a poll expires (or NULL) */
+  int32_t world, rank;
+  int64_t slice;                     /* floats per rank slice: hpfg_peer_buf_slice(world, n) */
+  int64_t n;                         /* floats of the buffer */
+} HpfgPeerBuf;
+long hpfg_peer_buf_slice(int world, long n);                 /* ceil(n / world) rounded up to a multiple of 4 */
+long hpfg_peer_buf_bytes(int world, long n);                 /* window size for buffers of up to n floats */
+int hpfg_peer_allreduce_f32(const HpfgPeerBuf* pb, float* buf, void* stream);      /* buf[0..n) = SUM over ranks, in place */
+
 /* ---- losses (main.py:164-197, medloss.py:44-56, diceloss.py:155-191, Mean-Teacher :103-106) -------------- */
 typedef struct HpfgLossArgs {
   const float* logits;      /* [N,H,W,C] student logits (NHWC) */

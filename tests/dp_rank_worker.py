@@ -9,6 +9,8 @@ Runs steps of the REAL engine on this rank's shard of a fixed global batch and s
     HPFG_TEST_GRAPH    1 | 0                  the step as a chain of hipGraphs around the eager gradient exchange, as bench.py runs it
     HPFG_TEST_P2P      1 | 0                  (sync_bn = 1) BatchNorm / loss sums exchanged by the kernels through peer mailboxes (hipIpc) instead of
                                               host-launched collectives
+    HPFG_TEST_P2P_GRADS 1 | 0                 the gradient all-reduce through the peer windows (kernels on the step's stream; with GRAPH = 1 the whole step
+                                              is then ONE hipGraph) instead of a host-launched collective
 """
 import os
 import sys
@@ -68,7 +70,7 @@ def _frozen(m):
     return e
 
 
-def run(dev, dp, rank, world, steps=2, overlap=True, step="mt", sync_bn=True, graph=False, shard=None, fixed=False, p2p=False):
+def run(dev, dp, rank, world, steps=2, overlap=True, step="mt", sync_bn=True, graph=False, shard=None, fixed=False, p2p=False, p2p_grads=False):
     """shard: (rank, world) of the data this process sees when it runs WITHOUT a process group (the per-shard reference runs of the
     sync_bn = 0 test); with dp the shard is the rank's.  fixed: the same dropout masks and the step's own consistency law in every
     iteration -- what a captured graph replays (graph=True implies it: one eager warm-up step, the capture, one replay = 2 iterations)."""
@@ -81,6 +83,8 @@ def run(dev, dp, rank, world, steps=2, overlap=True, step="mt", sync_bn=True, gr
         dp.sync_bn, dp.overlap = sync_bn, overlap
         if p2p:
             dp.enable_peer_exchange()
+        if p2p_grads:
+            assert dp.enable_peer_grads(4 * 1024 * 1024), "the peer gradient exchange failed its self-test"
     xl, yl, xu = global_batch()
     srank, sworld = (rank, world) if shard is None else shard
     kl, ku = N_LAB // sworld, N_UNL // sworld
@@ -145,16 +149,43 @@ def run(dev, dp, rank, world, steps=2, overlap=True, step="mt", sync_bn=True, gr
     return (torch.stack(losses),) + tuple(saved())
 
 
+ALLREDUCE_SIZES = (1, 3, 4, 7, 1021, 4096, 65537, 1000003)
+
+
+def allreduce_case(rank, n):
+    g = torch.Generator().manual_seed(100 * n + rank)
+    return torch.randn(n, generator=g)
+
+
+def run_allreduce(dev, dp):
+    """The peer-window all-reduce alone: ragged sizes (tails, slices shorter than a vector, empty slices), several uses of the same window."""
+    assert dp.enable_peer_grads(1000003)
+    outs = []
+    for rep in range(2):
+        for n in ALLREDUCE_SIZES:
+            t = allreduce_case(dp.rank, n).to(dev)
+            outs.append(dp.peer_allreduce_sum(t).cpu())
+    torch.cuda.synchronize()
+    dp.check_peer_errors()
+    return tuple(outs)
+
+
 def main():
     out = sys.argv[1]
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     dp = parallel.init_from_env(dev, backend="gloo")
+    if os.environ.get("HPFG_TEST_STEP") == "allreduce":
+        try:
+            torch.save(run_allreduce(dev, dp), f"{out}.rank{dp.rank}")
+        finally:
+            dp.shutdown()
+        return
     try:
         res = run(dev, dp, dp.rank, dp.world_size, steps=int(os.environ.get("HPFG_TEST_STEPS", "2")), overlap=os.environ.get("HPFG_TEST_OVERLAP", "1") == "1",
                   step=os.environ.get("HPFG_TEST_STEP", "mt"), sync_bn=os.environ.get("HPFG_TEST_SYNC_BN", "1") == "1",
                   graph=os.environ.get("HPFG_TEST_GRAPH", "0") == "1", fixed=os.environ.get("HPFG_TEST_FIXED", "0") == "1",
-                  p2p=os.environ.get("HPFG_TEST_P2P", "0") == "1")
+                  p2p=os.environ.get("HPFG_TEST_P2P", "0") == "1", p2p_grads=os.environ.get("HPFG_TEST_P2P_GRADS", "0") == "1")
         torch.save(res, f"{out}.rank{dp.rank}")
     finally:
         dp.shutdown()

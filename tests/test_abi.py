@@ -29,7 +29,8 @@ def test_struct_layouts_match_header_field_order():
     src = open(os.path.join(ROOT, "include", "hpfg_hip.h")).read()
     for cname, pyt in (("HpfgAct", L.Act), ("HpfgConvArgs", L.ConvArgs), ("HpfgWgradArgs", L.WgradArgs), ("HpfgPackDesc", L.PackDesc),
                        ("HpfgLossArgs", L.LossArgs), ("HpfgAugSample", L.AugSample), ("HpfgSlabDesc", L.SlabDesc),
-                       ("HpfgPredBlocks", L.PredBlocks), ("HpfgFusedBwdArgs", L.FusedBwdArgs)):
+                       ("HpfgPredBlocks", L.PredBlocks), ("HpfgFusedBwdArgs", L.FusedBwdArgs), ("HpfgPeerX", L.PeerX),
+                       ("HpfgPeerBuf", L.PeerBuf)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []
@@ -39,7 +40,7 @@ def test_struct_layouts_match_header_field_order():
                 continue
             names = decl.split(",")
             first = names[0].split()[-1].lstrip("*")
-            first = re.sub(r"\[\d+\]$", "", first)          # array members: `const float* p[8]`
+            first = re.sub(r"\[\w+\]$", "", first)          # array members: `const float* p[8]`, `void* mbox[HPFG_PEER_MAX_RANKS]`
             fields.append(first)
             fields += [n.strip().lstrip("*") for n in names[1:]]
         assert fields == [f[0] for f in pyt._fields_], (cname, fields, [f[0] for f in pyt._fields_])

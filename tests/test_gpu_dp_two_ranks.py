@@ -7,6 +7,8 @@
     students + teacher on three streams, CutMix, Dense_Loss: BASELINE configs[2] is "DDP over 2/4/8").
     The same with the PEER MAILBOX exchange (p2p: the BatchNorm / loss sums cross the ranks inside the finalize kernels over hipIpc-mapped
     memory, no collective between kernels), eager and -- only possible that way -- captured into the chain of hipGraphs.
+  * the gradient exchange through peer windows (hpfg_peer_allreduce_f32: push / reduce / gather kernels behind epoch flags, no RCCL call):
+    ragged sizes against the plain sum, the per-rank mode with it == the mean of the shard runs, and the whole step as ONE hipGraph.
   * per-rank BatchNorm (sync_bn = False, what `bench.py --gpus N` times): after ONE step from identical weights the parameters equal the MEAN
     of the two single-process runs on the shards (SGD's first step is linear in the gradient), and the chain of hipGraphs around the eager
     exchange (both overlap settings) equals the eager run.
@@ -104,6 +106,42 @@ def test_global_batch_mode_with_peer_mailboxes_captures_into_graphs(tmp_path, st
     common = dict(HPFG_TEST_STEP=step, HPFG_TEST_OVERLAP=int(overlap), HPFG_TEST_SYNC_BN=1, HPFG_TEST_P2P=1, HPFG_TEST_STEPS=2)
     g0, g1 = _two_ranks(tmp_path, f"pg_{step}", HPFG_TEST_GRAPH=1, **common)
     e0, e1 = _two_ranks(tmp_path, f"pe_{step}", HPFG_TEST_GRAPH=0, HPFG_TEST_FIXED=1, **common)
+    assert torch.equal(g0[1], g1[1])
+    for a, b in zip(g0[1:], e0[1:]):
+        assert maxerr(a, b) < 1e-6
+    assert maxerr(g0[0][-1], e0[0][-1]) < 1e-6
+
+
+def test_peer_window_allreduce_ragged_sizes(tmp_path):
+    r0, r1 = _two_ranks(tmp_path, "ar", HPFG_TEST_STEP="allreduce")
+    k = 0
+    for rep in range(2):
+        for n in W.ALLREDUCE_SIZES:
+            want = W.allreduce_case(0, n) + W.allreduce_case(1, n)
+            assert torch.equal(r0[k], want) and torch.equal(r1[k], want), (rep, n)
+            k += 1
+
+
+@pytest.mark.parametrize("step", ["mt", "cps", "hpfg"])
+def test_peer_gradient_exchange_averages_the_shard_gradients(tmp_path, step):
+    """sync_bn = False with the gradient all-reduce through the peer windows: same contract as the collective (mean of the shard runs)."""
+    r0, r1 = _two_ranks(tmp_path, f"pg_{step}", HPFG_TEST_STEP=step, HPFG_TEST_OVERLAP=0, HPFG_TEST_SYNC_BN=0, HPFG_TEST_STEPS=1, HPFG_TEST_P2P_GRADS=1)
+    s0 = W.run(DEV, None, 0, 1, steps=1, step=step, shard=(0, 2))
+    s1 = W.run(DEV, None, 0, 1, steps=1, step=step, shard=(1, 2))
+    assert torch.equal(r0[1], r1[1])
+    assert maxerr(r0[1], 0.5 * (s0[1] + s1[1])) < 2e-6
+    if step != "mt":
+        assert torch.equal(r0[2], r1[2]) and maxerr(r0[2], 0.5 * (s0[2] + s1[2])) < 2e-6
+    assert maxerr(r0[0], s0[0]) < 1e-6 and maxerr(r1[0], s1[0]) < 1e-6
+
+
+@pytest.mark.parametrize("step,sync_bn", [("mt", 0), ("cps", 0), ("mt", 1)])
+def test_peer_gradient_exchange_makes_the_step_one_graph(tmp_path, step, sync_bn):
+    """No host-launched collective left (sync_bn = 1: BatchNorm / loss sums through the mailboxes as well): forward + loss + backward + exchange +
+    update captured as ONE hipGraph -- and equal to the eager two-rank run of the same two iterations with the host-launched all-reduce."""
+    common = dict(HPFG_TEST_STEP=step, HPFG_TEST_OVERLAP=0, HPFG_TEST_SYNC_BN=sync_bn, HPFG_TEST_P2P=sync_bn, HPFG_TEST_STEPS=2)
+    g0, g1 = _two_ranks(tmp_path, f"og_{step}{sync_bn}", HPFG_TEST_GRAPH=1, HPFG_TEST_P2P_GRADS=1, **common)
+    e0, e1 = _two_ranks(tmp_path, f"oe_{step}{sync_bn}", HPFG_TEST_GRAPH=0, HPFG_TEST_FIXED=1, **common)
     assert torch.equal(g0[1], g1[1])
     for a, b in zip(g0[1:], e0[1:]):
         assert maxerr(a, b) < 1e-6
