@@ -233,6 +233,8 @@ def timed_run(wl, dp, use_graph, steps, warmup, dev):
         except Exception as e:  # capture unsupported: fall back to eager launches (still the HIP path)
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             runner, use_graph = None, False
+        if dp is not None:
+            dp.barrier()      # every rank has finished capturing before any rank replays (the in-graph exchange polls its peers with a bound)
 
     def one(i):
         if runner is not None:

@@ -37,7 +37,7 @@ __device__ inline void pb_handshake(const HpfgPeerBuf& pb, int which, int32_t ep
     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != ep) {
       if (spins < 64) __builtin_amdgcn_s_sleep(1);
       else __builtin_amdgcn_s_sleep(32);
-      if (++spins > HPFG_PEER_MAX_SPINS) {          // every wave reaches an exit: report and go on
+      if (++spins > 8 * HPFG_PEER_MAX_SPINS) {      // (more patient than the mailbox polls: a rank may still be capturing its graph) every wave reaches an exit: report and go on
         if (pb.err) __hip_atomic_store(pb.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
