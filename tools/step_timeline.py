@@ -13,7 +13,7 @@ def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
     m = re.search(r"Cfg<([^>]*)>, (\d)", n)
     if m:
-        return ("ws " if "conv_ws" in n else "") + ("conv1x1 " if "1x1" in n else "conv ") + m.group(1).replace(" ", "") + " k" + m.group(2)
+        return ("conv1x1 " if "1x1" in n else "conv ") + m.group(1).replace(" ", "") + " k" + m.group(2)
     m = re.search(r"wgrad_bf16x3_kernel<([^>]*)>", n)
     if m:
         return "wgrad " + m.group(1).replace(" ", "")
