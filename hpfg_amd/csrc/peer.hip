@@ -47,8 +47,10 @@ __device__ inline void pb_handshake(const HpfgPeerBuf& pb, int which, int32_t ep
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
 }
 
-// (1) my copy of slice p -> rank p's inbox[my rank]; grid = (chunks, world)
+// (1) my copy of slice p -> rank p's inbox[my rank]; grid = (chunks, world).  One thread also counts the call (the epoch the two
+// handshakes of this call carry; nothing in this launch reads it).
 __global__ __launch_bounds__(256) void pb_push_kernel(HpfgPeerBuf pb, const float* __restrict__ buf) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *pb.epoch = (int32_t)(((uint32_t)*pb.epoch + 1u) & 0x7fffffffu);
   const int p = blockIdx.y;
   if (p == pb.rank) return;
   const long cnt = pb_count(pb, p);
@@ -113,7 +115,6 @@ extern "C" int hpfg_peer_allreduce_f32(const HpfgPeerBuf* pb, float* buf, void* 
   HPFG_ARG_CHECK(((uintptr_t)buf & 15) == 0, "peer_allreduce: the buffer must be 16-byte aligned");
   for (int r = 0; r < pb->world; ++r) HPFG_ARG_CHECK(pb->win[r], "peer_allreduce: window of rank %d not mapped", r);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(word_add_kernel, dim3(1), dim3(64), 0, st, pb->epoch, 1);
   const long c4 = pb->slice / 4;
   const int chunks = (int)(c4 / 256 < 1 ? 1 : (c4 / 256 > 64 ? 64 : c4 / 256));
   hipLaunchKernelGGL(pb_push_kernel, dim3(chunks, pb->world), dim3(256), 0, st, *pb, (const float*)buf);

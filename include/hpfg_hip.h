@@ -232,8 +232,7 @@ int hpfg_bn_bwd_finalize_x(const float* partials, int nblk, const HpfgPeerX* px,
  * ran on more than one card (main.py:44: it does not).  xGMI is point to point, so the exchange is not a ring: every rank owns one slice of the
  * buffer; (1) push: each rank stores its copy of slice p into rank p's window (all links busy at once), (2) reduce: the owner adds the
  * contributions in rank order and stores the reduced slice into every rank's window, (3) gather: each rank copies the reduced buffer back.
- * Flags carry the epoch (consecutive use counts, bumped by the call itself); polls are bounded like the mailbox polls.  Three launches + the
- * epoch bump on `stream`, no host code: the whole training step stays ONE hipGraph under data parallel.  Every rank receives bit-identical
+ * Flags carry the epoch (consecutive use counts, bumped by the call itself); polls are bounded like the mailbox polls.  Three launches on `stream`, no host code: the whole training step stays ONE hipGraph under data parallel.  Every rank receives bit-identical
  * sums (each slice is reduced once).  Window layout: 256 bytes of flags, world x slice floats of inbox, world x slice floats of result. */
 typedef struct HpfgPeerBuf {
   void* win[HPFG_PEER_MAX_RANKS];    /* win[r] = rank r's window as mapped in this process */
