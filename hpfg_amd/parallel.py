@@ -200,13 +200,17 @@ class DataParallelContext:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)          # (everything is mapped everywhere, or nobody starts)
         if int(flag.item()) == 1:
             self.p2p_grads = True
-            n = min(self.grad_floats, 262147)
-            t = (torch.arange(n, device=self.device, dtype=torch.float32) % 97.0) * float(self.rank + 1)
-            want = (torch.arange(n, device=self.device, dtype=torch.float32) % 97.0) * float(self.world_size * (self.world_size + 1) // 2)
-            for _ in range(2):          # twice: the second use of the flags is the one every later step repeats
-                got = self.peer_allreduce_sum(t.clone())
-            torch.cuda.synchronize(self.device)
-            good = bool(torch.equal(got, want)) and int(self.peer_err.item()) == 0
+            good = False
+            try:          # (a rank that fails here still reaches the agreement below)
+                n = min(self.grad_floats, 262147)
+                t = (torch.arange(n, device=self.device, dtype=torch.float32) % 97.0) * float(self.rank + 1)
+                want = (torch.arange(n, device=self.device, dtype=torch.float32) % 97.0) * float(self.world_size * (self.world_size + 1) // 2)
+                for _ in range(2):          # twice: the second use of the flags is the one every later step repeats
+                    got = self.peer_allreduce_sum(t.clone())
+                torch.cuda.synchronize(self.device)
+                good = bool(torch.equal(got, want)) and int(self.peer_err.item()) == 0
+            except Exception as e:
+                print(f"[hpfg_amd.parallel] rank {self.rank}: peer-window self-test raised {type(e).__name__}: {e}", flush=True)
             flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=self.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
             self.p2p_grads = int(flag.item()) == 1
