@@ -210,7 +210,8 @@ class DataParallelContext:
                 torch.cuda.synchronize(self.device)
                 good = bool(torch.equal(got, want)) and int(self.peer_err.item()) == 0
             except Exception as e:
-                print(f"[hpfg_amd.parallel] rank {self.rank}: peer-window self-test raised {type(e).__name__}: {e}", flush=True)
+                import sys
+                print(f"[hpfg_amd.parallel] rank {self.rank}: peer-window self-test raised {type(e).__name__}: {e}", file=sys.stderr, flush=True)
             flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=self.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
             self.p2p_grads = int(flag.item()) == 1
