@@ -52,6 +52,12 @@ def test_argument_errors_are_reported_not_crashed():
     assert b"null" in lib.hpfg_last_error()
     assert lib.hpfg_wgrad(None, None) == -1
     assert lib.hpfg_fused_bwd(None, None) == -1 and lib.hpfg_fused_bwd_grid(None) == -1
+    assert lib.hpfg_peer_allreduce_f32(None, None, None) == -1 and b"null" in lib.hpfg_last_error()
+    pb = L.PeerBuf()
+    pb.world, pb.rank, pb.n, pb.slice = 9, 0, 16, 4
+    assert lib.hpfg_peer_allreduce_f32(ctypes.byref(pb), ctypes.c_void_p(256), None) == -1          # more ranks than a node has
+    pb.world, pb.n, pb.slice = 1, 16, 16
+    assert lib.hpfg_peer_allreduce_f32(ctypes.byref(pb), ctypes.c_void_p(256), None) == 0           # one rank: nothing to exchange, nothing launched
     assert lib.hpfg_conv_stat_blocks(2, 32, 32) == 2 * 4 and lib.hpfg_conv_stat_blocks(1, 24, 24) == 12
     assert lib.hpfg_wgrad_splits(16, 224, 224, 16, 16, 9) >= 1
     assert ctypes.sizeof(L.Act) % 8 == 0
@@ -69,3 +75,7 @@ def test_host_side_size_queries():
     # one BatchNorm partial-sum row per workgroup of the first layer, at most 1024
     assert lib.hpfg_conv_first_rows(16, 224, 224) == 1024 and lib.hpfg_conv_first_rows(2, 32, 32) == 8
     assert lib.hpfg_upsample2x_bwd_blocks(16, 112, 112, 16) % 8 == 0   # (the XCD-aware ranges need a multiple of 8 workgroups)
+    # peer-window gradient exchange: one slice per rank, a multiple of 4 floats; window = 256 bytes of flags + inbox + result
+    assert lib.hpfg_peer_buf_slice(8, 1001) == 128 and lib.hpfg_peer_buf_slice(2, 10) == 8 and lib.hpfg_peer_buf_slice(1, 7) == 8
+    assert lib.hpfg_peer_buf_bytes(2, 10) == 256 + 2 * 2 * 8 * 4
+    assert lib.hpfg_peer_slot_bytes(2, 512) > 0
