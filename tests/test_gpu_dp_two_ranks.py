@@ -37,12 +37,12 @@ def _free_port():
     return p
 
 
-def _two_ranks(tmp_path, tag, **env_kw):
+def _two_ranks(tmp_path, tag, world=2, **env_kw):
     out = str(tmp_path / tag)
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", **{k: str(v) for k, v in env_kw.items()})
         procs.append(subprocess.Popen([sys.executable, "-X", "faulthandler", "-m", "tests.dp_rank_worker", out], cwd=ROOT, env=env))
     try:
@@ -52,7 +52,7 @@ def _two_ranks(tmp_path, tag, **env_kw):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    return torch.load(f"{out}.rank0"), torch.load(f"{out}.rank1")
+    return tuple(torch.load(f"{out}.rank{r}") for r in range(world))
 
 
 @pytest.mark.parametrize("step,overlap,p2p", [("mt", True, 0), ("mt", False, 0), ("cps", True, 0), ("cps", False, 0), ("hpfg", True, 0), ("hpfg", False, 0),
@@ -112,13 +112,18 @@ def test_global_batch_mode_with_peer_mailboxes_captures_into_graphs(tmp_path, st
     assert maxerr(g0[0][-1], e0[0][-1]) < 1e-6
 
 
-def test_peer_window_allreduce_ragged_sizes(tmp_path):
-    r0, r1 = _two_ranks(tmp_path, "ar", HPFG_TEST_STEP="allreduce")
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_window_allreduce_ragged_sizes(tmp_path, world):
+    """(four ranks -- four processes on this one GPU -- exercise the slice / flag indexing beyond a pair; sums are formed in rank order)"""
+    res = _two_ranks(tmp_path, f"ar{world}", world=world, HPFG_TEST_STEP="allreduce")
     k = 0
     for rep in range(2):
         for n in W.ALLREDUCE_SIZES:
-            want = W.allreduce_case(0, n) + W.allreduce_case(1, n)
-            assert torch.equal(r0[k], want) and torch.equal(r1[k], want), (rep, n)
+            want = torch.zeros(n)
+            for r in range(world):
+                want = want + W.allreduce_case(r, n)
+            for got in res:
+                assert torch.equal(got[k], want), (rep, n)
             k += 1
 
 
