@@ -84,7 +84,7 @@ def parse():
     ap.add_argument("--force-sync", action="store_true", help="diagnostics: run the data-parallel code path (RCCL collectives) on one rank")
     ap.add_argument("--sync-bn", action="store_true", help="N > 1: all-reduce every BatchNorm statistic and the loss sums (R ranks == one process on the "
                     "global batch) instead of the default per-rank BatchNorm + averaged gradients (DDP semantics)")
-    ap.add_argument("--overlap", action="store_true", help="N > 1: bucketed gradient all-reduce overlapped with the encoder half of backward (a chain of "
+    ap.add_argument("--overlap", action="store_true", help="N > 1: bucketed gradient exchange overlapped with the encoder half of backward (peer windows: inside the one graph; --rccl: a chain of "
                     "hipGraphs around eager RCCL calls) instead of ONE all-reduce between two hipGraphs")
     ap.add_argument("--no-overlap", action="store_true", help="(the default; kept for older command lines)")
     ap.add_argument("--rccl", action="store_true", help="N > 1: the gradient all-reduce as an RCCL call between two hipGraphs instead of the peer-window "
@@ -528,14 +528,15 @@ def main():
         # N > 1 default: the flat gradients cross the ranks through IPC-mapped peer windows (xGMI pushes: csrc/peer.hip) as kernels of the
         # captured step -- one hipGraph per step, as at N = 1.  The path is tried on the actual devices first; RCCL between two graphs otherwise.
         exchange = "RCCL all-reduce between two hipGraphs"
-        if not a.rccl and not dp.overlap:
+        if not a.rccl:
             nmax = max([int(m.flat_grads.numel()) if hasattr(m, "flat_grads") and not hasattr(m, "_hpfg_generic_flat") else
                         sum(p.numel() for p in m.parameters() if p.requires_grad) for m in wl.models if any(p.requires_grad for p in m.parameters())] or [0])
             if nmax and dp.enable_peer_grads(nmax):
-                exchange = "peer-window all-reduce over xGMI (push / reduce / gather kernels inside the step's hipGraph)"
+                exchange = "peer-window all-reduce over xGMI (push / reduce / gather kernels inside the step's hipGraph" + \
+                    (", decoder bucket on a side stream beside the encoder half of backward)" if dp.overlap else ")")
             elif rank == 0:
                 print("[bench] peer-window gradient exchange unavailable on this node; using RCCL", file=sys.stderr)
-        elif dp.overlap:
+        if dp.overlap and not dp.p2p_grads:
             exchange = "bucketed RCCL all-reduces overlapped with backward (chain of hipGraphs)"
 
     # N > 1: graphs around the gradient all-reduce (no RCCL node inside a hipGraph).  --sync-bn exchanges the BatchNorm / loss sums inside the

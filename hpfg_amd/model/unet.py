@@ -104,7 +104,7 @@ class _UNetFn(torch.autograd.Function):
             df = dfeat.permute(0, 2, 3, 1).contiguous()
         dp = net.dp
         cb = None
-        if dp is not None and dp.active and getattr(dp, "overlap", False) and getattr(eng, "direct", False) and not getattr(dp, "p2p_grads", False):
+        if dp is not None and dp.active and getattr(dp, "overlap", False) and getattr(eng, "direct", False):
             # data parallel: hand each finished slice of the flat gradient buffer to the all-reduce while backward continues
             cb = lambda i: dp.launch_bucket(net.grad_bucket(i))
             net._buckets_launched = True

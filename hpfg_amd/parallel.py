@@ -78,6 +78,19 @@ class DataParallelContext:
         the collective runs on a side stream that waits for the producers; `join_buckets()` makes the consumers wait for it."""
         if not self.active:
             return
+        if self.p2p_grads and t.is_cuda:
+            # peer windows: the exchange is three launches on the side stream, forked from and joined into the step's stream -- capturable, so
+            # the bucket runs beside the encoder half of backward INSIDE the step's one hipGraph (buckets follow each other on the side stream:
+            # one window, one epoch sequence)
+            main = torch.cuda.current_stream(t.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=t.device)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                self.peer_allreduce_sum(t)
+            t.record_stream(self._side)
+            self._pending = True
+            return
         if self.bucket_hook is not None:
             self.bucket_hook(t)
             return
