@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ = range(7)
 LOSS_NSUM = 32
-VERSION = 126
+VERSION = 127
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -51,7 +51,7 @@ class PeerX(C.Structure):
 
 class PeerBuf(C.Structure):
     _fields_ = [("win", C.c_void_p * 8), ("epoch", C.c_void_p), ("err", C.c_void_p), ("world", C.c_int32), ("rank", C.c_int32),
-                ("slice", C.c_int64), ("n", C.c_int64)]
+                ("slice", C.c_int64), ("n", C.c_int64), ("stride", C.c_int64)]
 
 
 class FusedBwdArgs(C.Structure):

@@ -12,10 +12,10 @@ constexpr int PB_FLAG_BYTES = 256;          // in_flag[r] at int 0..7, out_flag[
 constexpr int PB_WG = 96;                   // workgroups of the polling kernels: few enough to share one GPU with another rank's kernels (tests)
 
 __device__ __forceinline__ float* pb_inbox(const HpfgPeerBuf& pb, int owner, int src) {
-  return reinterpret_cast<float*>(reinterpret_cast<char*>(pb.win[owner]) + PB_FLAG_BYTES) + (size_t)src * pb.slice;
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(pb.win[owner]) + PB_FLAG_BYTES) + (size_t)src * pb.stride;
 }
 __device__ __forceinline__ float* pb_result(const HpfgPeerBuf& pb, int owner) {
-  return reinterpret_cast<float*>(reinterpret_cast<char*>(pb.win[owner]) + PB_FLAG_BYTES) + (size_t)pb.world * pb.slice;
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(pb.win[owner]) + PB_FLAG_BYTES) + (size_t)pb.world * pb.stride;
 }
 __device__ __forceinline__ long pb_count(const HpfgPeerBuf& pb, int s) {          // valid floats of slice s
   const long c = pb.n - (long)s * pb.slice;
@@ -112,6 +112,9 @@ extern "C" int hpfg_peer_allreduce_f32(const HpfgPeerBuf* pb, float* buf, void* 
                  pb->world, pb->rank);
   if (pb->world == 1 || pb->n == 0) return 0;
   HPFG_ARG_CHECK(pb->epoch && pb->n > 0 && pb->slice == hpfg_peer_buf_slice(pb->world, pb->n), "peer_allreduce: bad epoch / n / slice");
+  // the window layout comes from the capacity, never from this call's n (consecutive calls of different sizes share the window without a handshake between them)
+  HPFG_ARG_CHECK(pb->stride >= pb->slice && pb->stride % 4 == 0 && (long)pb->world * pb->slice <= (long)pb->world * pb->stride,
+                 "peer_allreduce: stride %ld must be the capacity slice (a multiple of 4, >= this call's slice %ld)", (long)pb->stride, (long)pb->slice);
   HPFG_ARG_CHECK(((uintptr_t)buf & 15) == 0, "peer_allreduce: the buffer must be 16-byte aligned");
   for (int r = 0; r < pb->world; ++r) HPFG_ARG_CHECK(pb->win[r], "peer_allreduce: window of rank %d not mapped", r);
   hipStream_t st = (hipStream_t)stream;

@@ -245,6 +245,7 @@ class DataParallelContext:
         pb = L.PeerBuf()
         pb.world, pb.rank, pb.n = self.world_size, self.rank, t.numel()
         pb.slice = lib.hpfg_peer_buf_slice(self.world_size, t.numel())
+        pb.stride = lib.hpfg_peer_buf_slice(self.world_size, self.grad_floats)      # layout from the CAPACITY: independent of this call's size
         pb.epoch, pb.err = self.grad_epoch.data_ptr(), self.peer_err.data_ptr()
         for r in range(self.world_size):
             pb.win[r] = self._gpeers[r]

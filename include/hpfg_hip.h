@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 126
+#define HPFG_VERSION 127
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -239,8 +239,11 @@ typedef struct HpfgPeerBuf {
   int32_t* epoch;                    /* device word counting the calls (the same sequence on every rank) */
   int32_t* err;                      /* device word set to 1 when a poll expires (or NULL) */
   int32_t world, rank;
-  int64_t slice;                     /* floats per rank slice: hpfg_peer_buf_slice(world, n) */
+  int64_t slice;                     /* floats per rank slice of THIS call: hpfg_peer_buf_slice(world, n) */
   int64_t n;                         /* floats of the buffer */
+  int64_t stride;                    /* floats between the inbox regions of a window = hpfg_peer_buf_slice(world, CAPACITY the windows were sized
+                                        for); the result region begins at world * stride.  The layout must not depend on the call's n: a rank
+                                        that has finished call k pushes call k+1 while a peer may still copy its call-k result out */
 } HpfgPeerBuf;
 long hpfg_peer_buf_slice(int world, long n);                 /* ceil(n / world) rounded up to a multiple of 4 */
 long hpfg_peer_buf_bytes(int world, long n);                 /* window size for buffers of up to n floats */

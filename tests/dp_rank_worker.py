@@ -150,6 +150,7 @@ def run(dev, dp, rank, world, steps=2, overlap=True, step="mt", sync_bn=True, gr
 
 
 ALLREDUCE_SIZES = (1, 3, 4, 7, 1021, 4096, 65537, 1000003)
+ALTERNATING = (630001, 1000003, 4099, 1000003, 630001, 300007) * 4      # (decoder bucket, encoder bucket, ... of different models: ADVICE r3)
 
 
 def allreduce_case(rank, n):
@@ -165,6 +166,14 @@ def run_allreduce(dev, dp):
         for n in ALLREDUCE_SIZES:
             t = allreduce_case(dp.rank, n).to(dev)
             outs.append(dp.peer_allreduce_sum(t).cpu())
+    # consecutive calls of DIFFERENT sizes with the ranks alternately held back on the device (a spin kernel in front of the call): the
+    # window layout must not depend on the size -- a rank that has finished call k pushes call k + 1 while its peer still reads call k
+    for k, n in enumerate(ALTERNATING):
+        if k % dp.world_size == dp.rank:
+            torch.cuda._sleep(400_000)
+        t = allreduce_case(dp.rank, n).to(dev)
+        outs.append(dp.peer_allreduce_sum(t).cpu() if k % 5 == 4 else dp.peer_allreduce_sum(t))
+    outs = [o.cpu() for o in outs]
     torch.cuda.synchronize()
     dp.check_peer_errors()
     return tuple(outs)

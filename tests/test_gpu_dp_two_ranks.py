@@ -125,6 +125,13 @@ def test_peer_window_allreduce_ragged_sizes(tmp_path, world):
             for got in res:
                 assert torch.equal(got[k], want), (rep, n)
             k += 1
+    for n in W.ALTERNATING:          # sizes alternate, ranks alternately delayed: the window layout does not depend on the call's size
+        want = torch.zeros(n)
+        for r in range(world):
+            want = want + W.allreduce_case(r, n)
+        for got in res:
+            assert torch.equal(got[k], want), ("alternating", k, n)
+        k += 1
 
 
 @pytest.mark.parametrize("step", ["mt", "cps", "hpfg"])
