@@ -23,31 +23,23 @@ namespace hpfg_conv16 {
 
 using namespace hpfg_stage;
 
-// NKG (k-groups, round 4): an 8-wave workgroup for the deep layers whose 4-wave form leaves one wave per SIMD (<= 256 workgroups on 256 CUs).  A
-// staged chunk then holds NKG * KC input channels and wave group g (waves 4g .. 4g+3) contracts channels [g * KC, (g + 1) * KC) of it with the
-// whole 3x3 tap loop of the 4-wave kernel; the groups' accumulators are added through LDS once per tile.  Two waves per SIMD share one staged
-// tile (half the conversion work per thread, half the barriers per channel) instead of nothing hiding the LDS / L2 latencies of a lone wave.
-// WN = 8 (NKG = 1) is the other 8-wave form: a 128-wide output slice for the 28 x 28 layers (each staged element feeds 8 waves).
-template <int TH_, int TW_, int WM_, int WN_, int NI_, int TAPS_, int KC_, int NKG_ = 1>
+template <int TH_, int TW_, int WM_, int WN_, int NI_, int TAPS_, int KC_>
 struct Cfg {
-  static constexpr int TH = TH_, TW = TW_, WM = WM_, WN = WN_, NI = NI_, TAPS = TAPS_, KC = KC_, NKG = NKG_;
-  static constexpr int NW = WM * WN * NKG, NTHR = 64 * NW;      // waves / threads per workgroup
-  static constexpr int KCT = KC * NKG;                            // input channels per staged chunk
+  static constexpr int TH = TH_, TW = TW_, WM = WM_, WN = WN_, NI = NI_, TAPS = TAPS_, KC = KC_;
   static constexpr int MI = TH * TW / 16 / WM;
   static constexpr int BN = 16 * NI * WN;
   static constexpr int HALO = TAPS == 9 ? 1 : 0;
   static constexpr int HP = TH + 2 * HALO, WP = TW + 2 * HALO;
   static constexpr int RS = TW == 16 ? WP : (TAPS == 9 ? 24 : 8);   // row stride in 16-B slots
   static constexpr int NSLOT = (HP * RS + 15) / 16 * 16;
-  static constexpr int NG = KCT / 8;
+  static constexpr int NG = KC / 8;
   static constexpr int PLANE = NSLOT * 16;
   static constexpr int BUF_BYTES = NG * 2 * PLANE;
   static constexpr int KSTEPS = TAPS == 1 ? 1 : (KC == 32 ? 9 : 5);
   static constexpr int NPIECE = HP * WP * NG;
-  static constexpr int NLD = (NPIECE + NTHR - 1) / NTHR;
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-  static_assert(NKG == 1 || (NKG == 2 && KC == 32 && TAPS == 9 && MI % 2 == 0), "k-groups: two halves of a 64-channel chunk of the 3x3 kernel");
-  static_assert(NTHR % NG == 0, "a thread must keep one channel group");
+  static constexpr int NLD = (NPIECE + 255) / 256;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(256 % NG == 0, "a thread must keep one channel group");
   static_assert(KC == 32 || (KC == 16 && TAPS == 9), "two-tap K packing only for 3x3");
   static_assert(TAPS == 1 || NLD + 2 <= KSTEPS, "stage pipeline must fit into the k-steps of a chunk");
 };
@@ -61,7 +53,7 @@ struct Piece {
 template <class C>
 __device__ __forceinline__ Piece make_piece(int tid, int i) {
   Piece q;
-  const int idx = tid + i * C::NTHR;
+  const int idx = tid + i * 256;
   const int pix = idx / C::NG, g = idx % C::NG;
   q.ok = idx < C::NPIECE;
   q.ly = pix / C::WP - C::HALO;
@@ -105,11 +97,10 @@ __device__ __forceinline__ void conv16_load_bias(const HpfgConvArgs& p, f32x4 (&
 // BatchNorm layer p.bwd_of, and (s1, s2) collect that layer's backward sums  sum(g), sum(g * xhat)  with
 // g = out * dropout * LeakyReLU'(bn(z))  -- the separate streaming pass over (dA, z) of hpfg_bn_bwd_reduce, done while the tile is
 // still in registers (it costs one read of z instead of a read of both tensors, and a launch).
-// MC / m0: the wave stores MC of its MI pixel tiles, beginning with tile m0 (k-group kernels: each wave group finishes half of the tiles)
-template <class C, bool BWD_OK = false, int MC = C::MI>
-__device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (&acc)[MC][C::NI], f32x4 (&s1)[C::NI], f32x4 (&s2)[C::NI],
+template <class C, bool BWD_OK = false>
+__device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (&acc)[C::MI][C::NI], f32x4 (&s1)[C::NI], f32x4 (&s2)[C::NI],
                                                   const f32x4 (&bias)[C::NI], int lane, int wm, int nt0, int n, int ty0, int tx0,
-                                                  bool reload_bias = false, int m0 = 0) {
+                                                  bool reload_bias = false) {
   const int H = p.H, W = p.W;
   const bool vec = (p.Cout & 3) == 0 && (p.out_pstride & 3) == 0 && (p.out2_pstride & 3) == 0;
   const bool bwd = BWD_OK && p.bwd_stats;
@@ -131,18 +122,18 @@ __device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (
     }
     // bwd: request the z values of all MI pixel tiles of this channel group before the first one is used (one exposed round trip per
     // channel group instead of one per tile when the scheduler would otherwise pair each load with its use)
-    f32x4 zq[MC];
+    f32x4 zq[C::MI];
     if (bwd) {
 #pragma unroll
-      for (int m = 0; m < MC; ++m) {
-        const int pxl = (wm * C::MI + m0 + m) * 16 + (lane & 15);
+      for (int m = 0; m < C::MI; ++m) {
+        const int pxl = (wm * C::MI + m) * 16 + (lane & 15);
         const int gy = min(ty0 + pxl / C::TW, H - 1), gx = min(tx0 + pxl % C::TW, W - 1);
         zq[m] = *reinterpret_cast<const f32x4*>(p.bwd_of.z + (((long)n * H + gy) * W + gx) * p.bwd_of.pstride + min(co, p.Cout - 4));
       }
     }
 #pragma unroll
-    for (int m = 0; m < MC; ++m) {
-      const int pxl = (wm * C::MI + m0 + m) * 16 + (lane & 15);
+    for (int m = 0; m < C::MI; ++m) {
+      const int pxl = (wm * C::MI + m) * 16 + (lane & 15);
       const int gy = ty0 + pxl / C::TW, gx = tx0 + pxl % C::TW;
       if (gy < H && gx < W && co < p.Cout) {
         f32x4 v = acc[m][j] + b;
@@ -184,7 +175,6 @@ __device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (
 template <class C, bool BWD = false>
 __device__ __forceinline__ void conv16_flush_stats(const HpfgConvArgs& p, f32x4 (&s1)[C::NI], f32x4 (&s2)[C::NI], float* ldsf, int tid, int lane, int wm,
                                                    int wn, int cb, int row) {
-  constexpr int WR = C::WM * C::NKG;      // wave rows that share output channels (wm = pixel-tile row of the wave, k-group included)
   if (!p.stat_partials || (p.math & 0x1000)) return;
 #pragma unroll
   for (int j = 0; j < C::NI; ++j)
@@ -203,8 +193,8 @@ __device__ __forceinline__ void conv16_flush_stats(const HpfgConvArgs& p, f32x4 
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) {
       const int cl = (wn * C::NI + j) * 16 + (lane >> 4) * 4;
-      *reinterpret_cast<f32x4*>(ldsf + (0 * WR + wm) * C::BN + cl) = s1[j];
-      *reinterpret_cast<f32x4*>(ldsf + (1 * WR + wm) * C::BN + cl) = s2[j];
+      *reinterpret_cast<f32x4*>(ldsf + (0 * C::WM + wm) * C::BN + cl) = s1[j];
+      *reinterpret_cast<f32x4*>(ldsf + (1 * C::WM + wm) * C::BN + cl) = s2[j];
     }
   }
   __syncthreads();
@@ -212,12 +202,12 @@ __device__ __forceinline__ void conv16_flush_stats(const HpfgConvArgs& p, f32x4 
     const int which = tid / C::BN, cl = tid % C::BN;
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < WR; ++w) t += ldsf[(which * WR + w) * C::BN + cl];
+    for (int w = 0; w < C::WM; ++w) t += ldsf[(which * C::WM + w) * C::BN + cl];
     const int co = cb * C::BN + cl;
     if (BWD && p.bwd_stats && which == 1 && co < p.Cout) {       // sum(g*z) -> sum(g*xhat)
       float sg = 0.f;
 #pragma unroll
-      for (int w = 0; w < WR; ++w) sg += ldsf[w * C::BN + cl];
+      for (int w = 0; w < C::WM; ++w) sg += ldsf[w * C::BN + cl];
       const float* tb = p.bwd_of.bn + p.bwd_of.bn_coff + co;
       t = tb[HPFG_BN_RSTD * p.bwd_of.bn_stride] * (t - tb[HPFG_BN_MEAN * p.bwd_of.bn_stride] * sg);
     }
@@ -239,8 +229,8 @@ template <class C>
 struct UpGeo {
   static constexpr int SH = C::TH / 2 + 3, SW = C::TW / 2 + 3;
   static constexpr int NPIECE = SH * SW * C::NG;
-  static constexpr int BYTES = SH * SW * C::KCT * 4;
-  static_assert(NPIECE <= C::NTHR, "one source piece per thread");
+  static constexpr int BYTES = SH * SW * C::KC * 4;
+  static_assert(NPIECE <= 256, "one source piece per thread");
 };
 template <int KIND>
 constexpr int eff_nr() { return KIND == HPFG_KIND_CAT ? 2 : RawCount<KIND>::N; }   // float4 loads in flight per piece
@@ -255,7 +245,6 @@ __device__ __forceinline__ int up_base(int o0, int L) {
 // workgroups per CU keep more tile loads in flight; everything else needs the registers of a two-per-CU budget.
 template <class C, int KIND>
 constexpr int wg_per_cu() {
-  if (C::NW == 8) return 1;      // 8-wave workgroups: two waves per SIMD from ONE workgroup
   return (C::KSTEPS == 5 && C::NI == 1 && RawCount<KIND>::N <= 2) ? 3 : 2;      // (the concat kernel would spill at 168 VGPRs)
 }
 
@@ -278,10 +267,9 @@ constexpr int wg_per_cu() {
 // BWD: the dgrad variant whose epilogue also produces the BatchNorm-backward sums of the layer below (p.bwd_stats); a separate
 // instantiation so that the plain kernels keep their register budget.
 template <class C, int KIND, bool BWD = false>
-__global__ __launch_bounds__(C::NTHR, (wg_per_cu<C, KIND>())) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   static_assert(C::TAPS == 9, "persistent kernel is the 3x3 path");
   constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
-  static_assert(C::WM * C::NKG <= 4, "statistics scratch: at most 4 wave rows per sum");
   constexpr int NR = eff_nr<KIND>();
   constexpr bool CATK = KIND == HPFG_KIND_CAT;
   constexpr int UP_BYTES = CATK ? UpGeo<C>::BYTES : 0;
@@ -290,8 +278,7 @@ __global__ __launch_bounds__(C::NTHR, (wg_per_cu<C, KIND>())) void conv_bf16x3_k
   float* ldsU = reinterpret_cast<float*>(lds + 2 * C::BUF_BYTES + STAT_BYTES);      // low-res source patch of an upsampled chunk
   (void)ldsU;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kgrp = wave / (C::WM * C::WN), wv = wave % (C::WM * C::WN);      // k-group (0 unless NKG == 2) and wave inside it
-  const int wm = wv % C::WM, wn = wv / C::WM;
+  const int wm = wave % C::WM, wn = wave / C::WM;
   const int cb = blockIdx.y;
   const int H = p.H, W = p.W;
   const int ntiles = tiles_x * tiles_y, nwork = ntiles * p.N;
@@ -316,7 +303,7 @@ __global__ __launch_bounds__(C::NTHR, (wg_per_cu<C, KIND>())) void conv_bf16x3_k
 #pragma unroll
   for (int m = 0; m < C::MI; ++m) {
     const int pxl = (wm * C::MI + m) * 16 + (lane & 15);
-    aoff[m] = ((gl + kgrp * (C::KC / 8)) * 2) * C::PLANE + ((pxl / C::TW) * C::RS + (pxl % C::TW)) * 16;
+    aoff[m] = (gl * 2) * C::PLANE + ((pxl / C::TW) * C::RS + (pxl % C::TW)) * 16;
   }
   // byte offsets of the k-steps' taps for this lane (KC=16 packs taps 2s, 2s+1 into one MFMA; tap 9 re-reads tap 8: zero weights)
   int toff[C::KSTEPS];
@@ -332,7 +319,7 @@ __global__ __launch_bounds__(C::NTHR, (wg_per_cu<C, KIND>())) void conv_bf16x3_k
   const int g8 = (tid % C::NG) * 8;          // this thread's channel group inside a chunk
 
   const int cin_total = p.a0.C + p.a1.C;
-  const int nchunks = (cin_total + C::KCT - 1) / C::KCT;
+  const int nchunks = (cin_total + C::KC - 1) / C::KC;
   const int ntn = p.CoutPad / 16;
   const int nt0 = (cb * C::WN + wn) * C::NI;
   const bf16x8* wpk = reinterpret_cast<const bf16x8*>(p.wpk);
@@ -393,10 +380,10 @@ __global__ __launch_bounds__(C::NTHR, (wg_per_cu<C, KIND>())) void conv_bf16x3_k
   // requested during the previous chunk, i.e. before this chunk's prefetch, and the k-loop never waits on it.
   constexpr int BR = C::KSTEPS == 5 ? 5 : (C::NI == 1 ? 9 : 3), BD = BR - 1;
   static_assert(C::KSTEPS % BR == 0, "ring size must divide the k-steps of a chunk");
-  // (k-step index in the packed weights: 32-channel chunk (ch * NKG + kgrp), tap s)
+  const int kperiod = nchunks * C::KSTEPS;
   bf16x8 bh[BR][C::NI], bl[BR][C::NI];
 #pragma unroll
-  for (int d = 0; d < BD; ++d) load_b<C>(bh[d], bl[d], wpk, kgrp * C::KSTEPS + d, ntn, nt0, lane);
+  for (int d = 0; d < BD; ++d) load_b<C>(bh[d], bl[d], wpk, d % kperiod, ntn, nt0, lane);
   HPFG_TR(3)
   __syncthreads();
   HPFG_TR(4)
@@ -424,7 +411,7 @@ __global__ __launch_bounds__(C::NTHR, (wg_per_cu<C, KIND>())) void conv_bf16x3_k
         nty = y2 * C::TH;
         ntx = x2 * C::TW;
       }
-      const int c0n = nch * C::KCT + g8;
+      const int c0n = nch * C::KC + g8;
       const bool chvn = more && c0n < cin_total && !(p.math & 0x400);
       const int c0c = c0n < cin_total ? c0n : 0;
       // No branches from here to the barrier (except the CAT loader's per-thread source select): the tables are reloaded even when
@@ -440,7 +427,7 @@ __global__ __launch_bounds__(C::NTHR, (wg_per_cu<C, KIND>())) void conv_bf16x3_k
       // concat: a chunk is entirely skip half (BN + LeakyReLU pieces, like BNACT) or entirely upsampled half (a0.C % KC == 0)
       constexpr int SK = CATK ? HPFG_KIND_BNACT : KIND;        // loader kind of the per-pixel pieces held in `raw`
       RawPiece<SK> raw[DEEP ? C::NLD : 2];
-      const bool up_next = CATK && nch * C::KCT >= p.a0.C;       // workgroup-uniform
+      const bool up_next = CATK && nch * C::KC >= p.a0.C;       // workgroup-uniform
       f32x4 rawU[2];
       int sy_base = 0, sx_base = 0;
       if (CATK && up_next) {
@@ -502,9 +489,9 @@ __global__ __launch_bounds__(C::NTHR, (wg_per_cu<C, KIND>())) void conv_bf16x3_k
               issue_piece<SK>(raw[i & 1], p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
             }
           }
-          int chb = ch + ((s + BD) >= C::KSTEPS ? 1 : 0);      // BD < KSTEPS: the fragment BD k-steps ahead is in this chunk or the next (of the tile, or of the next tile: same weights)
-          chb = chb >= nchunks ? chb - nchunks : chb;
-          load_b<C>(bh[(s + BD) % BR], bl[(s + BD) % BR], wpk, (chb * C::NKG + kgrp) * C::KSTEPS + (s + BD) % C::KSTEPS, ntn, nt0, lane);
+          int ksn = ch * C::KSTEPS + s + BD;
+          ksn = ksn >= kperiod ? ksn - kperiod : ksn;       // BD < KSTEPS <= kperiod: one subtraction wraps
+          load_b<C>(bh[(s + BD) % BR], bl[(s + BD) % BR], wpk, ksn, ntn, nt0, lane);
         }
 #pragma unroll
         for (int j = 0; j < C::NI; ++j) { HPFG16_MFMA3(acc[m][j], ah[q % AR], al[q % AR], bh[s % BR][j], bl[s % BR][j]) }
@@ -515,7 +502,7 @@ __global__ __launch_bounds__(C::NTHR, (wg_per_cu<C, KIND>())) void conv_bf16x3_k
         using UG = UpGeo<C>;
         // park the low-res patch (fp32, [pixel][KC channels]), then every output piece blends its four taps from LDS
         if (tid < UG::NPIECE) {
-          float* d = ldsU + (tid / C::NG) * C::KCT + g8;
+          float* d = ldsU + (tid / C::NG) * C::KC + g8;
           *reinterpret_cast<f32x4*>(d) = rawU[0];
           *reinterpret_cast<f32x4*>(d + 4) = rawU[1];
         }
@@ -529,9 +516,9 @@ __global__ __launch_bounds__(C::NTHR, (wg_per_cu<C, KIND>())) void conv_bf16x3_k
           up_coord(clampi(gy, 0, H - 1), p.a1.Hs, y0, y1, wy1);
           up_coord(clampi(gx, 0, W - 1), p.a1.Ws, x0, x1, wx1);
           const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
-          const float* r0 = ldsU + ((y0 - sy_base) * UG::SW) * C::KCT + g8;
-          const float* r1 = ldsU + ((y1 - sy_base) * UG::SW) * C::KCT + g8;
-          const int o0 = (x0 - sx_base) * C::KCT, o1 = (x1 - sx_base) * C::KCT;
+          const float* r0 = ldsU + ((y0 - sy_base) * UG::SW) * C::KC + g8;
+          const float* r1 = ldsU + ((y1 - sy_base) * UG::SW) * C::KC + g8;
+          const int o0 = (x0 - sx_base) * C::KC, o1 = (x1 - sx_base) * C::KC;
           const f32x4 a00 = *reinterpret_cast<const f32x4*>(r0 + o0), b00 = *reinterpret_cast<const f32x4*>(r0 + o0 + 4);
           const f32x4 a01 = *reinterpret_cast<const f32x4*>(r0 + o1), b01 = *reinterpret_cast<const f32x4*>(r0 + o1 + 4);
           const f32x4 a10 = *reinterpret_cast<const f32x4*>(r1 + o0), b10 = *reinterpret_cast<const f32x4*>(r1 + o0 + 4);
@@ -559,29 +546,7 @@ __global__ __launch_bounds__(C::NTHR, (wg_per_cu<C, KIND>())) void conv_bf16x3_k
       __syncthreads();
       HPFG_TR(8)
     }
-    if constexpr (C::NKG == 2) {
-      // Add the two k-groups' accumulators: each group keeps half of its pixel tiles and hands the other half over through the LDS buffer the
-      // last chunk was read from (the other buffer already holds the next tile's first chunk).  Bracketed by two barriers: the hand-over
-      // must be complete before it is read, and read before the next chunk's staging stores reuse the buffer.
-      constexpr int MH = C::MI / 2;
-      f32x4* xch = reinterpret_cast<f32x4*>(lds + ((item + 1) & 1) * C::BUF_BYTES);
-      static_assert(C::BUF_BYTES >= 8 * MH * C::NI * 64 * 16, "hand-over area");
-#pragma unroll
-      for (int m = 0; m < MH; ++m)
-#pragma unroll
-        for (int j = 0; j < C::NI; ++j) xch[((wave * MH + m) * C::NI + j) * 64 + lane] = kgrp ? acc[m][j] : acc[MH + m][j];
-      __syncthreads();
-      f32x4 half[MH][C::NI];
-#pragma unroll
-      for (int m = 0; m < MH; ++m)
-#pragma unroll
-        for (int j = 0; j < C::NI; ++j)
-          half[m][j] = (kgrp ? acc[MH + m][j] : acc[m][j]) + xch[(((wave ^ 4) * MH + m) * C::NI + j) * 64 + lane];
-      __syncthreads();
-      conv16_store_tile<C, BWD, MH>(p, half, s1, s2, bias, lane, wm, nt0, n, ty0, tx0, TIGHT, kgrp * MH);
-    } else {
-      conv16_store_tile<C, BWD>(p, acc, s1, s2, bias, lane, wm, nt0, n, ty0, tx0, TIGHT);
-    }
+    conv16_store_tile<C, BWD>(p, acc, s1, s2, bias, lane, wm, nt0, n, ty0, tx0, TIGHT);
     HPFG_TR(9)
 #pragma unroll
     for (int m = 0; m < C::MI; ++m)
@@ -603,7 +568,7 @@ __global__ __launch_bounds__(C::NTHR, (wg_per_cu<C, KIND>())) void conv_bf16x3_k
     ty0 = tyi * C::TH;
     tx0 = txi * C::TW;
   }
-  conv16_flush_stats<C, BWD>(p, s1, s2, ldsf, tid, lane, kgrp * C::WM + wm, wn, cb, (int)blockIdx.x);
+  conv16_flush_stats<C, BWD>(p, s1, s2, ldsf, tid, lane, wm, wn, cb, (int)blockIdx.x);
   HPFG_TR(10)
   HPFG_TR_REAL(12)
 }
@@ -714,11 +679,11 @@ int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
     dim3 grid((unsigned)persistent_grid<C, KIND>(a), a.CoutPad / C::BN);
     if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLAIN) {
       if (a.bwd_stats) {
-        hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND, true>), grid, dim3(C::NTHR), 0, st, a, tx, ty);
+        hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND, true>), grid, dim3(256), 0, st, a, tx, ty);
         return hpfg_launch_status("conv_bf16x3_kernel<bwd stats>");
       }
     }
-    hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND>), grid, dim3(C::NTHR), 0, st, a, tx, ty);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND>), grid, dim3(256), 0, st, a, tx, ty);
   } else {
     dim3 grid(tx * ty, a.N, a.CoutPad / C::BN);
     if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLAIN) {
@@ -750,20 +715,13 @@ int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
     // it divides (one wave per 16 channels, 4 pixel tiles per wave: every staged input tile and every B fragment feeds 4x the
     // MFMAs of the 32-wide slice, and the B ring can be a whole chunk deep) -- measured 21 vs 29 us on 128->128 @28, 36 vs 50 us
     // on 256->128 @28; a 128-wide slice (two channel tiles per wave, shallow B ring) is slower again.
-    // Round 4: layers that leave at most one 4-wave workgroup per CU (28 x 28 and 14 x 14 at the BASELINE batch) get 8-wave workgroups, two
-    // waves per SIMD on ONE staged tile: (i) two k-groups over a 64-channel chunk where the 64-wide slices give <= 256 workgroups
-    // (256->256 @14: 256), (ii) 128-wide slices where those give <= 256 (128->128 @28: 224).  HPFG_CONV8=0 (read once) keeps the 4-wave forms.
-    static const int conv8 = getenv("HPFG_CONV8") ? atoi(getenv("HPFG_CONV8")) : 3;
-    const long tiles = (long)a.N * ((a.H + 3) / 4) * ((a.W + 15) / 16);
-    const int cin = a.a0.C + a.a1.C;
-    if ((conv8 & 1) && cp % 64 == 0 && tiles * (cp / 64) <= 256 && cin % 64 == 0 && (KIND != HPFG_KIND_CAT || a.a0.C % 64 == 0))
-      return launch_cfg<Cfg<4, 16, 1, 4, 1, TAPS, 32, 2>, KIND>(a, st, rows_only);
-    if ((conv8 & 2) && cp % 128 == 0 && tiles * (cp / 128) <= 256) return launch_cfg<Cfg<4, 16, 1, 8, 1, TAPS, 32>, KIND>(a, st, rows_only);
+    // (round 4: 8-wave workgroups for the <= 256-workgroup layers -- two k-groups per staged chunk, or 128-wide slices -- sped those launches up
+    // by 10-25 % and the step down by 2 %: such a workgroup owns its CU and the other stream's kernels lose their share; profiles/r04_conv8_lever_b.txt)
     if (cp % 64 == 0) return launch_cfg<Cfg<4, 16, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only);
     if (cp % 32 == 0) return launch_cfg<Cfg<4, 16, 2, 2, 1, TAPS, 32>, KIND>(a, st, rows_only);
     return launch_cfg<Cfg<4, 16, 4, 1, 1, TAPS, 32>, KIND>(a, st, rows_only);
   }
-  // 1x1 on small spatial sizes: 8x8 tiles; narrow the output-channel slice per workgroup until there are >= 2 workgroups per CU
+  // 1x1 on small spatial sizes (8x8 tiles): narrow the output-channel slice per workgroup until there are >= 2 workgroups per CU
   const long nwork = (long)a.N * ((a.H + 7) / 8) * ((a.W + 7) / 8);
   if (cp % 128 == 0 && nwork * (cp / 128) >= 512) return launch_cfg<Cfg<8, 8, 1, 4, 2, TAPS, 32>, KIND>(a, st, rows_only);
   if (cp % 64 == 0 && (nwork * (cp / 64) >= 512 || cp % 32 != 0)) return launch_cfg<Cfg<8, 8, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only);

@@ -28,7 +28,7 @@ CONV_CASES = [  # N, H, W, cin, cout, taps
     (2, 24, 24, 32, 64, 9), (2, 8, 8, 64, 128, 9), (3, 12, 12, 16, 32, 9), (2, 4, 4, 128, 256, 9), (2, 2, 2, 256, 256, 9),
     (2, 6, 6, 32, 16, 9), (2, 32, 32, 16, 4, 9), (2, 32, 32, 16, 2, 9), (2, 32, 32, 4, 16, 9), (2, 16, 16, 2, 16, 9),
     (2, 14, 14, 256, 128, 1), (2, 16, 16, 32, 16, 1), (1, 8, 8, 64, 32, 1), (2, 28, 28, 128, 64, 1),
-    # round 4, 8-wave workgroups at BASELINE-like sizes: 128-wide output slices (224 tiles x 1 slice), two k-groups (64 tiles x 4 slices; 224 x 1)
+    # BASELINE-like sizes of the deep layers (16 images): 448 / 256 / 224 workgroups of the 4x16-tile kernel
     (16, 28, 28, 64, 128, 9), (16, 14, 14, 128, 256, 9), (16, 28, 28, 128, 64, 9),
 ]
 
