@@ -2,7 +2,7 @@
 """Headline benchmark: labeled+unlabeled images/sec/node of one step of the reference's drivers on the MI355X hot path, synthetic data.
 
     python bench.py [--workload mt|sup|hpfg|cps|ctct] [--gpus N] [--steps K] [--warmup W] [--math bf16x3|f32] [--no-graph]
-                    [--sync-bn] [--overlap] [--rccl] [--no-cpu-baseline] [--no-f32-line] [--no-probe]
+                    [--local-bn] [--no-overlap] [--rccl] [--no-cpu-baseline] [--no-f32-line] [--no-probe]
 
 Workloads = BASELINE.json configs (the default, `mt`, is configs[1], the one the metric is quoted on):
   sup   configs[0]  sup_ACDC.py:83-93                          U-Net 1->4, 8 x 224^2, SGD + cosine schedule
@@ -14,8 +14,12 @@ Every statement of the loop body is inside the timed region; inputs are resident
 
 `python bench.py --gpus N` with N > 1 and no launcher environment starts `python -m torch.distributed.run --nproc-per-node N` on this
 file as a CHILD process (before anything here touches the GPU) and relays its JSON line; under a launcher (RANK / WORLD_SIZE set) it is
-one rank of the job.  One rank per GPU (process group over RCCL), weak scaling (per-GPU batch fixed); the per-step gradient exchange runs
-through IPC-mapped peer windows over xGMI inside the step's hipGraph (after a self-test on the node; `--rccl`: an RCCL all-reduce between two graphs).
+one rank of the job.  One rank per GPU (process group over RCCL), weak scaling (per-GPU batch fixed).  N > 1 runs the mode BASELINE.json's
+north_star names: gradients AND BatchNorm / loss sums cross the ranks (R ranks == one process on the global batch; the sums through peer
+mailboxes inside the finalize kernels), the gradient exchange bucketed and overlapped with the encoder half of backward, everything through
+IPC-mapped peer windows over xGMI inside the step's hipGraph (after a self-test on the node; `--rccl`: RCCL all-reduces between graphs).  The
+same job then times the DistributedDataParallel-semantics mode (per-rank BatchNorm, averaged gradients: `--local-bn` makes it the headline)
+and reports it beside the headline as `other_bn_mode`.
 
 Prints ONE JSON line (rank 0): the driver's contract plus
   step_roofline   the whole step against its algorithmic bytes / FLOPs,
@@ -23,6 +27,7 @@ Prints ONE JSON line (rank 0): the driver's contract plus
                   BatchNorm launch of the U-Net engines is bracketed by device time stamps (one-wave kernels storing s_memrealtime) inside
                   a second captured hipGraph of the same step -- no host events, no eager steps -- and the families' times are summed per
                   step; `longest_launch` is kept beside it,
+  blocks          the contract's K timed steps are block 0; four more blocks of K steps follow: ms/step of each, median, min, max,
   f32_math        the same step with exact-fp32 MFMA products (N = 1, `mt` only),
   cpu_baseline    the CPU oracle of the same step on this host's cores (bounded sample; all physical cores).
 """
@@ -82,11 +87,14 @@ def parse():
     ap.add_argument("--lab", type=int, default=None, help="labelled images per GPU (default: the workload's BASELINE figure)")
     ap.add_argument("--unlab", type=int, default=None)
     ap.add_argument("--force-sync", action="store_true", help="diagnostics: run the data-parallel code path (RCCL collectives) on one rank")
-    ap.add_argument("--sync-bn", action="store_true", help="N > 1: all-reduce every BatchNorm statistic and the loss sums (R ranks == one process on the "
-                    "global batch) instead of the default per-rank BatchNorm + averaged gradients (DDP semantics)")
-    ap.add_argument("--overlap", action="store_true", help="N > 1: bucketed gradient exchange overlapped with the encoder half of backward (peer windows: inside the one graph; --rccl: a chain of "
-                    "hipGraphs around eager RCCL calls) instead of ONE all-reduce between two hipGraphs")
-    ap.add_argument("--no-overlap", action="store_true", help="(the default; kept for older command lines)")
+    ap.add_argument("--sync-bn", action="store_true", help="(the default for N > 1; kept for older command lines) exchange every BatchNorm statistic and the "
+                    "loss sums: R ranks == one process on the global batch")
+    ap.add_argument("--local-bn", action="store_true", help="N > 1: per-rank BatchNorm + averaged gradients (DistributedDataParallel semantics) as the headline "
+                    "mode; the global-batch mode is then the `other_bn_mode` line")
+    ap.add_argument("--overlap", action="store_true", help="(the default for N > 1) bucketed gradient exchange overlapped with the encoder half of backward "
+                    "(peer windows: inside the one graph; --rccl: a chain of hipGraphs around eager RCCL calls)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: ONE gradient exchange after backward instead")
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps (block 0 is the contract's measurement)")
     ap.add_argument("--rccl", action="store_true", help="N > 1: the gradient all-reduce as an RCCL call between two hipGraphs instead of the peer-window "
                     "exchange captured inside the step's one graph (the fallback bench.py takes by itself when the peer windows fail their self-test)")
     ap.add_argument("--no-p2p", action="store_true", help="--sync-bn: exchange the BatchNorm / loss sums with host-launched RCCL all-reduces (eager step) instead "
@@ -220,8 +228,9 @@ class Workload:
         return [e for m in self.models for pool in getattr(m, "_engines", {}).values() for e in pool]
 
 
-def timed_run(wl, dp, use_graph, steps, warmup, dev):
-    """W untimed + K timed steps bracketed by barrier + synchronize; returns (seconds, graph actually used, last iteration)."""
+def timed_run(wl, dp, use_graph, steps, warmup, dev, blocks=1):
+    """W untimed + K timed steps bracketed by barrier + synchronize; returns (seconds, graph actually used, last iteration, [seconds of every
+    block]): block 0 is the contract's measurement, `blocks - 1` further blocks of K steps are timed the same way (spread of the figure)."""
     import torch
     from hpfg_amd.train import GraphedStep
     step, inputs = wl.step, wl.inputs
@@ -251,15 +260,25 @@ def timed_run(wl, dp, use_graph, steps, warmup, dev):
         it += 1
         one(it)
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        it += 1
-        one(it)
-    barrier()
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(max(1, blocks)):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            it += 1
+            one(it)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dp is not None:
+            dt = dp.max_float(dt)
+        dts.append(dt)
     if dp is not None:
-        dt = dp.max_float(dt)
-    return dt, use_graph, it
+        # a peer exchange whose poll expired carried on with partial sums (it must not hang the GPU): such a run is not a measurement
+        try:
+            dp.check_peer_errors()
+        except RuntimeError as e:
+            print(f"[bench] rank {dp.rank}: {e}", file=sys.stderr, flush=True)
+            raise SystemExit(3)
+    return dts[0], use_graph, it, dts
 
 
 # ---- per-kernel probe ------------------------------------------------------------------------------------------------------------------
@@ -370,12 +389,17 @@ def roofline_objects(wl, fams, longest, calib, math):
     roof["share_of_bracketed_kernel_time"] = round(top["us"] / total, 4)
     roof["timing"] = (f"device time stamps (s_memrealtime) around each launch inside a captured hipGraph of the step, minus the same bracket around nothing "
                       f"({calib:.2f} us); bf16-MFMA passes per product: {passes:g}")
-    try:      # HBM bytes per launch of this family from the PMC passes committed under profiles/ (tools/family_traffic.py)
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_family_traffic.json")))
-        if tj.get("workload") == wl.name and name in tj.get("families", {}):
-            roof["traffic"] = int(tj["families"][name]["hbm_bytes_per_launch"])
-    except Exception:
-        pass
+    # HBM bytes per launch of this family: NOT measured by this run -- the figure of the PMC passes (FETCH_SIZE x 2 / WRITE_SIZE, separate
+    # rocprofv3 --pmc runs of the same step) committed under profiles/ by tools/family_traffic.py; `traffic_source` names the file
+    for tf in ("r04_family_traffic.json", "r03_family_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
+            if tj.get("workload") == wl.name and name in tj.get("families", {}):
+                roof["traffic"] = int(tj["families"][name]["hbm_bytes_per_launch"])
+                roof["traffic_source"] = f"profiles/{tf} (committed PMC passes of `{tj.get('command', 'bench.py --no-graph')}`, {tj.get('commit', 'commit n/a')}); not collected by this run"
+                break
+        except Exception:
+            pass
     roof["families"] = {k: {"us_per_step": round(f["us"], 1), "launches": f["launches"], "share": round(f["us"] / total, 4),
                             **({"GBps": round(f["bytes"] / (f["us"] * 1e-6) / 1e9, 1), "TFLOPs_bf16_passes": round(f["flops"] * passes / (f["us"] * 1e-6) / 1e12, 1)}
                                if f["bytes"] > 0 and f["us"] > 0 else {})}
@@ -518,8 +542,9 @@ def main():
                 os.environ.setdefault(k, v)
         dp = parallel.init_from_env(dev, backend=os.environ.get("HPFG_DP_BACKEND") or None)
         dp.force_sync = bool(a.force_sync)
-        dp.sync_bn = bool(a.sync_bn or (a.force_sync and os.environ.get("HPFG_BENCH_LOCAL_BN", "0") != "1"))
-        dp.overlap = bool(a.overlap) and not a.no_overlap
+        # N > 1 default = the mode north_star names: BatchNorm / loss sums exchanged (global-batch equivalence), gradient buckets overlapped with backward
+        dp.sync_bn = bool((world > 1 and not a.local_bn) or a.sync_bn or (a.force_sync and os.environ.get("HPFG_BENCH_LOCAL_BN", "0") != "1"))
+        dp.overlap = bool(world > 1 or a.overlap) and not a.no_overlap
         if dp.sync_bn and not a.no_p2p:
             dp.enable_peer_exchange()
     wl = Workload(a.workload, a, dev, a.math, dp, rank)
@@ -543,10 +568,34 @@ def main():
     # kernels (peer mailboxes) and captures as well; with --no-p2p (collectives between the kernels), and for the HPFG step (its Dense_Loss
     # all-gathers the neck features with a host-launched collective), the global-batch mode runs eager.
     sync_mode = dp is not None and dp.sync_bn and (world > 1 or a.force_sync)
-    use_graph = (not a.no_graph) and (not sync_mode or (dp.p2p and a.workload != "hpfg"))
-    dt, use_graph, it = timed_run(wl, dp, use_graph, a.steps, a.warmup, dev)
+    use_graph = (not a.no_graph) and (not sync_mode or (dp.p2p and (a.workload != "hpfg" or dp.p2p_grads)))
+    dt, use_graph, it, dts = timed_run(wl, dp, use_graph, a.steps, a.warmup, dev, blocks=a.blocks)
     ms = dt / a.steps * 1e3
     value = wl.n_img * world / (dt / a.steps)
+    bl = sorted(d / a.steps * 1e3 for d in dts)
+    blocks = {"ms_per_step": [round(d / a.steps * 1e3, 4) for d in dts], "median_ms": round(bl[len(bl) // 2], 4), "min_ms": round(bl[0], 4),
+              "max_ms": round(bl[-1], 4), "note": "block 0 = the contract's K timed steps (value / ms_per_step); each block bracketed by barrier + synchronize"}
+    headline_sync = bool(dp is not None and dp.sync_bn)
+
+    other = None
+    if dp is not None and world > 1:
+        # the other BatchNorm mode on the same ranks (fresh models and step objects): DistributedDataParallel semantics when the headline is
+        # the global-batch mode, and vice versa
+        dp.sync_bn = not headline_sync
+        if dp.sync_bn and not a.no_p2p:
+            dp.enable_peer_exchange()
+        try:
+            wl2 = Workload(a.workload, a, dev, a.math, dp, rank)
+            sync2 = dp.sync_bn
+            ug2 = (not a.no_graph) and (not sync2 or (dp.p2p and (a.workload != "hpfg" or dp.p2p_grads)))
+            k2 = max(5, a.steps // 2)
+            dt2, ug2, _, _ = timed_run(wl2, dp, ug2, k2, max(3, a.warmup // 2), dev)
+            other = {"sync_bn": bool(sync2), "value": round(wl2.n_img * world / (dt2 / k2), 2), "unit": "images/s", "ms_per_step": round(dt2 / k2 * 1e3, 4),
+                     "steps": k2, "hipgraph": bool(ug2),
+                     "mode": "global-batch equivalence (BatchNorm + loss sums exchanged)" if sync2 else "per-rank BatchNorm, gradients averaged (DDP semantics)"}
+            del wl2
+        finally:
+            dp.sync_bn = headline_sync
 
     roof = f32 = cpu = None
     if rank == 0 and not a.no_probe and use_graph:
@@ -566,7 +615,7 @@ def main():
         torch.cuda.empty_cache()
         wl = Workload(a.workload, a, dev, "f32", None, rank)
         k2 = max(5, a.steps // 2)
-        dt2, g2, _ = timed_run(wl, None, use_graph, k2, max(3, a.warmup // 2), dev)
+        dt2, g2, _, _ = timed_run(wl, None, use_graph, k2, max(3, a.warmup // 2), dev)
         f32 = {"dtype": DTYPE["f32"], "value": round(wl.n_img / (dt2 / k2), 2), "unit": "images/s", "ms_per_step": round(dt2 / k2 * 1e3, 4), "steps": k2,
                "hipgraph": bool(g2), "note": "same step, HPFG_MATH=f32: every product exact fp32 (v_mfma_f32_16x16x4_f32); meets 1e-3 on every fixture"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:      # reported baseline: rank 0 at N=1 only
@@ -591,7 +640,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[a.math], "data": "synthetic",
             "config": {"workload": wl.desc, "per_gpu_batch": [wl.lab, wl.unlab], "size": wl.size, "hipgraph": bool(use_graph),
                        "sync_bn": bool(dp is not None and dp.sync_bn), "parallelism": par, "math": a.math},
-            "step_roofline": step_roof, "roofline": roof, "f32_math": f32, "cpu_baseline": cpu,
+            "step_roofline": step_roof, "roofline": roof, "blocks": blocks, "other_bn_mode": other, "f32_math": f32, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if dp is not None:

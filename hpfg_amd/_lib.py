@@ -15,8 +15,10 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 # enums from include/hpfg_hip.h
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ = range(7)
+OPT_CONV_THIN, OPT_FIRST_MFMA = 0, 1          # hpfg_set_option
 LOSS_NSUM = 32
-VERSION = 127
+ACC_MAX_SHARDS = 8          # HPFG_ACC_MAX_SHARDS: a BatchNorm sum accumulator is long long [shards][2][C][2]
+VERSION = 129
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -28,14 +30,17 @@ class Act(C.Structure):
     _fields_ = [("z", C.c_void_p), ("bn", C.c_void_p), ("aux", C.c_void_p), ("mode", C.c_int32), ("C", C.c_int32),
                 ("Hs", C.c_int32), ("Ws", C.c_int32), ("pstride", C.c_int32), ("aux_pstride", C.c_int32),
                 ("bn_stride", C.c_int32), ("bn_coff", C.c_int32), ("sn", C.c_int32), ("sc", C.c_int32), ("sy", C.c_int32),
-                ("sx", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("drop_mask", C.c_void_p), ("seed_dev", C.c_void_p)]
+                ("sx", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("drop_mask", C.c_void_p), ("seed_dev", C.c_void_p),
+                ("bn_acc", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_beta", C.c_void_p), ("bn_count", C.c_float), ("bn_eps", C.c_float),
+                ("bn_shards", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class ConvArgs(C.Structure):
     _fields_ = [("a0", Act), ("a1", Act), ("wpk", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
                 ("stat_partials", C.c_void_p), ("out_pstride", C.c_int32), ("Cout", C.c_int32), ("CoutPad", C.c_int32),
                 ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("taps", C.c_int32), ("math", C.c_int32),
-                ("bwd_stats", C.c_int32), ("bwd_of", Act), ("out2", C.c_void_p), ("out_split", C.c_int32), ("out2_pstride", C.c_int32)]
+                ("bwd_stats", C.c_int32), ("bwd_of", Act), ("out2", C.c_void_p), ("out_split", C.c_int32), ("out2_pstride", C.c_int32),
+                ("stat_acc", C.c_void_p), ("stat_shards", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -63,6 +68,16 @@ class AugSample(C.Structure):
     _fields_ = [("img_off", C.c_int64), ("lab_off", C.c_int64), ("h", C.c_int32), ("w", C.c_int32), ("mode", C.c_int32), ("k", C.c_int32),
                 ("axis", C.c_int32), ("tab_off", C.c_int32), ("m00", C.c_double), ("m01", C.c_double), ("m10", C.c_double),
                 ("m11", C.c_double), ("off_y", C.c_double), ("off_x", C.c_double)]
+
+
+class BnAccDesc(C.Structure):
+    _fields_ = [("acc", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("bn", C.c_void_p), ("C", C.c_int32), ("count", C.c_float), ("shards", C.c_int32), ("reserved", C.c_int32)]
+
+
+class BnAccBwdDesc(C.Structure):
+    _fields_ = [("acc", C.c_void_p), ("gamma", C.c_void_p), ("bn", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("C", C.c_int32), ("count", C.c_float), ("shards", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SlabDesc(C.Structure):
@@ -94,6 +109,7 @@ _i, _l, _f, _d, _p, _u32 = C.c_int, C.c_long, C.c_float, C.c_double, C.c_void_p,
 PROTOTYPES = {
     "hpfg_version": (_i, []),
     "hpfg_last_error": (C.c_char_p, []),
+    "hpfg_set_option": (_i, [_i, _i]),
     "hpfg_conv3x3_first_fwd": (_i, [C.POINTER(Act), _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "hpfg_conv_fwd": (_i, [C.POINTER(ConvArgs), _p]),
     "hpfg_conv_stat_blocks": (_i, [_i, _i, _i]),
@@ -103,7 +119,12 @@ PROTOTYPES = {
     "hpfg_conv_kc": (_i, [_i, _i, _i]),
     "hpfg_wpk16_elems": (_l, [_i, _i, _i, _i]),
     "hpfg_pack_weights": (_i, [_p, C.POINTER(PackDesc), _i, _p]),
-    "hpfg_pack_weights_bump": (_i, [_p, C.POINTER(PackDesc), _i, _p, _i, _p, _i, _p]),
+    "hpfg_pack_weights_bump": (_i, [_p, C.POINTER(PackDesc), _i, _p, _i, _p, _i, _p, _l, _p]),
+    "hpfg_conv3x3_first_fwd_acc": (_i, [C.POINTER(Act), _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "hpfg_bn_acc_finalize": (_i, [_p, C.POINTER(BnAccDesc), _i, _f, _f, _p]),
+    "hpfg_bn_acc_bwd_finalize": (_i, [_p, C.POINTER(BnAccBwdDesc), _i, _p]),
+    "hpfg_bn_bwd_reduce_acc": (_i, [C.POINTER(Act), _i, _i, _i, _p, _i, _p]),
+    "hpfg_bn_bwd_reduce_pool_acc": (_i, [C.POINTER(Act), _p, _i, _i, _i, _i, _p, _i, _p]),
     "hpfg_act_materialize": (_i, [C.POINTER(Act), C.POINTER(Act), _i, _i, _i, _p, _p]),
     "hpfg_dropout_mask": (_i, [_p, _l, _f, _u32, _p, _p]),
     "hpfg_bn_eval_table": (_i, [_p, _p, _p, _p, _f, _p, _i, _p]),

@@ -106,21 +106,64 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(HpfgBnFinalizeArgs
       s1 = v[0];
       s2 = v[1];
     }
-    double mean = s1 / count;
-    double var = s2 / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    double rstd = 1.0 / sqrt(var + (double)eps);
-    float scale = (float)((double)ga * rstd);
-    bn[HPFG_BN_MEAN * C + c] = (float)mean;
-    bn[HPFG_BN_RSTD * C + c] = (float)rstd;
-    bn[HPFG_BN_SCALE * C + c] = scale;
-    bn[HPFG_BN_SHIFT * C + c] = (float)((double)be - mean * (double)ga * rstd);
+    const HpfgBnCoef q = hpfg_bn_coef(s1, s2, count, eps, ga, be);      // (the definition the accumulator path's consumers share: same bits)
+    const double mean = s1 / count, var = q.var;
+    bn[HPFG_BN_MEAN * C + c] = q.mean;
+    bn[HPFG_BN_RSTD * C + c] = q.rstd;
+    bn[HPFG_BN_SCALE * C + c] = q.scale;
+    bn[HPFG_BN_SHIFT * C + c] = q.shift;
     if (running_mean) {
       double unb = count > 1.0 ? var * count / (count - 1.0) : var;
       running_mean[c] = (float)((1.0 - momentum) * (double)rm + momentum * mean);
       running_var[c] = (float)((1.0 - momentum) * (double)rv + momentum * unb);
     }
   }
+}
+
+// Every BatchNorm layer of a forward pass in ONE launch, from the layers' sum accumulators (HpfgConvArgs.stat_acc): table rows mean / rstd /
+// scale / shift for the backward kernels and the running statistics.  The forward consumers derived the same scale / shift themselves
+// (hpfg_bn_coef, the shared definition), so this launch sits at the END of the forward, off every conv -> conv dependency.
+__global__ __launch_bounds__(256) void bn_acc_finalize_kernel(const HpfgBnAccDesc* __restrict__ table, float momentum, float eps) {
+  const HpfgBnAccDesc d = table[blockIdx.y];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d.C) return;
+  const double count = (double)d.count;
+  double s1, s2;
+  hpfg_acc_read2(d.acc, d.C, d.shards, c, s1, s2);
+  const HpfgBnCoef q = hpfg_bn_coef(s1, s2, count, eps, d.gamma[c], d.beta[c]);
+  d.bn[HPFG_BN_MEAN * d.C + c] = q.mean;
+  d.bn[HPFG_BN_RSTD * d.C + c] = q.rstd;
+  d.bn[HPFG_BN_SCALE * d.C + c] = q.scale;
+  d.bn[HPFG_BN_SHIFT * d.C + c] = q.shift;
+  if (d.running_mean) {
+    const double mean = s1 / count;
+    const double unb = count > 1.0 ? q.var * count / (count - 1.0) : q.var;
+    d.running_mean[c] = (float)((1.0 - momentum) * (double)d.running_mean[c] + momentum * mean);
+    d.running_var[c] = (float)((1.0 - momentum) * (double)d.running_var[c] + momentum * unb);
+  }
+}
+
+// Backward counterpart, at the END of a backward pass (or of its decoder half): dgamma / dbeta of every listed layer from its backward sum
+// accumulator (+ the k1 .. k3 table rows, for readers of the table), after which the accumulator is ZEROED for the next pass -- every dZ
+// consumer of the pass has run by then (the caller joins its side stream first).
+__global__ __launch_bounds__(256) void bn_acc_bwd_finalize_kernel(const HpfgBnAccBwdDesc* __restrict__ table) {
+  const HpfgBnAccBwdDesc d = table[blockIdx.y];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d.C) return;
+  double sg, sgx;
+  hpfg_acc_read2(d.acc, d.C, d.shards, c, sg, sgx);
+  const HpfgBnBwdCoef q = hpfg_bn_bwd_coef(sg, sgx, (double)d.count, (double)d.bn[HPFG_BN_MEAN * d.C + c], (double)d.bn[HPFG_BN_RSTD * d.C + c], (double)d.gamma[c]);
+  d.bn[HPFG_BN_K1 * d.C + c] = q.k1;
+  d.bn[HPFG_BN_K2 * d.C + c] = q.k2;
+  d.bn[HPFG_BN_K3 * d.C + c] = q.k3;
+  if (d.dgamma) d.dgamma[c] = (float)sgx;
+  if (d.dbeta) d.dbeta[c] = (float)sg;
+  for (int s = 0; s < d.shards; ++s)
+    for (int w = 0; w < 2; ++w) {
+      long long* b = d.acc + ((long)((s * 2 + w) * d.C + c)) * 2;
+      b[0] = 0;
+      b[1] = 0;
+    }
 }
 
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nblk, int C, double* __restrict__ sums) {
@@ -136,7 +179,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // and pixel lane t / Q; a workgroup strides over the pixels with four independent pixel loads in flight per thread.
 constexpr int BWD_MAX_BLOCKS = 1024;
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(HpfgAct s, long npix, float* __restrict__ partials) {
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(HpfgAct s, long npix, float* __restrict__ partials, long long* __restrict__ acc, int shards) {
   __shared__ float red[256 * 8];
   const int C = s.C, Q = C >> 2, tid = threadIdx.x;
   const ActCtx cx = make_ctx(s);
@@ -184,9 +227,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(HpfgAct s, long npix
   __syncthreads();
   for (int o = tid; o < 2 * C; o += 256) {
     const int which = o / C, cc = o % C, qq = cc >> 2, j = cc & 3;
-    float acc = 0.f;
-    for (int l = 0; l < PL; ++l) acc += red[(l * Q + qq) * 8 + which * 4 + j];
-    partials[((long)blockIdx.x * 2 + which) * C + cc] = acc;
+    float t = 0.f;
+    for (int l = 0; l < PL; ++l) t += red[(l * Q + qq) * 8 + which * 4 + j];
+    if (acc) hpfg_acc_add(acc, C, (int)blockIdx.x & (shards - 1), which, cc, t);      // (the layer's backward accumulator: HpfgAct.bn_acc of its dZ consumers)
+    if (partials) partials[((long)blockIdx.x * 2 + which) * C + cc] = t;
   }
 }
 
@@ -196,7 +240,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(HpfgAct s, long npix
 // torch's max_pool2d), adds dP there, writes the completed dA back for the dgrad / wgrad loaders, and accumulates the BatchNorm
 // sums from the registers.  Replaces pool_scatter_add + bn_bwd_reduce (one read of z and dA and one launch less).
 __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(HpfgAct s, const float* __restrict__ dP, int dp_ps, long npool, int Hp, int Wp,
-                                                                 float* __restrict__ partials) {
+                                                                 float* __restrict__ partials, long long* __restrict__ acc, int shards) {
   __shared__ float red[256 * 8];
   const int C = s.C, Q = C >> 2, tid = threadIdx.x;
   const int q = tid % Q, pl = tid / Q, PL = 256 / Q;
@@ -253,9 +297,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(HpfgAct s, cons
   __syncthreads();
   for (int o = tid; o < 2 * C; o += 256) {
     const int which = o / C, cc = o % C, qq = cc >> 2, j = cc & 3;
-    float acc = 0.f;
-    for (int l = 0; l < PL; ++l) acc += red[(l * Q + qq) * 8 + which * 4 + j];
-    partials[((long)blockIdx.x * 2 + which) * C + cc] = acc;
+    float t = 0.f;
+    for (int l = 0; l < PL; ++l) t += red[(l * Q + qq) * 8 + which * 4 + j];
+    if (acc) hpfg_acc_add(acc, C, (int)blockIdx.x & (shards - 1), which, cc, t);      // (the layer's backward accumulator: HpfgAct.bn_acc of its dZ consumers)
+    if (partials) partials[((long)blockIdx.x * 2 + which) * C + cc] = t;
   }
 }
 
@@ -280,10 +325,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
       sg = v[0];
       sgx = v[1];
     }
-    double m1 = sg / count, m2 = sgx / count;
-    bn[HPFG_BN_K1 * C + c] = (float)(ga * rstd);
-    bn[HPFG_BN_K2 * C + c] = (float)(-ga * rstd * rstd * m2);
-    bn[HPFG_BN_K3 * C + c] = (float)(ga * rstd * (mean * rstd * m2 - m1));
+    const HpfgBnBwdCoef q = hpfg_bn_bwd_coef(sg, sgx, count, mean, rstd, ga);      // (the definition the accumulator path's consumers share)
+    bn[HPFG_BN_K1 * C + c] = q.k1;
+    bn[HPFG_BN_K2 * C + c] = q.k2;
+    bn[HPFG_BN_K3 * C + c] = q.k3;
     if (dgamma) dgamma[c] = (float)(sgx * pscale);
     if (dbeta) dbeta[c] = (float)(sg * pscale);
   }
@@ -344,6 +389,33 @@ extern "C" int hpfg_bn_fwd_finalize_x(const float* partials, int nblk, const Hpf
   return hpfg_launch_status("bn_fwd_finalize_kernel");
 }
 
+extern "C" int hpfg_bn_acc_finalize(const HpfgBnAccDesc* table_dev, const HpfgBnAccDesc* table_host, int nlayers, float momentum, float eps, void* stream) {
+  HPFG_ARG_CHECK(table_dev && table_host && nlayers > 0 && nlayers < 65536, "bn_acc_finalize: bad args");
+  int maxc = 0;
+  for (int i = 0; i < nlayers; ++i) {
+    const HpfgBnAccDesc& d = table_host[i];
+    HPFG_ARG_CHECK(d.acc && d.gamma && d.beta && d.bn && d.C > 0 && d.count >= 1.f && (d.running_mean == nullptr) == (d.running_var == nullptr) &&
+                       d.shards >= 1 && d.shards <= HPFG_ACC_MAX_SHARDS && (d.shards & (d.shards - 1)) == 0,
+                   "bn_acc_finalize: bad descriptor %d", i);
+    if (d.C > maxc) maxc = d.C;
+  }
+  hipLaunchKernelGGL(bn_acc_finalize_kernel, dim3((maxc + 255) / 256, nlayers), dim3(256), 0, (hipStream_t)stream, table_dev, momentum, eps);
+  return hpfg_launch_status("bn_acc_finalize_kernel");
+}
+
+extern "C" int hpfg_bn_acc_bwd_finalize(const HpfgBnAccBwdDesc* table_dev, const HpfgBnAccBwdDesc* table_host, int nlayers, void* stream) {
+  HPFG_ARG_CHECK(table_dev && table_host && nlayers > 0 && nlayers < 65536, "bn_acc_bwd_finalize: bad args");
+  int maxc = 0;
+  for (int i = 0; i < nlayers; ++i) {
+    const HpfgBnAccBwdDesc& d = table_host[i];
+    HPFG_ARG_CHECK(d.acc && d.gamma && d.bn && d.C > 0 && d.count >= 1.f && d.shards >= 1 && d.shards <= HPFG_ACC_MAX_SHARDS && (d.shards & (d.shards - 1)) == 0,
+                   "bn_acc_bwd_finalize: bad descriptor %d", i);
+    if (d.C > maxc) maxc = d.C;
+  }
+  hipLaunchKernelGGL(bn_acc_bwd_finalize_kernel, dim3((maxc + 255) / 256, nlayers), dim3(256), 0, (hipStream_t)stream, table_dev);
+  return hpfg_launch_status("bn_acc_bwd_finalize_kernel");
+}
+
 extern "C" int hpfg_reduce_partials(const float* partials, int nblk, int C, double* sums, void* stream) {
   HPFG_ARG_CHECK(partials && sums && nblk > 0 && C > 0, "reduce_partials: bad args");
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(C, 2), dim3(256), 0, (hipStream_t)stream, partials, nblk, C, sums);
@@ -358,13 +430,21 @@ extern "C" int hpfg_bn_bwd_blocks(int N, int H, int W, int C) {
   return (int)(want > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : want);
 }
 
+static int bn_bwd_reduce_impl(const HpfgAct* g, int N, int H, int W, float* partials, long long* acc, int shards, void* stream);
 extern "C" int hpfg_bn_bwd_reduce(const HpfgAct* g, int N, int H, int W, float* partials, void* stream) {
-  HPFG_ARG_CHECK(g && partials && g->mode == HPFG_ACT_DZ && g->z && g->aux && g->bn, "bn_bwd_reduce: needs a DZ source");
+  return bn_bwd_reduce_impl(g, N, H, W, partials, nullptr, 1, stream);
+}
+extern "C" int hpfg_bn_bwd_reduce_acc(const HpfgAct* g, int N, int H, int W, long long* acc, int shards, void* stream) {
+  HPFG_ARG_CHECK(acc && shards >= 1 && shards <= HPFG_ACC_MAX_SHARDS && (shards & (shards - 1)) == 0, "bn_bwd_reduce_acc: bad accumulator / shards");
+  return bn_bwd_reduce_impl(g, N, H, W, nullptr, acc, shards, stream);
+}
+static int bn_bwd_reduce_impl(const HpfgAct* g, int N, int H, int W, float* partials, long long* acc, int shards, void* stream) {
+  HPFG_ARG_CHECK(g && (partials || acc) && g->mode == HPFG_ACT_DZ && g->z && g->aux && g->bn, "bn_bwd_reduce: needs a DZ source");
   HPFG_ARG_CHECK(g->C % 4 == 0 && g->C >= 4 && g->C <= 1024 && 256 % (g->C / 4) == 0, "bn_bwd_reduce: unsupported C=%d", g->C);
   HPFG_ARG_CHECK(g->Hs == H && g->Ws == W, "bn_bwd_reduce: source size mismatch");
   long npix = (long)N * H * W;
   int nblk = hpfg_bn_bwd_blocks(N, H, W, g->C);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *g, npix, partials);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *g, npix, partials, acc, shards);
   return hpfg_launch_status("bn_bwd_reduce_kernel");
 }
 
@@ -376,14 +456,24 @@ extern "C" int hpfg_bn_bwd_pool_blocks(int N, int Hp, int Wp, int C) {
   return (int)(want > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : want);
 }
 
+static int bn_bwd_reduce_pool_impl(const HpfgAct* g, const float* dP, int dp_pstride, int N, int Hp, int Wp, float* partials, long long* acc, int shards,
+                                   void* stream);
 extern "C" int hpfg_bn_bwd_reduce_pool(const HpfgAct* g, const float* dP, int dp_pstride, int N, int Hp, int Wp, float* partials, void* stream) {
-  HPFG_ARG_CHECK(g && dP && partials && g->mode == HPFG_ACT_DZ && g->z && g->aux && g->bn, "bn_bwd_reduce_pool: needs a DZ source and dP");
+  return bn_bwd_reduce_pool_impl(g, dP, dp_pstride, N, Hp, Wp, partials, nullptr, 1, stream);
+}
+extern "C" int hpfg_bn_bwd_reduce_pool_acc(const HpfgAct* g, const float* dP, int dp_pstride, int N, int Hp, int Wp, long long* acc, int shards, void* stream) {
+  HPFG_ARG_CHECK(acc && shards >= 1 && shards <= HPFG_ACC_MAX_SHARDS && (shards & (shards - 1)) == 0, "bn_bwd_reduce_pool_acc: bad accumulator / shards");
+  return bn_bwd_reduce_pool_impl(g, dP, dp_pstride, N, Hp, Wp, nullptr, acc, shards, stream);
+}
+static int bn_bwd_reduce_pool_impl(const HpfgAct* g, const float* dP, int dp_pstride, int N, int Hp, int Wp, float* partials, long long* acc, int shards,
+                                   void* stream) {
+  HPFG_ARG_CHECK(g && dP && (partials || acc) && g->mode == HPFG_ACT_DZ && g->z && g->aux && g->bn, "bn_bwd_reduce_pool: needs a DZ source and dP");
   HPFG_ARG_CHECK(g->C % 4 == 0 && g->C >= 4 && g->C <= 1024 && 256 % (g->C / 4) == 0, "bn_bwd_reduce_pool: unsupported C=%d", g->C);
   HPFG_ARG_CHECK(g->Hs == 2 * Hp && g->Ws == 2 * Wp && N > 0, "bn_bwd_reduce_pool: the source must be exactly twice the pooled size");
   HPFG_ARG_CHECK(g->drop_p == 0.f, "bn_bwd_reduce_pool: a pooled block output has no dropout behind it");
   HPFG_ARG_CHECK(dp_pstride % 4 == 0 && g->aux_pstride % 4 == 0 && g->pstride % 4 == 0, "bn_bwd_reduce_pool: pixel strides must be multiples of 4");
   hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(hpfg_bn_bwd_pool_blocks(N, Hp, Wp, g->C)), dim3(256), 0, (hipStream_t)stream, *g, dP, dp_pstride,
-                     (long)N * Hp * Wp, Hp, Wp, partials);
+                     (long)N * Hp * Wp, Hp, Wp, partials, acc, shards);
   return hpfg_launch_status("bn_bwd_reduce_pool_kernel");
 }
 

@@ -10,6 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define HPFG_LEAKY 0.01f
 
 extern "C" void hpfg_set_error(const char* fmt, ...);
+int hpfg_opt(int which);      // current value of a kernel-form switch (hpfg_set_option, misc.hip)
 #define HPFG_ARG_CHECK(cond, ...)            \
   do {                                       \
     if (!(cond)) {                           \
@@ -51,6 +52,137 @@ __host__ __device__ static inline bool hpfg_keep(uint32_t i, uint32_t seed, uint
 }
 
 __device__ static inline float lrelu(float y) { return fmaxf(y, HPFG_LEAKY * y); }   // == y > 0 ? y : 0.01*y
+
+// ---- BatchNorm sums through integer atomics (HpfgConvArgs.stat_acc / HpfgAct.bn_acc) ----------------------------------------------------
+// A producer workgroup adds its per-channel partial sums to the layer accumulator, long long [SHARDS][which][limb][C]; every consumer reads
+// the 8 shards of its channels and derives the BatchNorm coefficients itself, so no finalize launch sits between the two kernels.  The
+// split t = hi + lo * 2^-52 (hi = rint(t), lo = (t - hi) * 2^52: both exact for a float t above 2^-29; |lo| <= 2^51, so 2^11 partial sums add
+// without overflow) loses nothing an fp64 sum would keep, and integer sums are associative: bit-reproducible totals without a fixed
+// workgroup order (a float atomic would make BatchNorm, hence the run, non-deterministic).
+__device__ __forceinline__ void hpfg_acc_add(long long* acc, int C, int shard, int which, int c, float t) {
+  const float r = rintf(t);
+  const long long hi = (long long)r, lo = (long long)rintf((t - r) * 4503599627370496.f);
+  long long* b = acc + ((long)((shard * 2 + which) * C + c)) * 2;
+  __hip_atomic_fetch_add(b, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (agent scope: correct wherever the workgroup runs; the
+  __hip_atomic_fetch_add(b + 1, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  //  sharding only spreads the same-address contention)
+}
+// both sums of channel c: every 16-byte (hi, lo) load of the `shards` shards in flight before the first add
+__device__ __forceinline__ void hpfg_acc_read2(const long long* __restrict__ acc, int C, int shards, int c, double& s1, double& s2) {
+  typedef long long i64x2 __attribute__((ext_vector_type(2)));
+  i64x2 v[HPFG_ACC_MAX_SHARDS][2];
+#pragma unroll
+  for (int s = 0; s < HPFG_ACC_MAX_SHARDS; ++s) {
+    const int sc = s < shards ? s : 0;          // (a clamped reload instead of a branch; its value is dropped below)
+    v[s][0] = *reinterpret_cast<const i64x2*>(acc + ((long)((sc * 2 + 0) * C + c)) * 2);
+    v[s][1] = *reinterpret_cast<const i64x2*>(acc + ((long)((sc * 2 + 1) * C + c)) * 2);
+  }
+  i64x2 a = {0, 0}, b = {0, 0};
+#pragma unroll
+  for (int s = 0; s < HPFG_ACC_MAX_SHARDS; ++s) {
+    if (s < shards) {
+      a += v[s][0];
+      b += v[s][1];
+    }
+  }
+  s1 = (double)a[0] + (double)a[1] * (1.0 / 4503599627370496.0);
+  s2 = (double)b[0] + (double)b[1] * (1.0 / 4503599627370496.0);
+}
+// The one definition of the forward coefficients that every consumer prologue and hpfg_bn_acc_finalize share (no contraction left to the
+// compiler: the values a forward consumer used and the table rows the backward kernels read must be the same bits).
+struct HpfgBnCoef {
+  float mean, rstd, scale, shift;
+  double var;
+};
+// Everything in fp64, as torch's CPU BatchNorm and hpfg_bn_fwd_finalize always did (E[z^2] - mean^2 cancels; on the 16- to 64-pixel test
+// fixtures one ulp of rstd flips an arg-max pseudo-label two steps later) -- but without the ~150 dependent instructions of the fp64
+// divide / sqrt / reciprocal sequences in every consumer prologue: 1 / count and 1 / sqrt(var + eps) start from the fp32 hardware
+// approximations (1 ulp) and take two Newton steps in fp64 (relative error 1e-7 -> 1e-14 -> below the fp64 rounding).
+__device__ __forceinline__ HpfgBnCoef hpfg_bn_coef(double s1, double s2, double count, float eps, float ga, float be) {
+#pragma clang fp contract(off)
+  double ic = (double)__builtin_amdgcn_rcpf((float)count);
+  ic = ic * __builtin_fma(-count, ic, 2.0);
+  ic = ic * __builtin_fma(-count, ic, 2.0);
+  const double mean = s1 * ic;
+  double var = __builtin_fma(-mean, mean, s2 * ic);
+  var = var < 0.0 ? 0.0 : var;
+  const double ve = var + (double)eps, hv = 0.5 * ve;
+  double r = (double)__builtin_amdgcn_rsqf((float)ve);
+  r = r * __builtin_fma(-hv * r, r, 1.5);      // Newton: r <- r (3 - ve r^2) / 2
+  r = r * __builtin_fma(-hv * r, r, 1.5);
+  const double gr = (double)ga * r;
+  HpfgBnCoef q;
+  q.mean = (float)mean;
+  q.rstd = (float)r;
+  q.scale = (float)gr;
+  q.shift = (float)__builtin_fma(-mean, gr, (double)be);
+  q.var = var;
+  return q;
+}
+// Backward coefficients dz = k1 * g + k2 * z + k3 of one channel from the backward sums (sum g, sum g * xhat) -- the definition
+// hpfg_bn_bwd_finalize and every dZ consumer's prologue share (HpfgAct.bn_acc on a DZ source = the layer's BACKWARD accumulator).
+struct HpfgBnBwdCoef {
+  float k1, k2, k3;
+};
+__device__ __forceinline__ HpfgBnBwdCoef hpfg_bn_bwd_coef(double sg, double sgx, double count, double mean, double rstd, double ga) {
+#pragma clang fp contract(off)
+  double ic = (double)__builtin_amdgcn_rcpf((float)count);
+  ic = ic * __builtin_fma(-count, ic, 2.0);
+  ic = ic * __builtin_fma(-count, ic, 2.0);
+  const double m1 = sg * ic, m2 = sgx * ic, gr = ga * rstd;
+  HpfgBnBwdCoef q;
+  q.k1 = (float)gr;
+  q.k2 = (float)(-(gr * rstd) * m2);
+  q.k3 = (float)(gr * __builtin_fma(mean * rstd, m2, -m1));
+  return q;
+}
+// rows scale, shift, k1, k2, k3 of the C channels of a DZ source -> t[r * cmax + c] (LDS; all threads call, the caller syncs): the table
+// rows, or (bn_acc) k1 .. k3 derived here from the layer's backward sums -- no bn_bwd_finalize launch between the kernel that completed the
+// sums and this one.  mean / rstd / scale / shift come from the table the forward pass left (hpfg_bn_acc_finalize / hpfg_bn_fwd_finalize).
+__device__ __forceinline__ void hpfg_dz_rows_to_lds(const HpfgAct& a, float* t, int cmax, int nch, int tid, int nthr) {
+  for (int c = tid; c < nch; c += nthr) {
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < a.C) {
+      const float* tb = a.bn + a.bn_coff + c;
+      const int st = a.bn_stride;
+      v[0] = tb[HPFG_BN_SCALE * st];
+      v[1] = tb[HPFG_BN_SHIFT * st];
+      if (a.bn_acc) {
+        double sg, sgx;
+        hpfg_acc_read2(a.bn_acc, st, a.bn_shards, a.bn_coff + c, sg, sgx);
+        const HpfgBnBwdCoef q = hpfg_bn_bwd_coef(sg, sgx, (double)a.bn_count, (double)tb[HPFG_BN_MEAN * st], (double)tb[HPFG_BN_RSTD * st],
+                                                 (double)a.bn_gamma[a.bn_coff + c]);
+        v[2] = q.k1;
+        v[3] = q.k2;
+        v[4] = q.k3;
+      } else {
+        v[2] = tb[HPFG_BN_K1 * st];
+        v[3] = tb[HPFG_BN_K2 * st];
+        v[4] = tb[HPFG_BN_K3 * st];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r) t[r * cmax + c] = v[r];
+  }
+}
+// scale / shift of the C channels of a BatchNorm'd source -> t[0 .. C) and t[cmax .. cmax + C) (LDS; all NTHR threads call, the caller syncs)
+__device__ __forceinline__ void hpfg_bn_rows_to_lds(const HpfgAct& a, float* t, int cmax, int tid, int nthr) {
+  for (int c = tid; c < a.C; c += nthr) {
+    float sc, sh;
+    if (a.bn_acc) {
+      const int cc = a.bn_coff + c;
+      double s1, s2;
+      hpfg_acc_read2(a.bn_acc, a.bn_stride, a.bn_shards, cc, s1, s2);
+      const HpfgBnCoef q = hpfg_bn_coef(s1, s2, (double)a.bn_count, a.bn_eps, a.bn_gamma[cc], a.bn_beta[cc]);
+      sc = q.scale;
+      sh = q.shift;
+    } else {
+      sc = a.bn[a.bn_coff + HPFG_BN_SCALE * a.bn_stride + c];
+      sh = a.bn[a.bn_coff + HPFG_BN_SHIFT * a.bn_stride + c];
+    }
+    t[c] = sc;
+    t[cmax + c] = sh;
+  }
+}
 
 // Per-block cache of everything a loader needs that does not depend on the pixel.
 struct ActCtx {

@@ -23,6 +23,8 @@ struct HpfgFirstConvArgs {   // kernel argument of the first-layer kernels
   const float* bias;
   float* out;
   float* stat_partials; // or NULL
+  long long* stat_acc;  // or NULL: the sums go into the layer accumulator by integer atomics instead (HpfgConvArgs.stat_acc)
+  int stat_shards;
 };
 
 inline bool tile_is_big(int H, int W) { return (H % 16 == 0) && (W % 16 == 0); }
@@ -38,6 +40,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(HpfgFirstConvArgs q, in
   const float* __restrict__ bias = q.bias;
   float* __restrict__ out = q.out;
   float* __restrict__ stat = q.stat_partials;
+  long long* __restrict__ sacc = q.stat_acc;
   __shared__ float tin[4][TP * TP];
   __shared__ __attribute__((aligned(16))) float wl[9 * 4 * CO];
   __shared__ float red[2][4][CO];
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(HpfgFirstConvArgs q, in
       }
     }
   }
-  if (stat) {
+  if (stat || sacc) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(HpfgFirstConvArgs q, in
     if (tid < 2 * CO) {
       int which = tid / CO, co = tid % CO;
       float t = red[which][0][co] + red[which][1][co] + red[which][2][co] + red[which][3][co];
-      stat[((long)blockIdx.x * 2 + which) * CO + co] = t;
+      if (sacc) hpfg_acc_add(sacc, CO, (int)blockIdx.x & (q.stat_shards - 1), which, co, t);
+      if (stat) stat[((long)blockIdx.x * 2 + which) * CO + co] = t;
     }
   }
 }
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(HpfgFirstConvArgs 
   const float* __restrict__ w = q.w_oihw;
   float* __restrict__ out = q.out;
   float* __restrict__ stat = q.stat_partials;
+  long long* __restrict__ sacc = q.stat_acc;
   __shared__ float tin[CIN * NPIX];
   __shared__ float red[2][4][CO];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(HpfgFirstConvArgs 
       s2[r] += acc * acc;    // conditional update of the accumulator arrays makes the compiler copy all 32 registers around each one
     }
   }
-  if (stat) {
+  if (stat || sacc) {
     const f32x4 t1 = (s1[0] + s1[2]) + (s1[1] + s1[3]), t2 = (s2[0] + s2[2]) + (s2[1] + s2[3]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -227,7 +232,9 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(HpfgFirstConvArgs 
     __syncthreads();
     if (tid < 2 * CO) {
       const int which = tid / CO, co = tid % CO;
-      stat[((long)blockIdx.x * 2 + which) * CO + co] = red[which][0][co] + red[which][1][co] + red[which][2][co] + red[which][3][co];
+      const float t = red[which][0][co] + red[which][1][co] + red[which][2][co] + red[which][3][co];
+      if (sacc) hpfg_acc_add(sacc, CO, (int)blockIdx.x & (q.stat_shards - 1), which, co, t);
+      if (stat) stat[((long)blockIdx.x * 2 + which) * CO + co] = t;
     }
   }
 }
@@ -269,12 +276,26 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
   HPFG_ARG_CHECK(a->out_split == 0 || (a->out2 && a->out_split % 16 == 0 && a->out_split < a->Cout && a->out2_pstride >= a->Cout - a->out_split &&
                                        !a->bwd_stats),
                  "conv_fwd: out_split needs out2, a multiple of 16 below Cout, and no bwd_stats");
+  HPFG_ARG_CHECK(!a->stat_acc || ((a->math & 0xff) == HPFG_MATH_BF16X3 && a->Cout == a->CoutPad && a->stat_shards >= 1 &&
+                                  a->stat_shards <= HPFG_ACC_MAX_SHARDS && (a->stat_shards & (a->stat_shards - 1)) == 0),
+                 "conv_fwd: stat_acc is a bf16x3 forward feature (Cout == CoutPad, stat_shards a power of two <= %d)", HPFG_ACC_MAX_SHARDS);
+  for (const HpfgAct* s : {&a->a0, &a->a1}) {
+    if (!s->bn_acc) continue;
+    HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && (s->mode == HPFG_ACT_BNACT || s->mode == HPFG_ACT_BNACT_POOL || s->mode == HPFG_ACT_DZ) &&
+                       s->bn_gamma && (s->bn_beta || s->mode == HPFG_ACT_DZ) && s->bn_count >= 1.f && s->C <= 256 && s->bn_shards >= 1 &&
+                       s->bn_shards <= HPFG_ACC_MAX_SHARDS,
+                   "conv_fwd: bn_acc needs a BNACT / BNACT_POOL / DZ source of the bf16x3 kernels with gamma (beta), count and at most 256 channels");
+  }
+  HPFG_ARG_CHECK((a->math & 0xff) != HPFG_MATH_BF16X3 || !(a->a0.mode == HPFG_ACT_BNACT || a->a0.mode == HPFG_ACT_BNACT_POOL || a->a0.mode == HPFG_ACT_DZ) ||
+                     a->a0.C <= 256,
+                 "conv_fwd(bf16x3): a BatchNorm'd source has at most 256 channels (got %d)", a->a0.C);
   hipStream_t st = (hipStream_t)stream;
   if (a->bwd_stats) {
     const int kind = hpfg_kind_of(a->a0, a->a1);
     HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && (kind == HPFG_KIND_DZ || kind == HPFG_KIND_PLAIN),
                    "conv_fwd: bwd_stats is a dgrad feature of the bf16x3 kernels (DZ or PLAIN source)");
-    HPFG_ARG_CHECK(a->stat_partials && a->bwd_of.z && a->bwd_of.bn && !a->bias, "conv_fwd: bwd_stats needs stat_partials, bwd_of.z / .bn and no bias");
+    HPFG_ARG_CHECK((a->stat_partials || a->stat_acc) && a->bwd_of.z && a->bwd_of.bn && !a->bias,
+                   "conv_fwd: bwd_stats needs stat_partials or stat_acc, bwd_of.z / .bn and no bias");
     HPFG_ARG_CHECK(a->bwd_of.C == a->Cout && a->Cout == a->CoutPad && a->bwd_of.Hs == a->H && a->bwd_of.Ws == a->W && a->bwd_of.pstride % 4 == 0,
                    "conv_fwd: bwd_of must describe a layer with C == Cout == CoutPad (%d/%d/%d) at the output size", a->bwd_of.C, a->Cout, a->CoutPad);
   }
@@ -316,11 +337,10 @@ static int conv_first_impl(const HpfgFirstConvArgs* q, int N, int H, int W, int 
   HPFG_ARG_CHECK(q->x.z && q->w_oihw && q->bias && q->out, "conv_first: null pointer");
   HPFG_ARG_CHECK(q->x.mode == HPFG_ACT_STRIDED, "conv_first: input must be a STRIDED source");
   // stat partial layout must match hpfg_conv_stat_blocks(): 16x16 tiles only when H,W are multiples of 16
-  HPFG_ARG_CHECK(q->stat_partials == nullptr || tile_is_big(H, W), "conv_first: BN partials need H,W multiples of 16 (got %dx%d)", H, W);
+  HPFG_ARG_CHECK((q->stat_partials == nullptr && q->stat_acc == nullptr) || tile_is_big(H, W), "conv_first: BN sums need H,W multiples of 16 (got %dx%d)", H, W);
   int tx = (W + 15) / 16, ty = (H + 15) / 16;
-  const char* fe = getenv("HPFG_FIRST_MFMA");      // 0: the VALU form for the 1-channel layer too (A/B runs)
   const dim3 g1(conv_first_grid(N, H, W));
-  if ((Cin == 1 || Cin == 3) && !(fe && atoi(fe) == 0)) {      // grey-scale (ACDC / LIDC) and RGB (CPS config) inputs
+  if ((Cin == 1 || Cin == 3) && hpfg_opt(HPFG_OPT_FIRST_MFMA) != 0) {      // grey-scale (ACDC / LIDC) and RGB (CPS config) inputs (option 0: the VALU form, A/B runs)
     if (Cin == 1) hipLaunchKernelGGL((conv_first_mfma_kernel<1>), g1, dim3(256), 0, (hipStream_t)stream, *q, N, H, W, tx, ty);
     else hipLaunchKernelGGL((conv_first_mfma_kernel<3>), g1, dim3(256), 0, (hipStream_t)stream, *q, N, H, W, tx, ty);
     return hpfg_launch_status("conv_first_mfma_kernel");
@@ -332,7 +352,15 @@ static int conv_first_impl(const HpfgFirstConvArgs* q, int N, int H, int W, int 
 extern "C" int hpfg_conv3x3_first_fwd(const HpfgAct* x, const float* w_oihw, const float* bias, float* out, float* stat_partials,
                                       int N, int H, int W, int Cin, int Cout, void* stream) {
   HPFG_ARG_CHECK(x, "conv_first: null pointer");
-  HpfgFirstConvArgs a = {*x, w_oihw, bias, out, stat_partials};
+  HpfgFirstConvArgs a = {*x, w_oihw, bias, out, stat_partials, nullptr, 1};
+  return conv_first_impl(&a, N, H, W, Cin, Cout, stream);
+}
+
+extern "C" int hpfg_conv3x3_first_fwd_acc(const HpfgAct* x, const float* w_oihw, const float* bias, float* out, float* stat_partials, long long* stat_acc,
+                                          int stat_shards, int N, int H, int W, int Cin, int Cout, void* stream) {
+  HPFG_ARG_CHECK(x && stat_acc, "conv_first_acc: null pointer");
+  HPFG_ARG_CHECK(stat_shards >= 1 && stat_shards <= HPFG_ACC_MAX_SHARDS && (stat_shards & (stat_shards - 1)) == 0, "conv_first_acc: bad shard count %d", stat_shards);
+  HpfgFirstConvArgs a = {*x, w_oihw, bias, out, stat_partials, stat_acc, stat_shards};
   return conv_first_impl(&a, N, H, W, Cin, Cout, stream);
 }
 

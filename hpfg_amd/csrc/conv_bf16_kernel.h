@@ -175,7 +175,7 @@ __device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (
 template <class C, bool BWD = false>
 __device__ __forceinline__ void conv16_flush_stats(const HpfgConvArgs& p, f32x4 (&s1)[C::NI], f32x4 (&s2)[C::NI], float* ldsf, int tid, int lane, int wm,
                                                    int wn, int cb, int row) {
-  if (!p.stat_partials || (p.math & 0x1000)) return;
+  if ((!p.stat_partials && !p.stat_acc) || (p.math & 0x1000)) return;
 #pragma unroll
   for (int j = 0; j < C::NI; ++j)
 #pragma unroll
@@ -211,7 +211,9 @@ __device__ __forceinline__ void conv16_flush_stats(const HpfgConvArgs& p, f32x4 
       const float* tb = p.bwd_of.bn + p.bwd_of.bn_coff + co;
       t = tb[HPFG_BN_RSTD * p.bwd_of.bn_stride] * (t - tb[HPFG_BN_MEAN * p.bwd_of.bn_stride] * sg);
     }
-    if (co < p.CoutPad) p.stat_partials[((long)row * 2 + which) * p.CoutPad + co] = t;
+    if (p.stat_acc && co < p.Cout)      // integer atomics into the layer accumulator: no finalize launch needs rows
+      hpfg_acc_add(p.stat_acc, p.CoutPad, ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x & (p.stat_shards - 1), which, co, t);
+    if (p.stat_partials && co < p.CoutPad) p.stat_partials[((long)row * 2 + which) * p.CoutPad + co] = t;
   }
 }
 
@@ -277,6 +279,9 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
   float* ldsf = reinterpret_cast<float*>(lds + 2 * C::BUF_BYTES);
   float* ldsU = reinterpret_cast<float*>(lds + 2 * C::BUF_BYTES + STAT_BYTES);      // low-res source patch of an upsampled chunk
   (void)ldsU;
+  constexpr bool TABK = tab_in_lds<KIND>();
+  __shared__ __attribute__((aligned(16))) float ldsBN[TABK ? tab_rows<KIND>() * HPFG_BN_CMAX : 4];      // scale | shift [| k1 | k2 | k3] of every channel of the source
+  (void)ldsBN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % C::WM, wn = wave / C::WM;
   const int cb = blockIdx.y;
@@ -359,16 +364,30 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
   {
     const int c0 = g8;
     const bool chv = c0 < cin_total;
-    load_tables<KIND>(tab, p.a0, c0, chv);
+    const int c0c = chv ? c0 : 0;
+    // the first tile's raw loads go out before the BatchNorm coefficients are formed (sum accumulators -> scale / shift in LDS): one
+    // exposed round trip for both
+    RawPiece<KIND> raw0[C::NLD];
 #pragma unroll
     for (int i = 0; i < C::NLD; ++i) {
       const int gy = ty0 + pc[i].ly, gx = tx0 + pc[i].lx;
       const bool ok = pc[i].ok && chv && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      RawPiece<KIND> raw;
+      issue_piece<KIND>(raw0[i], p.a0, p.a1, cx0, n, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
+    }
+    if constexpr (TABK) {
+      fill_tables_lds<KIND>(p.a0, ldsBN, tid, 256);
+      __syncthreads();
+      load_tables_lds<KIND>(tab, ldsBN, p.a0, c0c);
+    } else {
+      load_tables<KIND>(tab, p.a0, c0, chv);
+    }
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) {
+      const int gy = ty0 + pc[i].ly, gx = tx0 + pc[i].lx;
+      const bool ok = pc[i].ok && chv && gy >= 0 && gy < H && gx >= 0 && gx < W;
       f32x4 v0, v1;
-      const int gyc = clampi(gy, 0, H - 1), gxc = clampi(gx, 0, W - 1), c0c = chv ? c0 : 0;
-      issue_piece<KIND>(raw, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
-      finish_piece<KIND>(v0, v1, raw, tab, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
+      const int gyc = clampi(gy, 0, H - 1), gxc = clampi(gx, 0, W - 1);
+      finish_piece<KIND>(v0, v1, raw0[i], tab, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
       store_piece<C, KIND>(lds, pc[i], v0, v1);
     }
   }
@@ -416,7 +435,8 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
       const int c0c = c0n < cin_total ? c0n : 0;
       // No branches from here to the barrier (except the CAT loader's per-thread source select): the tables are reloaded even when
       // they cannot have changed, so that the whole chunk is one scheduling region with a hand-placed instruction order.
-      if (!TIGHT || (more && nchunks > 1)) load_tables<KIND>(tab, p.a0, c0c, true);
+      if constexpr (TABK) load_tables_lds<KIND>(tab, ldsBN, p.a0, c0c);
+      else if (!TIGHT || (more && nchunks > 1)) load_tables<KIND>(tab, p.a0, c0c, true);
       // Prefetch depth: kinds with few raw loads per piece (PLAIN/BNACT) put ALL pieces of the next item in flight before the
       // first MFMA and finish them after the last one (a whole item of latency cover); DZ (4 raw float4 + 10 table registers) and
       // POOL/CAT (8 raw float4 per piece) keep the two-k-step ring to stay inside the register budget.
@@ -581,6 +601,9 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int
   constexpr int NR = RawCount<KIND>::N;
   __shared__ __attribute__((aligned(16))) unsigned char lds[C::BUF_BYTES + STAT_BYTES];
   float* ldsf = reinterpret_cast<float*>(lds + C::BUF_BYTES);
+  constexpr bool TABK = tab_in_lds<KIND>();
+  __shared__ __attribute__((aligned(16))) float ldsBN[TABK ? tab_rows<KIND>() * HPFG_BN_CMAX : 4];
+  (void)ldsBN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % C::WM, wn = wave / C::WM;
   const int tile = blockIdx.x, n = blockIdx.y, cb = blockIdx.z;
@@ -606,10 +629,15 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int
   const int nt0 = (cb * C::WN + wn) * C::NI;
   const bf16x8* wpk = reinterpret_cast<const bf16x8*>(p.wpk);
   Tab tab;
+  if constexpr (TABK) {
+    fill_tables_lds<KIND>(p.a0, ldsBN, tid, 256);
+    __syncthreads();
+  }
   for (int ch = 0; ch < nchunks; ++ch) {
     const int c0 = ch * C::KC + g8;
     const bool chv = c0 < cin_total;
-    load_tables<KIND>(tab, p.a0, c0, chv);
+    if constexpr (TABK) load_tables_lds<KIND>(tab, ldsBN, p.a0, chv ? c0 : 0);
+    else load_tables<KIND>(tab, p.a0, c0, chv);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < C::NLD; ++i) {

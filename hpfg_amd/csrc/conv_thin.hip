@@ -16,10 +16,7 @@ int launch(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   return hpfg_launch_status("conv_thin_kernel");
 }
 
-bool enabled() {      // (read per call: tests switch it inside one process)
-  const char* e = getenv("HPFG_CONV_THIN");
-  return !e || atoi(e) != 0;
-}
+bool enabled() { return hpfg_opt(HPFG_OPT_CONV_THIN) != 0; }      // (tests switch it inside one process: hpfg_set_option)
 
 }  // namespace
 

@@ -70,11 +70,6 @@ __global__ __launch_bounds__(64 * NW, WGS) void conv_thin_kernel(HpfgConvArgs p,
   const ActCtx cxa = make_ctx(aS);
   const int gsel = tid & 1;                              // this thread's 8-channel group inside a 16-channel chunk
 
-  for (int i = tid; i < G::TROWS * 16 * NA0; i += NTH) {
-    const int r = i / (16 * NA0), ch = i % (16 * NA0);
-    const int row = r == 0 ? HPFG_BN_SCALE : r == 1 ? HPFG_BN_SHIFT : r == 2 ? HPFG_BN_K1 : r == 3 ? HPFG_BN_K2 : HPFG_BN_K3;
-    tabA[i] = ch < aS.C ? aS.bn[aS.bn_coff + row * aS.bn_stride + ch] : 0.f;
-  }
   const int ntn = p.CoutPad / 16;
   const bf16x8* wpk = reinterpret_cast<const bf16x8*>(p.wpk);
   constexpr int PB = G::BREG ? KS : 0;
@@ -150,6 +145,31 @@ __global__ __launch_bounds__(64 * NW, WGS) void conv_thin_kernel(HpfgConvArgs p,
 
   int w = xg * per_x + xj;
   if (w < wend) issue(w / ntiles, ((w % ntiles) / tiles_x) * T, ((w % ntiles) % tiles_x) * T, true);
+  // BatchNorm coefficients of the source -> LDS, behind the first tile's loads (one exposed round trip for both): the table rows, or --
+  // forward kinds with HpfgAct.bn_acc -- scale / shift derived here from the producer's sum accumulators (no finalize launch in between)
+  if (AK0 != HPFG_KIND_DZ && aS.bn_acc) {
+    for (int ch = tid; ch < 16 * NA0; ch += NTH) {
+      float sc = 0.f, sh = 0.f;
+      if (ch < aS.C) {
+        const int cc = aS.bn_coff + ch;
+        double s1, s2;
+        hpfg_acc_read2(aS.bn_acc, aS.bn_stride, aS.bn_shards, cc, s1, s2);
+        const HpfgBnCoef q = hpfg_bn_coef(s1, s2, (double)aS.bn_count, aS.bn_eps, aS.bn_gamma[cc], aS.bn_beta[cc]);
+        sc = q.scale;
+        sh = q.shift;
+      }
+      tabA[ch] = sc;
+      tabA[16 * NA0 + ch] = sh;
+    }
+  } else if (AK0 == HPFG_KIND_DZ) {      // rows scale, shift, k1, k2, k3 (table, or k1 .. k3 derived from the backward sum accumulators)
+    hpfg_dz_rows_to_lds(aS, tabA, 16 * NA0, 16 * NA0, tid, NTH);
+  } else if (AK0 != HPFG_KIND_PLAIN) {
+    for (int i = tid; i < G::TROWS * 16 * NA0; i += NTH) {
+      const int r = i / (16 * NA0), ch = i % (16 * NA0);
+      const int row = r == 0 ? HPFG_BN_SCALE : HPFG_BN_SHIFT;
+      tabA[i] = ch < aS.C ? aS.bn[aS.bn_coff + row * aS.bn_stride + ch] : 0.f;
+    }
+  }
   __syncthreads();                                       // tables, weight fragments
 
   for (; w < wend; w += GS) {
@@ -295,8 +315,9 @@ __global__ __launch_bounds__(64 * NW, WGS) void conv_thin_kernel(HpfgConvArgs p,
     }
     __syncthreads();                                     // this tile's LDS reads are done: the next one may be written
   }
-  if (p.stat_partials) {
+  if (p.stat_partials || p.stat_acc) {
     // per-lane sums -> over the 16 pixel lanes -> over the waves; row blockIdx.x of stat_partials ([rows][2][CoutPad]): sum(z), sum(z^2)
+    // (or, stat_acc: integer atomics into the layer accumulator)
 #pragma unroll
     for (int j = 0; j < CO; ++j)
 #pragma unroll
@@ -325,7 +346,8 @@ __global__ __launch_bounds__(64 * NW, WGS) void conv_thin_kernel(HpfgConvArgs p,
       float t = 0.f;
 #pragma unroll
       for (int k = 0; k < NW; ++k) t += ldsf[(which * NW + k) * BN + cl];
-      if (cl < p.CoutPad) p.stat_partials[((long)blockIdx.x * 2 + which) * p.CoutPad + cl] = t;
+      if (p.stat_acc && cl < p.Cout) hpfg_acc_add(p.stat_acc, p.CoutPad, (int)blockIdx.x & (p.stat_shards - 1), which, cl, t);
+      if (p.stat_partials && cl < p.CoutPad) p.stat_partials[((long)blockIdx.x * 2 + which) * p.CoutPad + cl] = t;
     }
   }
 }

@@ -79,7 +79,9 @@ extern "C" int hpfg_fused_bwd(const HpfgFusedBwdArgs* a, void* stream) {
   HPFG_ARG_CHECK(!d.out_split || (d.out2 && d.out_split % 16 == 0 && d.out_split < d.Cout && !d.bwd_stats),
                  "fused_bwd: out_split needs out2, a multiple of 16 below Cin, and no bwd_stats");
   if (d.bwd_stats) {
-    HPFG_ARG_CHECK(d.stat_partials && d.bwd_of.z && d.bwd_of.bn, "fused_bwd: bwd_stats needs stat_partials and bwd_of.z / .bn");
+    HPFG_ARG_CHECK((d.stat_partials || d.stat_acc) && d.bwd_of.z && d.bwd_of.bn, "fused_bwd: bwd_stats needs stat_partials or stat_acc, and bwd_of.z / .bn");
+    HPFG_ARG_CHECK(!d.stat_acc || (d.stat_shards >= 1 && d.stat_shards <= HPFG_ACC_MAX_SHARDS && (d.stat_shards & (d.stat_shards - 1)) == 0),
+                   "fused_bwd: bad stat_shards %d", d.stat_shards);
     HPFG_ARG_CHECK(d.bwd_of.C == d.Cout && d.Cout == d.CoutPad && d.bwd_of.Hs == d.H && d.bwd_of.Ws == d.W && d.bwd_of.pstride % 4 == 0,
                    "fused_bwd: bwd_of must describe a layer with C == Cin == CinPad at the layer's size");
     // the epilogue takes z and the scale / shift rows of that layer from the staged input tile
@@ -87,7 +89,7 @@ extern "C" int hpfg_fused_bwd(const HpfgFusedBwdArgs* a, void* stream) {
                        d.bwd_of.bn_coff == a->xa0.bn_coff && d.bwd_of.pstride == a->xa0.pstride,
                    "fused_bwd: bwd_of must be the producer of this layer's (BNACT) input");
   } else {
-    HPFG_ARG_CHECK(!d.stat_partials, "fused_bwd: stat_partials without bwd_stats");
+    HPFG_ARG_CHECK(!d.stat_partials && !d.stat_acc, "fused_bwd: stat_partials / stat_acc without bwd_stats");
   }
   const int r = dispatch(*a, (hipStream_t)stream, false);
   HPFG_ARG_CHECK(r != -2, "fused_bwd: no instantiation for CinPad %d, CoutPad %d, input kind %d, dZ kind %d", a->CinPad, a->CoutPad,

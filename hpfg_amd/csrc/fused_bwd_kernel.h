@@ -123,13 +123,7 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
   const int gsel = tid & 1;                              // this thread's 8-channel group inside a 16-channel chunk (256 % 2 == 0)
 
   // ---- per-channel tables -> LDS, once (rows: scale, shift [, k1, k2, k3])
-  if (GK == HPFG_KIND_DZ) {
-    for (int i = tid; i < 5 * 16 * CO; i += NTH) {
-      const int r = i / (16 * CO), ch = i % (16 * CO);
-      const int row = r == 0 ? HPFG_BN_SCALE : r == 1 ? HPFG_BN_SHIFT : r == 2 ? HPFG_BN_K1 : r == 3 ? HPFG_BN_K2 : HPFG_BN_K3;
-      tabD[i] = ch < aD.C ? aD.bn[aD.bn_coff + row * aD.bn_stride + ch] : 0.f;
-    }
-  }
+  if (GK == HPFG_KIND_DZ) hpfg_dz_rows_to_lds(aD, tabD, 16 * CO, 16 * CO, tid, NTH);      // (table rows, or k1 .. k3 from the backward sum accumulators)
   for (int i = tid; i < 2 * 16 * NA0 && AK0 != HPFG_KIND_PLAIN; i += NTH) {
     const int r = i / (16 * NA0), ch = i % (16 * NA0);
     tabA[i] = ch < aS.C ? aS.bn[aS.bn_coff + (r == 0 ? HPFG_BN_SCALE : HPFG_BN_SHIFT) * aS.bn_stride + ch] : 0.f;
@@ -507,7 +501,8 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
         const float* tb = p.d.bwd_of.bn + p.d.bwd_of.bn_coff + cl;
         t = tb[HPFG_BN_RSTD * p.d.bwd_of.bn_stride] * (t - tb[HPFG_BN_MEAN * p.d.bwd_of.bn_stride] * sg);
       }
-      p.d.stat_partials[((long)blockIdx.x * 2 + which) * p.d.CoutPad + cl] = t;
+      if (p.d.stat_acc) hpfg_acc_add(p.d.stat_acc, p.d.CoutPad, (int)blockIdx.x & (p.d.stat_shards - 1), which, cl, t);
+      if (p.d.stat_partials) p.d.stat_partials[((long)blockIdx.x * 2 + which) * p.d.CoutPad + cl] = t;
     }
   }
   HPFG_TR(11)

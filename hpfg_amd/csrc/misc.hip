@@ -14,6 +14,16 @@ extern "C" void hpfg_set_error(const char* fmt, ...) {
 extern "C" const char* hpfg_last_error(void) { return g_err; }
 extern "C" int hpfg_version(void) { return HPFG_VERSION; }
 
+// ---- kernel-form switches (tests and A/B tools; never read from the environment in a launch path) -------------------------------------
+static int g_opt[HPFG_OPT_COUNT] = {1, 1};
+int hpfg_opt(int which) { return which >= 0 && which < HPFG_OPT_COUNT ? g_opt[which] : 0; }
+extern "C" int hpfg_set_option(int which, int value) {
+  HPFG_ARG_CHECK(which >= 0 && which < HPFG_OPT_COUNT, "set_option: unknown option %d", which);
+  const int old = g_opt[which];
+  g_opt[which] = value;
+  return old;
+}
+
 namespace {
 
 // ---- weight packing: OIHW -> MFMA B-fragment order (see conv.hip) ------------------------------------------------------
@@ -22,11 +32,13 @@ namespace {
 // Two per-forward device counters ride along (one workgroup, before any packing): num_batches_tracked of the network's BatchNorm layers
 // (+1 each) and the dropout seed word of the engine (+seed_add) -- no launches of their own in front of every forward.
 __global__ __launch_bounds__(256) void pack_weights_kernel(const HpfgPackDesc* __restrict__ table, long long* __restrict__ counters, int n_counters,
-                                                           int* __restrict__ seed_word, int seed_add) {
+                                                           int* __restrict__ seed_word, int seed_add, long long* __restrict__ zero, long n_zero) {
   if (blockIdx.x == 0 && blockIdx.y == 0) {
     for (int i = threadIdx.x; i < n_counters; i += 256) counters[i] += 1;
     if (threadIdx.x == 0 && seed_word && seed_add) *seed_word = (*seed_word + seed_add) & 0x7FFFFFFF;
   }
+  // the BatchNorm sum accumulators of the pass that follows (HpfgConvArgs.stat_acc) start from zero
+  for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < n_zero; i += (long)gridDim.x * gridDim.y * 256) zero[i] = 0;
   const HpfgPackDesc d = table[blockIdx.y];
   const long total = (long)d.taps * d.CinPad * d.CoutPad;
   const int nt_f = d.CoutPad / 16, nch_f = d.CinPad / 16;
@@ -501,8 +513,9 @@ extern "C" long hpfg_wpk16_elems(int Kchannels, int NchannelsPad, int taps, int 
 }
 
 extern "C" int hpfg_pack_weights_bump(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, long long* counters, int n_counters,
-                                      int32_t* seed_word, int seed_add, void* stream) {
+                                      int32_t* seed_word, int seed_add, long long* zero_words, long n_zero, void* stream) {
   HPFG_ARG_CHECK(table_dev && table_host && nlayers > 0 && nlayers < 65536, "pack_weights: bad args");
+  HPFG_ARG_CHECK(n_zero >= 0 && (n_zero == 0 || zero_words), "pack_weights: bad zero region");
   HPFG_ARG_CHECK(n_counters >= 0 && (n_counters == 0 || counters) && (seed_add == 0 || seed_word), "pack_weights: bad counter arguments");
   long mx = 0;
   for (int i = 0; i < nlayers; ++i) {
@@ -514,12 +527,12 @@ extern "C" int hpfg_pack_weights_bump(const HpfgPackDesc* table_dev, const HpfgP
     if (t > mx) mx = t;
   }
   hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(mx, 256), nlayers), dim3(256), 0, (hipStream_t)stream, table_dev, counters, n_counters, seed_word,
-                     seed_add);
+                     seed_add, zero_words, n_zero);
   return hpfg_launch_status("pack_weights_kernel");
 }
 
 extern "C" int hpfg_pack_weights(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, void* stream) {
-  return hpfg_pack_weights_bump(table_dev, table_host, nlayers, nullptr, 0, nullptr, 0, stream);
+  return hpfg_pack_weights_bump(table_dev, table_host, nlayers, nullptr, 0, nullptr, 0, nullptr, 0, stream);
 }
 
 extern "C" int hpfg_act_materialize(const HpfgAct* a0, const HpfgAct* a1, int N, int H, int W, float* out, void* stream) {

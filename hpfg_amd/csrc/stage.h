@@ -69,6 +69,36 @@ __device__ __forceinline__ void load_tables(Tab& t, const HpfgAct& a0, int c0, b
   }
 }
 
+// The forward kinds (BNACT / POOL / concat skip half) read scale / shift of the whole source from LDS rows the kernel prologue filled
+// (hpfg_bn_rows_to_lds: from the table, or derived from the producer's sum accumulators).
+constexpr int HPFG_BN_CMAX = 256;      // channels of a BatchNorm'd source whose coefficients a consumer keeps in LDS
+template <int KIND>
+constexpr bool tab_in_lds() { return KIND == HPFG_KIND_BNACT || KIND == HPFG_KIND_POOL || KIND == HPFG_KIND_CAT || KIND == HPFG_KIND_DZ; }
+template <int KIND>
+constexpr int tab_rows() { return KIND == HPFG_KIND_DZ ? 5 : 2; }      // scale, shift [, k1, k2, k3]
+template <int KIND>
+__device__ __forceinline__ void load_tables_lds(Tab& t, const float* ldsT, const HpfgAct& a0, int c0) {
+  if (KIND == HPFG_KIND_CAT && c0 >= a0.C) return;
+  t.sc[0] = ld4(ldsT, c0);
+  t.sc[1] = ld4(ldsT, c0 + 4);
+  t.sh[0] = ld4(ldsT, HPFG_BN_CMAX + c0);
+  t.sh[1] = ld4(ldsT, HPFG_BN_CMAX + c0 + 4);
+  if (KIND == HPFG_KIND_DZ) {
+    t.k1[0] = ld4(ldsT, 2 * HPFG_BN_CMAX + c0);
+    t.k1[1] = ld4(ldsT, 2 * HPFG_BN_CMAX + c0 + 4);
+    t.k2[0] = ld4(ldsT, 3 * HPFG_BN_CMAX + c0);
+    t.k2[1] = ld4(ldsT, 3 * HPFG_BN_CMAX + c0 + 4);
+    t.k3[0] = ld4(ldsT, 4 * HPFG_BN_CMAX + c0);
+    t.k3[1] = ld4(ldsT, 4 * HPFG_BN_CMAX + c0 + 4);
+  }
+}
+// the kernel prologue's fill of those rows
+template <int KIND>
+__device__ __forceinline__ void fill_tables_lds(const HpfgAct& a0, float* ldsT, int tid, int nthr) {
+  if (KIND == HPFG_KIND_DZ) hpfg_dz_rows_to_lds(a0, ldsT, HPFG_BN_CMAX, a0.C, tid, nthr);
+  else hpfg_bn_rows_to_lds(a0, ldsT, HPFG_BN_CMAX, tid, nthr);
+}
+
 // bilinear x2 (align_corners=True) source taps of output coordinate o for a low-res extent L
 __device__ __forceinline__ void up_coord(int o, int L, int& i0, int& i1, float& w1) {
   const float r = L > 1 ? (float)(L - 1) / (float)(2 * L - 1) : 0.f;

@@ -135,12 +135,11 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
   const bool cva = ca < cin_total, cvg = cg < p.g.C;
   const bool a_up = CATA && ci0 >= p.a0.C;                // workgroup-uniform
   if (!a_up) load_tables<SA>(ta, p.a0, cva ? ca : 0, true);
-  if (GK == HPFG_KIND_DZ) {
-    for (int i = tid; i < 5 * 16 * NJ; i += NTHR) {
-      const int r = i / (16 * NJ), c = co0 + i % (16 * NJ);
-      const int row = r == 0 ? HPFG_BN_SCALE : (r == 1 ? HPFG_BN_SHIFT : (r == 2 ? HPFG_BN_K1 : (r == 3 ? HPFG_BN_K2 : HPFG_BN_K3)));
-      ldsTG[r][i % (16 * NJ)] = c < p.g.C ? p.g.bn[p.g.bn_coff + row * p.g.bn_stride + c] : 0.f;
-    }
+  if (GK == HPFG_KIND_DZ) {      // (table rows, or k1 .. k3 derived from the backward sum accumulators: HpfgAct.bn_acc)
+    HpfgAct gs = p.g;          // this workgroup's 16 NJ output channels
+    gs.bn_coff += co0;
+    gs.C = p.g.C - co0 < 16 * NJ ? p.g.C - co0 : 16 * NJ;
+    hpfg_dz_rows_to_lds(gs, &ldsTG[0][0], 16 * NJ, 16 * NJ, tid, NTHR);
   }
 
   // Staging is batched: every global load of a batch is in flight before the first one is consumed (a thread owns NA pieces of
@@ -356,22 +355,63 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
     __syncthreads();
     HPFG_WTR(7)
     // ---- 4 MFMA k-steps of 32 pixels (2 tile rows each)
+    if constexpr (NT == 9 && TAPS == 9) {
+      // A wave that owns all nine taps (the 2 x 2 channel-rich shape): the A fragment of (k-step ks, kernel row ky) covers tile rows
+      // 2 ks + ky and 2 ks + ky + 1, so (ks, ky = 2) and (ks + 1, ky = 0) are the SAME registers -- carried over instead of read again:
+      // 27 instead of 36 fragment pairs per work item.  The MFMA phase of this kernel is bound by its transposing LDS reads (40 per 27
+      // MFMAs before, LDS shared by the 8 waves of a CU), not by the matrix pipe.  Every accumulator sees the same MFMAs in the same order.
+      bf16x8 ch[3], cl[3];
 #pragma unroll
-    for (int ks = 0; ks < TH / 2; ++ks) {
-      const int r0 = 2 * ks;
-      const unsigned char* b = ldsG + wj * 2 * G_PLANE + (r0 * TW + xoff) * 32 + pp * 8;
-      const bf16x8 gh = tr_read8(b, b + TW * 32);
-      const bf16x8 gl = tr_read8(b + G_PLANE, b + G_PLANE + TW * 32);
+      for (int kx = 0; kx < 3; ++kx) {
+        const unsigned char* a = ldsA + wi * 2 * A_PLANE + (xoff + kx) * 32 + pp * 8;
+        ch[kx] = tr_read8(a, a + WP * 32);
+        cl[kx] = tr_read8(a + A_PLANE, a + A_PLANE + WP * 32);
+      }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int tap = wt0 + t * TSTR < TAPS ? wt0 + t * TSTR : TAPS - 1;
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        const unsigned char* a = ldsA + wi * 2 * A_PLANE + ((r0 + ky) * WP + xoff + kx) * 32 + pp * 8;
-        const bf16x8 ah = tr_read8(a, a + WP * 32);
-        const bf16x8 al = tr_read8(a + A_PLANE, a + A_PLANE + WP * 32);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gh, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gl, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, gh, acc[t], 0, 0, 0);
+      for (int ks = 0; ks < TH / 2; ++ks) {
+        const int r0 = 2 * ks;
+        const unsigned char* b = ldsG + wj * 2 * G_PLANE + (r0 * TW + xoff) * 32 + pp * 8;
+        const bf16x8 gh = tr_read8(b, b + TW * 32);
+        const bf16x8 gl = tr_read8(b + G_PLANE, b + G_PLANE + TW * 32);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            bf16x8 ah = ch[kx], al = cl[kx];
+            if (ky > 0) {
+              const unsigned char* a = ldsA + wi * 2 * A_PLANE + ((r0 + ky) * WP + xoff + kx) * 32 + pp * 8;
+              ah = tr_read8(a, a + WP * 32);
+              al = tr_read8(a + A_PLANE, a + A_PLANE + WP * 32);
+              if (ky == 2) {
+                ch[kx] = ah;
+                cl[kx] = al;
+              }
+            }
+            const int t = ky * 3 + kx;
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, gh, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < TH / 2; ++ks) {
+        const int r0 = 2 * ks;
+        const unsigned char* b = ldsG + wj * 2 * G_PLANE + (r0 * TW + xoff) * 32 + pp * 8;
+        const bf16x8 gh = tr_read8(b, b + TW * 32);
+        const bf16x8 gl = tr_read8(b + G_PLANE, b + G_PLANE + TW * 32);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int tap = wt0 + t * TSTR < TAPS ? wt0 + t * TSTR : TAPS - 1;
+          const int ky = tap / 3, kx = tap - 3 * ky;
+          const unsigned char* a = ldsA + wi * 2 * A_PLANE + ((r0 + ky) * WP + xoff + kx) * 32 + pp * 8;
+          const bf16x8 ah = tr_read8(a, a + WP * 32);
+          const bf16x8 al = tr_read8(a + A_PLANE, a + A_PLANE + WP * 32);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, gh, acc[t], 0, 0, 0);
+        }
       }
     }
     HPFG_WTR(8)

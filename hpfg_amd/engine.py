@@ -141,6 +141,37 @@ class UNetEngine:
         self.wpk16_d = {s.name: torch.empty(self.lib.hpfg_wpk16_elems(s.cout, s.cin_pad, s.taps, self.kc[s.name]), dtype=torch.bfloat16, device=device)
                         for s in self.packed}
         self._pack_tables: Dict[tuple, tuple] = {}   # (math, with_dgrad) -> (host descriptors, device copy), built on first use
+        # BatchNorm sums through integer atomics (csrc/common.h: hpfg_acc_add): a conv adds its per-channel sums to the layer's accumulator and
+        # every forward consumer derives scale / shift from it in its prologue, so NO finalize launch sits between two convs; ONE launch at the
+        # end of the forward (hpfg_bn_acc_finalize) writes all 18 tables for the backward kernels and the running statistics.  bf16x3 kernels,
+        # per-rank statistics only (the global-batch data-parallel mode exchanges the sums inside its finalize kernels and keeps them).
+        self.bn_layers = [s for s in self.order if s.bn]      # (encoder layers first: build_specs order)
+        self._n_enc_bn = sum(1 for s in self.bn_layers if s.name.startswith("encoder."))
+        self.bn_acc_mode = int(os.environ.get("HPFG_BN_ACC", "1"))      # 0 off; 1 on; 2 / 3: timing experiments (atomics only / + consumer prologues, finalize launches kept)
+        self.bn_acc_on = self.bn_acc_mode != 0
+        # shards: the producers' same-address atomics want many (ONE shard: +0.3 ms per step, two: +0.09), every consumer workgroup's prologue
+        # wants few (32 bytes per channel and shard).  Measured in the step (profiles/r04_bn_acc.txt): 8 everywhere beats 4 and beats 8 / 4 / 2 by
+        # channel count -- the contention costs more than the prologue reads.
+        force = int(os.environ.get("HPFG_ACC_SHARDS", "0"))
+        self.acc_shards = {s.name: (force or L.ACC_MAX_SHARDS) for s in self.bn_layers}
+        self.acc_all = torch.zeros(sum(self.acc_shards[s.name] * 4 * s.cout for s in self.bn_layers), dtype=torch.int64, device=device)
+        self.acc_of, off = {}, 0
+        for s in self.bn_layers:
+            assert s.cout == s.cout_pad
+            self.acc_of[s.name] = self.acc_all[off:off + self.acc_shards[s.name] * 4 * s.cout]
+            off += self.acc_shards[s.name] * 4 * s.cout
+        self._acc_live = False
+        self._acc_tables: Dict[bool, tuple] = {}
+        # the same for the backward sums (sum g, sum g * xhat): added by the dgrad epilogue / the reduction pass that completes a layer's
+        # gradient, read by every dZ consumer's prologue (k1 .. k3 derived there), turned into dgamma / dbeta -- and zeroed again -- by ONE
+        # launch per backward (hpfg_bn_acc_bwd_finalize) instead of 18 finalize launches on the critical chain
+        self.accb_all = torch.zeros_like(self.acc_all)
+        self.accb_of, off = {}, 0
+        for s in self.bn_layers:
+            self.accb_of[s.name] = self.accb_all[off:off + self.acc_shards[s.name] * 4 * s.cout]
+            off += self.acc_shards[s.name] * 4 * s.cout
+        self._accb_live, self._accb_dirty = False, False
+        self._accb_table = None
         self.seed_dev = torch.zeros(1, dtype=torch.int32, device=device)   # run-time dropout seed word
         self.bump_counters: Optional[torch.Tensor] = None      # set by the module in front of a train-mode forward: int64 counters the pack launch advances
         self.base_seed = 0x1234567
@@ -197,6 +228,9 @@ class UNetEngine:
         a = L.Act()
         a.z, a.bn, a.mode, a.C = L.ptr(self.z[name]), L.ptr(self.bn[name]), mode, s.cout
         a.Hs, a.Ws, a.pstride, a.bn_stride, a.bn_coff = s.h, s.w, s.cout, s.cout, 0
+        if self._acc_live and self.bn_acc_mode != 2 and mode in (L.ACT_BNACT, L.ACT_BNACT_POOL):      # the forward consumers form scale / shift from the sums themselves
+            a.bn_acc, a.bn_gamma, a.bn_beta = L.ptr(self.acc_of[name]), L.ptr(self.params[f"{s.bn}.weight"]), L.ptr(self.params[f"{s.bn}.bias"])
+            a.bn_count, a.bn_eps, a.bn_shards = float(self.N * s.h * s.w), BN_EPS, self.acc_shards[name]
         if mode == L.ACT_BNACT and s.drop_p > 0 and self.dropout_on:
             a.drop_p, a.drop_seed, a.seed_dev = s.drop_p, self.layer_seed(s), L.ptr(self.seed_dev)
             a.drop_mask = L.ptr(self.ext_masks.get(name)) if self.ext_masks else None
@@ -222,6 +256,8 @@ class UNetEngine:
         a = L.Act()
         a.z, a.bn, a.aux, a.mode, a.C = L.ptr(self.z[name]), L.ptr(self.bn[name]), L.ptr(dA), L.ACT_DZ, s.cout
         a.Hs, a.Ws, a.pstride, a.aux_pstride, a.bn_stride = s.h, s.w, s.cout, da_pstride, s.cout
+        if self._accb_live:          # the dZ consumers form k1 .. k3 from the backward sums themselves
+            a.bn_acc, a.bn_gamma, a.bn_count, a.bn_shards = L.ptr(self.accb_of[name]), L.ptr(self.params[f"{s.bn}.weight"]), float(self.N * s.h * s.w), self.acc_shards[name]
         if s.drop_p > 0 and self.dropout_on:
             a.drop_p, a.drop_seed, a.seed_dev = s.drop_p, self.layer_seed(s), L.ptr(self.seed_dev)
             a.drop_mask = L.ptr(self.ext_masks.get(name)) if self.ext_masks else None
@@ -271,15 +307,48 @@ class UNetEngine:
             self._pack_tables[key] = (descs, dev)
         return self._pack_tables[key]
 
-    def pack(self, with_dgrad: bool = True, counters: Optional[torch.Tensor] = None, seed_add: int = 0):
+    def pack(self, with_dgrad: bool = True, counters: Optional[torch.Tensor] = None, seed_add: int = 0, zero_acc: bool = False):
         """counters: int64 tensor whose elements the same launch advances by one (num_batches_tracked of the network's BatchNorm layers);
-        seed_add: advance of the engine's dropout seed word (hpfg_pack_weights_bump)."""
+        seed_add: advance of the engine's dropout seed word (hpfg_pack_weights_bump); zero_acc: the launch also zeroes the BatchNorm sum
+        accumulators of the forward it precedes."""
         host, dev = self._pack_table(self.math, with_dgrad)
         if counters is not None:
             assert counters.dtype == torch.int64 and counters.is_contiguous() and counters.device == self.dev
         self._run("pack_weights", lambda: L.check(self.lib.hpfg_pack_weights_bump(
             dev.data_ptr(), host, len(self.packed), L.ptr(counters) if counters is not None else None,
-            counters.numel() if counters is not None else 0, L.ptr(self.seed_dev), int(seed_add), self._stream()), "pack_weights"))
+            counters.numel() if counters is not None else 0, L.ptr(self.seed_dev), int(seed_add),
+            L.ptr(self.acc_all) if zero_acc else None, self.acc_all.numel() if zero_acc else 0, self._stream()), "pack_weights"))
+
+    def _finalize_bwd_all(self, lo: int, hi: int):
+        """hpfg_bn_acc_bwd_finalize for BatchNorm layers [lo, hi) of self.bn_layers (encoder layers come first): dgamma / dbeta (+ the k rows)
+        from the backward accumulators, which the launch zeroes again."""
+        if not self._accb_live or hi <= lo:
+            return
+        if self._accb_table is None:
+            descs = (L.BnAccBwdDesc * len(self.bn_layers))()
+            for d, s in zip(descs, self.bn_layers):
+                d.acc, d.gamma, d.bn = L.ptr(self.accb_of[s.name]), L.ptr(self.params[f"{s.bn}.weight"]), L.ptr(self.bn[s.name])
+                d.dgamma, d.dbeta = L.ptr(self.grads[f"{s.bn}.weight"]), L.ptr(self.grads[f"{s.bn}.bias"])
+                d.C, d.count, d.shards = s.cout, float(self.N * s.h * s.w), self.acc_shards[s.name]
+            self._accb_table = (descs, torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.dev))
+        host, dev = self._accb_table
+        sz = C.sizeof(L.BnAccBwdDesc)
+        sub = (L.BnAccBwdDesc * (hi - lo)).from_buffer(host, lo * sz)
+        self._run("bn_bfin_all", lambda: L.check(self.lib.hpfg_bn_acc_bwd_finalize(dev.data_ptr() + lo * sz, sub, hi - lo, self._stream()), "bn_acc_bwd_finalize"))
+
+    def _finalize_all(self, track: bool):
+        """hpfg_bn_acc_finalize: every BatchNorm table of this forward (+ running statistics) in one launch, from the sum accumulators."""
+        if track not in self._acc_tables:
+            descs = (L.BnAccDesc * len(self.bn_layers))()
+            for d, s in zip(descs, self.bn_layers):
+                d.acc, d.gamma, d.beta = L.ptr(self.acc_of[s.name]), L.ptr(self.params[f"{s.bn}.weight"]), L.ptr(self.params[f"{s.bn}.bias"])
+                d.running_mean = L.ptr(self.buffers[f"{s.bn}.running_mean"]) if track else None
+                d.running_var = L.ptr(self.buffers[f"{s.bn}.running_var"]) if track else None
+                d.bn, d.C, d.count, d.shards = L.ptr(self.bn[s.name]), s.cout, float(self.N * s.h * s.w), self.acc_shards[s.name]
+            self._acc_tables[track] = (descs, torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.dev))
+        host, dev = self._acc_tables[track]
+        self._run("bn_fin_all", lambda: L.check(self.lib.hpfg_bn_acc_finalize(dev.data_ptr(), host, len(self.bn_layers), BN_MOMENTUM, BN_EPS, self._stream()),
+                                                "bn_acc_finalize"))
 
     def _finalize_bn(self, s: ConvSpec, nblk: int, track: bool):
         if self._skip_fin and self._fin_done.get(s.name):      # timing experiment only (HPFG_SKIP_FINALIZE=1): stale tables
@@ -316,7 +385,9 @@ class UNetEngine:
         if seed_step is not None and seed_step != SEED_BUMP:
             self.seed_dev.fill_(int(seed_step) & 0x7FFFFFFF)
         counters, self.bump_counters = self.bump_counters, None
-        self.pack(with_dgrad=bool(train and needs_grad), counters=counters, seed_add=1 if seed_step == SEED_BUMP else 0)
+        self._acc_live = bool(train and self.bn_acc_on and self.math == L.MATH_BF16X3 and self.peer is None and not (self.world > 1 or self.force_sync)
+                              and not self._skip_fin)
+        self.pack(with_dgrad=bool(train and needs_grad), counters=counters, seed_add=1 if seed_step == SEED_BUMP else 0, zero_acc=self._acc_live)
         if self.marks is not None:
             self.marks.calib(self._stream())
         if train and self.peer is not None and (self.world > 1 or self.force_sync):
@@ -340,6 +411,8 @@ class UNetEngine:
         logits = self._fwd_begin(x, train, dropout, seed_step, needs_grad)
         for s in self.order:
             self._fwd_layer(s, logits, train, track_running)
+        if self._acc_live and self.bn_acc_mode == 1:
+            self._finalize_all(track_running)
         self.bwd_ready = bool(train and needs_grad)
         return logits
 
@@ -348,20 +421,31 @@ class UNetEngine:
         st = self._stream()
         out = logits if s.name == "decoder.out_conv" else self.z[s.name]
         want_stats = bool(s.bn) and train
+        acc = self._acc_live and want_stats      # the sums go into the layer accumulator; the consumers (and _finalize_all) take them from there
         nblk = self.lib.hpfg_conv_stat_blocks(self.N, s.h, s.w)
         if s.idx == 0:
             a0, _ = self.input_acts(s.name)
-            self._run("fwd:" + s.name, lambda: L.check(self.lib.hpfg_conv3x3_first_fwd(
-                C.byref(a0), L.ptr(self.params[f"{s.name}.weight"]), L.ptr(self.params[f"{s.name}.bias"]), L.ptr(out),
-                L.ptr(self.partials) if want_stats else None, self.N, s.h, s.w, s.cin, s.cout, st), "conv3x3_first_fwd"))
+            if acc:
+                self._run("fwd:" + s.name, lambda: L.check(self.lib.hpfg_conv3x3_first_fwd_acc(
+                    C.byref(a0), L.ptr(self.params[f"{s.name}.weight"]), L.ptr(self.params[f"{s.name}.bias"]), L.ptr(out),
+                    L.ptr(self.partials) if self.bn_acc_mode > 1 else None, L.ptr(self.acc_of[s.name]), self.acc_shards[s.name], self.N, s.h, s.w, s.cin,
+                    s.cout, st), "conv3x3_first_fwd_acc"))
+            else:
+                self._run("fwd:" + s.name, lambda: L.check(self.lib.hpfg_conv3x3_first_fwd(
+                    C.byref(a0), L.ptr(self.params[f"{s.name}.weight"]), L.ptr(self.params[f"{s.name}.bias"]), L.ptr(out),
+                    L.ptr(self.partials) if want_stats else None, self.N, s.h, s.w, s.cin, s.cout, st), "conv3x3_first_fwd"))
             nblk = self.lib.hpfg_conv_first_rows(self.N, s.h, s.w)
         else:
-            ca = self._conv_args(s, out, want_stats)
+            ca = self._conv_args(s, out, want_stats and (not acc or self.bn_acc_mode > 1))
+            if acc:
+                ca.stat_acc, ca.stat_shards = L.ptr(self.acc_of[s.name]), self.acc_shards[s.name]
             self._run("fwd:" + s.name, lambda: L.check(self.lib.hpfg_conv_fwd(C.byref(ca), st), f"conv_fwd[{s.name}]"))
-            if want_stats:
+            if want_stats and (not acc or self.bn_acc_mode > 1):
                 nblk = self.lib.hpfg_conv_stat_rows(C.byref(ca))
         if s.bn:
-            if train:
+            if train and acc and self.bn_acc_mode == 1:
+                pass
+            elif train:
                 self._finalize_bn(s, nblk, track_running)
             else:
                 L.check(self.lib.hpfg_bn_eval_table(L.ptr(self.params[f"{s.bn}.weight"]), L.ptr(self.params[f"{s.bn}.bias"]),
@@ -469,6 +553,17 @@ class UNetEngine:
         st = self._stream()
         g = self._act_dz(s.name, self.dA[s.name], self.dA_ps[s.name])
         fused = self._fused_rows.pop(s.name, None)
+        if self._accb_live:          # sums -> the layer's backward accumulator; no finalize launch: the consumers of `g` derive k1 .. k3
+            acc, sh = L.ptr(self.accb_of[s.name]), self.acc_shards[s.name]
+            if fused is not None:
+                assert pooled_grad is None      # (the dgrad epilogue that produced dA added them)
+            elif pooled_grad is not None:
+                self._run("bn_red:" + s.name, lambda: L.check(self.lib.hpfg_bn_bwd_reduce_pool_acc(
+                    C.byref(g), L.ptr(pooled_grad), s.cout, self.N, s.h // 2, s.w // 2, acc, sh, st), f"bn_bwd_reduce_pool_acc[{s.name}]"))
+            else:
+                self._run("bn_red:" + s.name, lambda: L.check(self.lib.hpfg_bn_bwd_reduce_acc(C.byref(g), self.N, s.h, s.w, acc, sh, st),
+                                                               f"bn_bwd_reduce_acc[{s.name}]"))
+            return g
         if fused is not None:          # the dgrad that produced dA already left the sums in self.partials
             assert pooled_grad is None
             nblk = fused
@@ -532,6 +627,8 @@ class UNetEngine:
             if rows * 2 * s.cin > self.partials.numel():
                 raise RuntimeError(f"fused_bwd[{s.name}]: {rows} rows of backward sums do not fit the partials workspace")
             ca.bwd_stats, ca.bwd_of, ca.stat_partials = 1, self._act_dz(stats_for, out, s.cin), L.ptr(self.partials)
+            if self._accb_live:
+                ca.stat_partials, ca.stat_acc, ca.stat_shards = None, L.ptr(self.accb_of[stats_for]), self.acc_shards[stats_for]
             self._fused_rows[stats_for] = rows
         self._last_fused[s.name] = fa      # (bench.py re-launches it alone)
         self._run("fused_bwd:" + s.name, lambda: L.check(self.lib.hpfg_fused_bwd(C.byref(fa), self._stream()), f"fused_bwd[{s.name}]"))
@@ -572,6 +669,8 @@ class UNetEngine:
             rows = self.lib.hpfg_conv_stat_rows(C.byref(ca))
             if rows <= 0 or rows * 2 * s.cin > self.partials.numel():
                 raise RuntimeError(f"dgrad[{s.name}]: {rows} rows of backward sums do not fit the partials workspace")
+            if self._accb_live:
+                ca.stat_partials, ca.stat_acc, ca.stat_shards = None, L.ptr(self.accb_of[stats_for]), self.acc_shards[stats_for]
             self._fused_rows[stats_for] = rows
         self._run("dgrad:" + s.name, lambda: L.check(self.lib.hpfg_conv_fwd(C.byref(ca), self._stream()), f"dgrad[{s.name}]"))
 
@@ -598,6 +697,12 @@ class UNetEngine:
         st = self._stream()
         N = self.N
         sp = self.specs
+        self._accb_live = bool(self.bn_acc_mode == 1 and self.math == L.MATH_BF16X3 and self.peer is None and not (self.world > 1 or self.force_sync)
+                               and not self._skip_fin and os.environ.get("HPFG_BN_ACC_BWD", "1") == "1")
+        if self._accb_live:
+            if self._accb_dirty:          # a backward pass that did not reach its finalize launch (an exception): start from zero
+                self.accb_all.zero_()
+            self._accb_dirty = True
         # ONE fork for the decoder's separate weight gradients (the channel-rich layers and the 1x1 convs; the thin layers' are fused with their
         # dgrad): they are queued while the decoder half back-propagates and run on the side stream beside the encoder half -- everything they
         # read (dA, z, the BatchNorm tables of their layers) stays in place until the next forward.  A fork / join per layer cost more than it
@@ -609,8 +714,15 @@ class UNetEngine:
         g = self._act_plain(dlogits, self.ncls, s.h, s.w)
         if self.marks is not None:
             self.marks.calib(st)          # (what a bracket costs by itself, measured where backward starts)
-        self._run("csum:" + s.name, lambda: L.check(self.lib.hpfg_channel_sum_partials(
-            L.ptr(dlogits), self.ncls, N * s.h * s.w, self.ncls, L.ptr(self.csum_part[s.name]), st), "channel_sum_partials"))
+
+        def csum(stream):          # out_conv's bias gradient: per-block channel sums of dlogits (rows of the final slab reduction)
+            self._run("csum:" + s.name, lambda: L.check(self.lib.hpfg_channel_sum_partials(
+                L.ptr(dlogits), self.ncls, N * s.h * s.w, self.ncls, L.ptr(self.csum_part[s.name]), stream), "channel_sum_partials"), stream)
+
+        if self._deferred is None:
+            csum(st)
+        # (else: nothing on the chain of backward reads those rows -- they go out with the decoder's queued weight gradients on the side stream,
+        # instead of 11 us at the head of the critical chain)
         self._wgrad_dgrad(s, g, self.dA["decoder.up4.conv.conv_conv.4"], "decoder.up4.conv.conv_conv.4")
         # ---- decoder blocks, last to first
         for k in range(4, 0, -1):
@@ -645,6 +757,8 @@ class UNetEngine:
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=self.dev)
                 self._side.wait_stream(main)
+                if hi == len(self._slab_host):          # the decoder batch: out_conv's bias sums ride along
+                    csum(self._side.cuda_stream)
                 for s_, g_ in self._deferred:
                     if os.environ.get("HPFG_SKIP_WGRAD", "0") != "1":       # timing experiment only (stale gradients): what the queued launches cost
                         self._wgrad(s_, g_, on_side=True)
@@ -658,6 +772,7 @@ class UNetEngine:
                 torch.cuda.current_stream(self.dev).wait_stream(self._side)
                 self._side_used = False
             self._slab_reduce(self._n_enc_desc, len(self._slab_host))
+            self._finalize_bwd_all(self._n_enc_bn, len(self.bn_layers))      # the decoder's dgamma / dbeta are part of bucket 0
             bucket_cb(0)
         # ---- encoder blocks, deepest first
         for lvl in range(4, -1, -1):
@@ -680,6 +795,9 @@ class UNetEngine:
         if self._side_used:
             torch.cuda.current_stream(self.dev).wait_stream(self._side)
             self._side_used = False
+        # every dZ consumer of the pass (the queued weight gradients on the side stream included) has been ordered before this point
+        self._finalize_bwd_all(0, self._n_enc_bn if bucket_cb is not None else len(self.bn_layers))
+        self._accb_dirty = False
         if bucket_cb is not None:
             self._slab_reduce(0, self._n_enc_desc)
             bucket_cb(1)

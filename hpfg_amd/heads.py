@@ -154,11 +154,18 @@ class _GatherRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, dp):
-        import torch.distributed as dist
         x = x.contiguous()
+        ctx.rank, ctx.n = dp.rank, x.shape[0]
+        if getattr(dp, "p2p_grads", False) and x.is_cuda and x.dtype == torch.float32 and dp.world_size * x.numel() <= dp.grad_floats:
+            # through the peer windows (kernels on this stream, capturable -- the HPFG step's global-batch mode then is ONE hipGraph): every rank
+            # puts its rows into its own slot of a zero buffer and the SUM all-reduce of csrc/peer.hip yields the concatenation (x + 0 is exact)
+            buf = torch.zeros((dp.world_size,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+            buf[dp.rank].copy_(x)
+            dp.peer_allreduce_sum(buf.view(-1))
+            return buf.view((dp.world_size * x.shape[0],) + tuple(x.shape[1:]))
+        import torch.distributed as dist
         parts = [torch.empty_like(x) for _ in range(dp.world_size)]
         dist.all_gather(parts, x, group=dp.group)
-        ctx.rank, ctx.n = dp.rank, x.shape[0]
         return torch.cat(parts, 0)
 
     @staticmethod

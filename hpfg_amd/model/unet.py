@@ -104,7 +104,12 @@ class _UNetFn(torch.autograd.Function):
             df = dfeat.permute(0, 2, 3, 1).contiguous()
         dp = net.dp
         cb = None
-        if dp is not None and dp.active and getattr(dp, "overlap", False) and getattr(eng, "direct", False):
+        # Peer-window buckets fork dp._side from the CURRENT stream.  With two trainable networks the second one back-propagates on a forked
+        # stream already, and an event wait between two non-origin streams of a capture makes hipStreamEndCapture fault (ROCm 7.2,
+        # tools/nested_fork_probe.py): only the single trainable network of a step (it runs on the origin stream) takes the bucketed path;
+        # the others are exchanged once after both backward passes have joined (_StepBase._reduce_grads).
+        nested = getattr(dp, "p2p_grads", False) and not getattr(net, "_alone", False)
+        if dp is not None and dp.active and getattr(dp, "overlap", False) and getattr(eng, "direct", False) and not nested:
             # data parallel: hand each finished slice of the flat gradient buffer to the all-reduce while backward continues
             cb = lambda i: dp.launch_bucket(net.grad_bucket(i))
             net._buckets_launched = True
@@ -263,12 +268,16 @@ class UNet(nn.Module):
         """Per-forward dropout seed word.  While a step is being captured into a hipGraph the forward advances the engine's device seed
         word itself (E.SEED_BUMP, inside its first launch), so every replay draws new masks."""
         if getattr(self, "_graph_seed_mode", False):
+            self._graph_fwds = getattr(self, "_graph_fwds", 0) + 1      # forwards of this network inside the step being captured
             return E.SEED_BUMP
         self._seed_counter += 1
         return self._seed_counter
 
     def bump_graph_seed(self):
-        """Nothing to do in front of a replay: a forward captured in graph-seed mode advances its engine's seed word itself (E.SEED_BUMP)."""
+        """In front of a replay: a forward captured in graph-seed mode advances its engine's seed word itself (E.SEED_BUMP); the host counter
+        follows, so that an EAGER step after replays (a ragged last batch in the driver loops) continues the seed sequence instead of
+        re-drawing masks the replays already used."""
+        self._seed_counter += getattr(self, "_fwds_per_replay", 0)
 
     def _acquire_engine(self, x: torch.Tensor) -> E.UNetEngine:
         if not x.is_cuda:

@@ -41,6 +41,16 @@ import torch.distributed as dist
 
 
 class DataParallelContext:
+    LOSS_SLOTS = 4          # fused-loss calls per step that can exchange their sums (HPFG / CPS / S4CVNet use two)
+
+    def next_loss_slot(self):
+        """(slot, epoch word) of the next seg_loss call of the current step."""
+        k = self._loss_call
+        if k >= self.LOSS_SLOTS:
+            raise RuntimeError(f"more than {self.LOSS_SLOTS} exchanged losses in one step (StepScalars.push() begins a step)")
+        self._loss_call = k + 1
+        return self.loss_slot + k, self.loss_epoch[k:k + 1]
+
     def __init__(self, group=None, device: Optional[torch.device] = None):
         self.group = group
         self.world_size = dist.get_world_size(group)
@@ -60,8 +70,9 @@ class DataParallelContext:
         self.peer_cap = 512          # payload values per rank in a slot: [2][C <= 256]
         self.peer_slots = 0
         self.peer_err = None         # device int32 word: set by a kernel whose poll for a peer's value expired
-        self.loss_slot = -1
-        self.loss_epoch = None
+        self.loss_slot = -1          # first of LOSS_SLOTS mailbox slots: one per seg_loss call of a step (call k uses slot k and epoch word k, so
+        self.loss_epoch = None       # two losses of one step never share a slot, whichever streams they are issued on)
+        self._loss_call = 0          # index of the next seg_loss call inside the current step (reset by StepScalars.push / GraphedStep)
         # peer gradient exchange (enable_peer_grads): the flat gradient crosses the ranks through IPC windows, inside the captured step
         self.p2p_grads = False
         self._gwin = None            # this rank's window, _gpeers[r] = rank r's window as mapped here
@@ -143,7 +154,7 @@ class DataParallelContext:
         self.peer_slots = n_slots
         self._slot_bytes = lib.hpfg_peer_slot_bytes(self.world_size, self.peer_cap)
         self.peer_err = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self.loss_epoch = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.loss_epoch = torch.zeros(self.LOSS_SLOTS, dtype=torch.int32, device=self.device)
         self._peers = [None] * self.world_size
         if self.world_size > 1:
             torch.cuda.set_device(self.device)
@@ -163,7 +174,7 @@ class DataParallelContext:
                 self._peers[r] = q.value
             dist.barrier(group=self.group)          # every mailbox is mapped everywhere before any kernel stores into one
         self.p2p = True
-        self.loss_slot = self.alloc_slots(1)
+        self.loss_slot = self.alloc_slots(self.LOSS_SLOTS)
 
     def enable_peer_grads(self, max_floats: int) -> bool:
         """Allocate and map the gradient windows (buffers of up to `max_floats` fp32 values), run one all-reduce through them and return

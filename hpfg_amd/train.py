@@ -52,8 +52,11 @@ class StepScalars:
         self.events = [None] * self.SLOTS
         self.slot = 0
         self.dev = torch.zeros(32, dtype=torch.float32, device=dev)
+        self.on_push = None          # called at the beginning of every step (data parallel: the per-step loss-slot counter restarts)
 
     def push(self):
+        if self.on_push is not None:
+            self.on_push()
         k = self.slot
         self.slot = (k + 1) % self.SLOTS
         if self.events[k] is not None:
@@ -109,6 +112,8 @@ class _StepBase:
     def __init__(self, dev, dp=None):
         self.dev, self.dp = dev, dp
         self.sc = StepScalars(dev)
+        if dp is not None:
+            self.sc.on_push = lambda: setattr(dp, "_loss_call", 0)
         # HPFG_STEP_MARKS=1: timestamp kernels at phase boundaries of the step (tools/stream_timeline.py); off by default
         self.marks = torch.zeros(32, dtype=torch.int64, device=dev) if os.environ.get("HPFG_STEP_MARKS", "0") == "1" else None
         # the no-grad teacher forward is independent of the student forward: run it on a second HIP stream so that the two
@@ -161,6 +166,7 @@ class _StepBase:
         joined: segmentation fault in capture_end; every fork / join against the origin stream itself is fine).  So inside a capture every
         side stream forks from and joins into the stream the capture began on, and nothing else."""
         model.dp = self.dp
+        model._alone = bool(alone)          # (UNet's backward node: the peer-window gradient buckets fork a side stream only from the step's origin stream)
         if alone:
             model.defer_wgrad = True
         if any(p.requires_grad for p in model.parameters()):
@@ -195,9 +201,15 @@ class _StepBase:
                     self.dp.join_buckets()
                 elif hasattr(m, "flat_grads") and not hasattr(m, "_hpfg_generic_flat"):
                     red(m.flat_grads)
-                else:                      # a model whose gradients live in per-parameter tensors (SegFormer): one flattened exchange of the
-                    gs = [p.grad for p in m.parameters() if p.grad is not None]      # SUM; the 1/world of the per-rank-BatchNorm mode is the
-                    flat = torch.cat([g.reshape(-1) for g in gs])                    # optimizer's grad_scale (FusedSGD / FusedAdamW), as for the U-Nets
+                elif getattr(m, "_hpfg_flat_optimizer", None) is not None:
+                    # SegFormer: autograd leaves per-parameter gradients; FusedAdamW packs them into the model's flat gradient buffer with ONE
+                    # concat (what its step() does anyway) -- the exchange reduces that buffer in place and the step consumes it: no copy back
+                    opt = m._hpfg_flat_optimizer
+                    red(opt.gather_flat_grads())
+                    opt._grads_gathered = True
+                else:                      # any other module: one flattened exchange of the SUM, copied back (the 1/world of the per-rank-BatchNorm
+                    gs = [p.grad for p in m.parameters() if p.grad is not None]      # mode is the optimizer's grad_scale)
+                    flat = torch.cat([g.reshape(-1) for g in gs])
                     red(flat)
                     o = 0
                     for g in gs:
@@ -777,7 +789,9 @@ class GraphedStep:
         before_capture: optional callable run between the eager warm-up steps and the capture (bench.py resets its time-stamp logs there)."""
         self.s = step_obj
         dp0 = getattr(step_obj, "dp", None)
-        host_gather = isinstance(step_obj, HPFGStep)      # (its Dense_Loss all-gathers the neck features with a host-launched collective)
+        # (HPFG's Dense_Loss gathers the neck features of all ranks: through the peer windows when they are enabled -- kernels, capturable --
+        # otherwise with a host-launched collective)
+        host_gather = isinstance(step_obj, HPFGStep) and not getattr(dp0, "p2p_grads", False)
         if dp0 is not None and getattr(dp0, "sync_bn", True) and (dp0.world_size > 1 or dp0.force_sync) and (not getattr(dp0, "p2p", False) or host_gather):
             # all-reduced BatchNorm statistics = a collective between the kernels of every layer: those never sit inside a captured region
             # (RCCL's watchdog thread polls its events while a capture is open; losing that race aborted the process)
@@ -800,6 +814,8 @@ class GraphedStep:
         torch.cuda.synchronize()
         if before_capture is not None:
             before_capture()
+        if dp0 is not None:
+            dp0._loss_call = 0          # the capture traces one step from its beginning
         self._freeze_seed_updates(True)
         # thread_local: another thread's HIP calls (the RCCL watchdog polling its events) must not invalidate this capture
         dp = getattr(step_obj, "dp", None)
@@ -870,6 +886,10 @@ class GraphedStep:
     def _freeze_seed_updates(self, capturing: bool):
         for m in self._models():
             m._graph_seed_mode = capturing
+            if capturing:
+                m._graph_fwds = 0
+            else:
+                m._fwds_per_replay = getattr(m, "_graph_fwds", 0)      # (UNet.bump_graph_seed keeps the host's seed counter in step with the replays)
 
     def step(self, inputs, cur_itrs, **kw):
         for dst, src in zip(self.static, inputs):
@@ -915,7 +935,14 @@ class CTCTStep(CPSStep):
 # Driver loops with the reference's names / signatures: same iteration law (two labelled iterators restarted on StopIteration,
 # return once cur_itrs > total_itrs), evaluation every ``step_size`` iterations through hpfg_amd.val.test_acdc, and best-Dice
 # checkpoints in the reference's dict format {"model", "optimizer", "lr_scheduler", "cur_itrs", "best_dice"}.
-# TensorBoard / tqdm output is not produced (out of scope); the per-iteration loss stays on the device and is returned.
+#
+# Every loop runs the path bench.py times: iteration 1 is an eager step (it allocates the engines' workspaces and IS iteration 1),
+# iteration 2 captures the step into ONE hipGraph on static input buffers, every later iteration is one copy per input (host -> the static
+# buffer) + one replay (``_LoopRunner``; ``args.hipgraph = False`` or HPFG_LOOP_GRAPH=0 keeps eager launches).  The reference's
+# per-iteration ``writer.add_scalar`` calls (main.py:216-222, 2017_03...py:111-113, sup_ACDC.py:96-97, 2021_06...py:124-128,
+# 2021_12...py:158-161) are served by ``ScalarLog``: the loss vectors stay on the device in a ring and reach ``args.writer`` (if there is
+# one) every ``args.log_every`` iterations with ONE device-to-host copy -- the scalar NAMES and values are the reference's, the
+# ``loss.item()`` synchronisation per iteration is not.  tqdm output is not produced.
 # ------------------------------------------------------------------------------------------------------------------------
 def _cycle(loader):
     it = iter(loader)
@@ -925,6 +952,101 @@ def _cycle(loader):
         except StopIteration:
             it = iter(loader)
             yield next(it)
+
+
+class ScalarLog:
+    """Per-iteration scalars without a host synchronisation per iteration.  ``add(itr, vecs, host)`` parks the device vectors ``vecs`` (the
+    fused-loss outputs [total, ce0, dice0, ce1, dice1, mse, 0, 0] of each network, ...) in row ``k`` of a device ring with one small copy
+    each and remembers the host-side scalars (learning rates, consistency weights) of that iteration; every ``every`` iterations -- and at
+    ``flush()`` -- ONE device-to-host copy brings the rows back and ``emit(row, host) -> {name: value}`` names them for
+    ``writer.add_scalar(name, value, itr)``.  ``history`` keeps (itr, {name: value}) of everything flushed; ``losses()`` = the per-iteration
+    total loss (row element 0 unless ``emit`` names a "<prefix>/loss")."""
+
+    def __init__(self, dev, width: int, emit, writer=None, every: int = 50):
+        self.dev, self.width, self.emit, self.writer = dev, int(width), emit, writer
+        self.every = max(1, int(every))
+        self.buf = torch.zeros(self.every, self.width, dtype=torch.float32, device=dev)
+        self.pending, self.history = [], []
+
+    def add(self, itr: int, vecs, host: Dict[str, float]):
+        k, o = len(self.pending), 0
+        for v in vecs:
+            v = v.detach().reshape(-1)
+            self.buf[k, o:o + v.numel()].copy_(v, non_blocking=True)
+            o += v.numel()
+        assert o <= self.width
+        self.pending.append((int(itr), dict(host)))
+        if len(self.pending) == self.every:
+            self.flush()
+
+    def flush(self):
+        if not self.pending:
+            return
+        rows = self.buf[:len(self.pending)].cpu()          # the one synchronisation per `every` iterations
+        for (itr, host), row in zip(self.pending, rows):
+            named = self.emit([float(x) for x in row], host)
+            self.history.append((itr, named))
+            if self.writer is not None:
+                for name, val in named.items():
+                    self.writer.add_scalar(name, val, itr)
+        self.pending = []
+
+    def losses(self) -> torch.Tensor:
+        self.flush()
+        vals = [next((v for n, v in named.items() if n.endswith("/loss")), float("nan")) for _, named in self.history]
+        return torch.tensor(vals, dtype=torch.float32, device=self.dev)
+
+
+class _LoopRunner:
+    """One training iteration of a driver loop: eager for iteration 1, captured at iteration 2, replayed afterwards (see the section header)."""
+
+    def __init__(self, st, args, slog: ScalarLog, vec_keys, host_fn):
+        self.st, self.args, self.slog, self.vec_keys, self.host_fn = st, args, slog, vec_keys, host_fn
+        self.graph_ok = bool(getattr(args, "hipgraph", True)) and os.environ.get("HPFG_LOOP_GRAPH", "1") == "1"
+        self.runner, self.n = None, 0
+        self.dev = torch.device(args.device)
+
+    def _to_dev(self, t):
+        t = t.to(self.dev, non_blocking=True)
+        return t.float() if t.is_floating_point() and t.dtype != torch.float32 else t
+
+    def __call__(self, inputs, cur_itrs: int, **kw):
+        """inputs: the step's tensor arguments as the loaders hand them over (host or device); images are converted to fp32 as the
+        reference's ``.to(args.device).float()`` does."""
+        self.n += 1
+        r = None
+        if self.graph_ok and self.n >= 2:
+            if self.runner is None:
+                dev_in = [self._to_dev(t) for t in inputs]
+                try:
+                    self.runner = GraphedStep(self.st, dev_in, warmup=0)          # captures; executes nothing
+                except RuntimeError as e:          # a step that cannot be captured (collectives between its kernels): stay eager
+                    logger = getattr(self.args, "logger", None)
+                    if logger is not None:
+                        logger.info(f"hipGraph capture unavailable ({e}); running eager")
+                    self.graph_ok = False
+            if self.runner is not None and all(tuple(a.shape) == tuple(b.shape) for a, b in zip(inputs, self.runner.static)):
+                r = self.runner.step(list(inputs), cur_itrs, **kw)          # copies (and converts) each input into its static buffer, replays
+        if r is None:          # the eager form of the same iteration (what every step object's .step() does)
+            self.st.host_scalars(cur_itrs, **kw)
+            self.st.sc.push()
+            r = self.st.device_step(*[self._to_dev(t) for t in inputs])
+            self.st.after()
+        self.slog.add(cur_itrs, [r[k] for k in self.vec_keys], self.host_fn())
+        return r
+
+
+def _writer(args):
+    return getattr(args, "writer", None)
+
+
+def _log_every(args):
+    return int(getattr(args, "log_every", 50) or 50)
+
+
+def _sup_of(row, o=0):
+    """0.5 * (CE + Dice) on the labelled images (the supervised term of every driver: coefficients 0.5 / 0.5) of the loss vector at offset o."""
+    return 0.5 * (row[o + 1] + row[o + 2])
 
 
 class _Best:
@@ -960,23 +1082,35 @@ def _due(cur_itrs, args, test_loader):
     return test_loader is not None and cur_itrs % args.step_size == 0
 
 
+def _check_peers(args, cur_itrs, final=False):
+    """Data parallel with the peer exchanges: a kernel whose poll for a peer's value expired carried on with partial sums (it must not hang
+    the GPU) and set a device word -- stop training on it at the evaluation cadence and at the end, not silently update weights from it."""
+    dp = getattr(args, "dp", None)
+    if dp is not None and (final or cur_itrs % args.step_size == 0):
+        dp.check_peer_errors()
+
+
 def Supervise(model, train_loader, test_loader, args):
     """sup_ACDC.py:59-125."""
     st = SupervisedStep(model, args, getattr(args, "dp", None))
     best = _Best(args, "model", path_fmt="model_{:.4f}.pth")
     model.train()
-    cur_itrs, log = 0, []
+    slog = ScalarLog(torch.device(args.device), 8, lambda row, h: {"supervise/loss": row[0], "supervise/lr": h["lr"]}, _writer(args), _log_every(args))
+    run = _LoopRunner(st, args, slog, ["parts"], lambda: {"lr": st._lr(st.optimizer)})
+    cur_itrs = 0
     max_epoch = args.total_itrs // len(train_loader) + 1
     for epoch in range(max_epoch):
         for img, label_true in train_loader:
             cur_itrs += 1
-            r = st.step(img.to(args.device).float(), label_true.to(args.device), cur_itrs)
-            log.append(r["loss"])
+            run([img, label_true], cur_itrs)
             if _due(cur_itrs, args, test_loader):
                 best(model, st.optimizer, st.lr_scheduler, test_loader, cur_itrs)
+            _check_peers(args, cur_itrs)
             if cur_itrs > args.total_itrs:
-                return torch.stack(log)
-    return torch.stack(log)
+                _check_peers(args, cur_itrs, final=True)
+                return slog.losses()
+    _check_peers(args, cur_itrs, final=True)
+    return slog.losses()
 
 
 def Mean_Teacher(model, ema_model, label_loader, unlabel_loader, test_loader, args):
@@ -985,21 +1119,27 @@ def Mean_Teacher(model, ema_model, label_loader, unlabel_loader, test_loader, ar
     best, best_ema = _Best(args, "model", "model_save_path"), _Best(args, "ema", "ema_model_save_path")
     model.train()
     ema_model.train()          # the teacher stays in train mode (2017_03...py:70)
-    cur_itrs, log = 0, []
+    w = [0.0]
+    emit = lambda row, h: {"mean_teacher/loss": row[0], "mean_teacher/lr": h["lr"], "mean_teacher/consistency_weight": h["w"]}
+    slog = ScalarLog(torch.device(args.device), 8, emit, _writer(args), _log_every(args))
+    run = _LoopRunner(st, args, slog, ["parts"], lambda: {"lr": st._lr(st.optimizer), "w": float(st.sc.host[S_COEF_A + 4])})
+    cur_itrs = 0
     labels = _cycle(label_loader)
     max_epoch = args.total_itrs // len(unlabel_loader) + 1
     for epoch in range(max_epoch):
         for unlabel_img, _ in unlabel_loader:
             cur_itrs += 1
             label_img, target_label = next(labels)
-            r = st.step(label_img.to(args.device).float(), target_label.to(args.device), unlabel_img.to(args.device).float(), cur_itrs)
-            log.append(r["loss"])
+            run([label_img, target_label, unlabel_img], cur_itrs)
             if _due(cur_itrs, args, test_loader):
                 best(model, st.optimizer, st.lr_scheduler, test_loader, cur_itrs, "model")
                 best_ema(ema_model, st.optimizer, st.lr_scheduler, test_loader, cur_itrs, "ema")
+            _check_peers(args, cur_itrs)
             if cur_itrs > args.total_itrs:
-                return torch.stack(log)
-    return torch.stack(log)
+                _check_peers(args, cur_itrs, final=True)
+                return slog.losses()
+    _check_peers(args, cur_itrs, final=True)
+    return slog.losses()
 
 
 def CPS(model1, model2, label_loader, unlabel_loader, test_loader, args, step_cls=None):
@@ -1008,21 +1148,37 @@ def CPS(model1, model2, label_loader, unlabel_loader, test_loader, args, step_cl
     best1, best2 = _Best(args, "model1", "model1_save_path"), _Best(args, "model2", "model2_save_path")
     model1.train()
     model2.train()
-    cur_itrs, log = 0, []
+    ctct = isinstance(st, CTCTStep)
+
+    def emit(row, h):          # rows: [parts1 (8) | parts2 (8)]
+        loss = row[0] + row[8]
+        if ctct:               # 2021_12...py:158-161
+            return {"mynet/loss": loss, "mynet/lr1": h["lr1"], "mynet/lr2": h["lr2"], "mynet/consistency_weight": h["w"]}
+        sup = _sup_of(row, 0) + _sup_of(row, 8)          # 2021_06...py:124-128
+        return {"mynet/loss": loss, "mynet/lr": h["lr1"], "mynet/consistency_weight": h["w"], "mynet/loss_semi": loss - sup, "mynet/loss_sup": sup}
+
+    slog = ScalarLog(torch.device(args.device), 16, emit, _writer(args), _log_every(args))
+    wpos = S_COEF_A + 3
+    run = _LoopRunner(st, args, slog, ["parts1", "parts2"],
+                      lambda: {"lr1": st._lr(st.optimizer1), "lr2": st._lr(st.optimizer2),
+                               "w": float(st.sc.host[wpos]) * (1.0 if ctct else 2.0)})          # CPS parks 0.5 * w there (0.5 * w * (CE + Dice))
+    cur_itrs = 0
     labels = _cycle(label_loader)
     max_epoch = args.total_itrs // len(unlabel_loader) + 1
     for epoch in range(max_epoch):
         for unlabel_img, _ in unlabel_loader:
             cur_itrs += 1
             label_img, target_label = next(labels)
-            r = st.step(label_img.to(args.device).float(), target_label.to(args.device), unlabel_img.to(args.device).float(), cur_itrs)
-            log.append(r["loss"])
+            run([label_img, target_label, unlabel_img], cur_itrs)
             if _due(cur_itrs, args, test_loader):
                 best1(model1, st.optimizer1, st.lr_scheduler1, test_loader, cur_itrs, "model1")
                 best2(model2, st.optimizer2, st.lr_scheduler2, test_loader, cur_itrs, "model2")
+            _check_peers(args, cur_itrs)
             if cur_itrs > args.total_itrs:
-                return torch.stack(log)
-    return torch.stack(log)
+                _check_peers(args, cur_itrs, final=True)
+                return slog.losses()
+    _check_peers(args, cur_itrs, final=True)
+    return slog.losses()
 
 
 def CTCT(model1, model2, label_loader, unlabel_loader, test_loader, args):
@@ -1037,22 +1193,34 @@ def S4CVnet(model1, model2, ema_model, label_loader, unlabel_loader, test_loader
     best_ema = _Best(args, "ema", "ema_model_save_path")
     model1.train()
     model2.train()
-    cur_itrs, log = 0, []
+
+    def emit(row, h):          # 2022_08_CVPR_S4CVNet_ACDC.py:174-180
+        loss, sup = row[0] + row[8], _sup_of(row, 0) + _sup_of(row, 8)
+        return {"S4CVnet/loss": loss, "S4CVnet/loss_semi": loss - sup, "S4CVnet/loss_sup": sup, "S4CVnet/lr1": h["lr1"], "S4CVnet/lr2": h["lr2"],
+                "S4CVnet/consistency_weight_cps": h["w"], "S4CVnet/consistency_weight_mt": h["w"]}
+
+    slog = ScalarLog(torch.device(args.device), 16, emit, _writer(args), _log_every(args))
+    run = _LoopRunner(st, args, slog, ["parts1", "parts2"],
+                      lambda: {"lr1": st._lr(st.optimizer1), "lr2": st._lr(st.optimizer2), "w": float(st.sc.host[S_COEF_A + 3]) / 7.0})
+    cur_itrs = 0
     labels = _cycle(label_loader)
     max_epoch = args.total_itrs // len(unlabel_loader) + 1
     for epoch in range(max_epoch):
         for img_unlabel, _ in unlabel_loader:
             cur_itrs += 1
             img_labeled, target_label = next(labels)
-            r = st.step(img_labeled.to(args.device).float(), target_label.to(args.device), img_unlabel.to(args.device).float(), cur_itrs)
-            log.append(r["loss"])
+            noise = st.draw_noise(img_unlabel.to(args.device).float())      # an INPUT of the (captured) step: drawn here, in the reference's order (:109)
+            run([img_labeled, target_label, img_unlabel, noise], cur_itrs)
             if _due(cur_itrs, args, test_loader):
                 best1(model1, st.optimizer1, st.lr_scheduler1, test_loader, cur_itrs, "model1")
                 best2(model2, st.optimizer2, st.lr_scheduler2, test_loader, cur_itrs, "model2")
                 best_ema(ema_model, st.optimizer2, st.lr_scheduler2, test_loader, cur_itrs, "ema")
+            _check_peers(args, cur_itrs)
             if cur_itrs > args.total_itrs:
-                return torch.stack(log)
-    return torch.stack(log)
+                _check_peers(args, cur_itrs, final=True)
+                return slog.losses()
+    _check_peers(args, cur_itrs, final=True)
+    return slog.losses()
 
 
 def HPFG(model1, model2, ema_model, label_loader, unlabel_loader, test_loader, args):
@@ -1062,7 +1230,17 @@ def HPFG(model1, model2, ema_model, label_loader, unlabel_loader, test_loader, a
     best_ema = _Best(args, "ema", "ema_model_save_path")
     model1.train()
     model2.train()
-    cur_itrs, log = 0, []
+
+    def emit(row, h):          # rows: [parts1 (8) | parts2 (8) | contrast]; main.py:216-222
+        loss = row[0] + row[8] + h["w"] * row[16]
+        sup = _sup_of(row, 0) + _sup_of(row, 8)
+        return {"HPFG/loss": loss, "HPFG/loss_semi": loss - sup, "HPFG/loss_sup": sup, "HPFG/lr1": h["lr1"], "HPFG/lr2": h["lr2"],
+                "HPFG/consistency_weight_cps": h["w"], "HPFG/consistency_weight_mt": h["w"]}
+
+    slog = ScalarLog(torch.device(args.device), 17, emit, _writer(args), _log_every(args))
+    run = _LoopRunner(st, args, slog, ["parts1", "parts2", "contrast"],
+                      lambda: {"lr1": st._lr(st.optimizer1), "lr2": st._lr(st.optimizer2), "w": float(st._w)})
+    cur_itrs = 0
     it_a, it_b = _cycle(label_loader), _cycle(label_loader)      # two independent labelled iterators (main.py:119-120)
     max_epoch = args.total_itrs // len(unlabel_loader) + 1
     for epoch in range(max_epoch):
@@ -1073,14 +1251,14 @@ def HPFG(model1, model2, ema_model, label_loader, unlabel_loader, test_loader, a
             nl, nu = label_img.shape[0], img_unlabel.shape[0]
             rep = nu // nl
             cm = st.make_cutmix_mask(nu, (args.train_crop_size[0], args.train_crop_size[1]), device=torch.device(args.device))
-            r = st.step(label_img.to(args.device).float(), target_label.to(args.device),
-                        label_img1.repeat(rep, 1, 1, 1).to(args.device).float(), target_label1.repeat(rep, 1, 1).to(args.device),
-                        img_unlabel.to(args.device).float(), cm.to(args.device), cur_itrs)
-            log.append(r["loss"])
+            run([label_img, target_label, label_img1.repeat(rep, 1, 1, 1), target_label1.repeat(rep, 1, 1), img_unlabel, cm], cur_itrs)
             if _due(cur_itrs, args, test_loader):
                 best1(model1, st.optimizer1, st.lr_scheduler1, test_loader, cur_itrs, "model1")
                 best2(model2, st.optimizer2, st.lr_scheduler2, test_loader, cur_itrs, "model2")
                 best_ema(ema_model, st.optimizer2, st.lr_scheduler2, test_loader, cur_itrs, "model1")      # main.py:259-272 saves optimizer2 with it
+            _check_peers(args, cur_itrs)
             if cur_itrs > args.total_itrs:
-                return torch.stack(log)
-    return torch.stack(log)
+                _check_peers(args, cur_itrs, final=True)
+                return slog.losses()
+    _check_peers(args, cur_itrs, final=True)
+    return slog.losses()

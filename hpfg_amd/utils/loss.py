@@ -68,8 +68,9 @@ class _SegLossFn(torch.autograd.Function):
             a.cons_mask = L.ptr(cm)
         st = torch.cuda.current_stream(dev).cuda_stream
         if dp is not None and getattr(dp, "p2p", False) and (dp.world_size > 1 or dp.force_sync):
-            dp.bump(dp.loss_epoch, st)          # the ranks' loss sums are added by the reduction kernel itself (peer mailboxes)
-            px = dp.peer_desc(dp.loss_slot, dp.loss_epoch)
+            slot, epoch = dp.next_loss_slot()      # (a slot and an epoch word per loss call of the step: no two calls share one)
+            dp.bump(epoch, st)          # the ranks' loss sums are added by the reduction kernel itself (peer mailboxes)
+            px = dp.peer_desc(slot, epoch)
             L.check(lib.hpfg_seg_loss_partials_x(C.byref(a), C.byref(px), st), "seg_loss_partials_x")
         else:
             L.check(lib.hpfg_seg_loss_partials(C.byref(a), st), "seg_loss_partials")

@@ -104,6 +104,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._lr_host = torch.zeros(1, dtype=torch.float32).pin_memory()
         self._lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.grad_scale = 1.0
+        self._grads_gathered = False      # set by the data-parallel exchange, which packs (and reduces) the flat gradient buffer itself
+        model._hpfg_flat_optimizer = self
 
     def zero_grad(self, set_to_none: bool = True):
         # grads are dropped, not zeroed: autograd then ASSIGNS each parameter's gradient (accumulating into kept views would cost one
@@ -124,7 +126,9 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, push_lr: bool = True):
         g = self.param_groups[0]
-        flat, grad = self.model.flat_params, self.gather_flat_grads()
+        flat = self.model.flat_params
+        grad = self.model.flat_grads if self._grads_gathered else self.gather_flat_grads()
+        self._grads_gathered = False
         if push_lr:
             self.push_lr()
         st = torch.cuda.current_stream(flat.device).cuda_stream

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 127
+#define HPFG_VERSION 129
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -57,6 +57,18 @@ typedef struct HpfgAct {
   const uint8_t* drop_mask; /* optional explicit keep-mask (bytes, NHWC element order) used instead of the RNG: lets parity
                                tests replay the masks torch drew in the reference run */
   const uint32_t* seed_dev; /* optional device word added to drop_seed at run time (lets a captured hipGraph draw new masks per replay) */
+  /* BatchNorm statistics straight from the producer's sum accumulators (round 4; BNACT / BNACT_POOL sources of the bf16x3 forward kernels):
+     with bn_acc != NULL the consumer derives scale / shift of its input channels itself in its prologue -- mean = S1 / count,
+     var = S2 / count - mean^2, rstd = 1 / sqrt(var + eps), scale = gamma * rstd, shift = beta - mean * scale (fp64, the arithmetic of
+     hpfg_bn_fwd_finalize) -- instead of reading the rows of `bn`, so that no finalize launch sits between a conv and its consumer
+     (unet.py:18-24: conv -> BatchNorm -> LeakyReLU).  `bn` is then written once per forward by hpfg_bn_acc_finalize for the backward kernels. */
+  const long long* bn_acc;  /* accumulators of the producing layer, see HpfgConvArgs.stat_acc; NULL = read the table rows */
+  const float* bn_gamma;    /* BatchNorm weight / bias of the producing layer ([bn_stride]) */
+  const float* bn_beta;
+  float bn_count;           /* N * H * W of the producing layer (elements per channel) */
+  float bn_eps;
+  int32_t bn_shards;        /* shards of bn_acc (the producer's stat_shards) */
+  int32_t reserved1;
 } HpfgAct;
 
 typedef struct HpfgConvArgs {
@@ -80,7 +92,18 @@ typedef struct HpfgConvArgs {
                            concat gradient, unet.py:57 -- into buffers of their own, so that neither is read through a half-used pixel stride */
   int32_t out_split;    /* multiple of 16; 0 = everything to `out` */
   int32_t out2_pstride;
+  long long* stat_acc;  /* optional (bf16x3 kernels), instead of stat_partials: the per-channel sums are ADDED to this layer accumulator,
+                           long long [HPFG_ACC_SHARDS][2 (sum z | sum z^2)][CoutPad][2 (limb)], by integer atomics.  A partial sum t is split
+                           exactly as t = hi + lo * 2^-52 (hi = rint(t), lo = (t - hi) * 2^52): integer addition is associative, so the
+                           totals are bit-reproducible whatever order the workgroups finish in.  Shard = workgroup id % stat_shards: more
+                           shards = less same-address contention among the producer's workgroups (1 shard of a 768-workgroup launch: +40 us),
+                           fewer = less to read in every consumer workgroup's prologue (32 bytes per channel and shard).
+                           The accumulator must be zero when the launch starts (hpfg_pack_weights_bump zeroes a region). */
+  int32_t stat_shards;  /* power of two, 1 .. HPFG_ACC_MAX_SHARDS */
+  int32_t reserved2;
 } HpfgConvArgs;
+#define HPFG_ACC_MAX_SHARDS 8
+#define HPFG_ACC_WORDS(C, shards) ((shards) * 2 * 2 * (C))   /* long long words of one layer accumulator */
 
 typedef struct HpfgWgradArgs {
   HpfgAct a0, a1;       /* conv input (as in forward) */
@@ -123,12 +146,20 @@ typedef struct HpfgPackDesc {   /* one conv layer for hpfg_pack_weights (device 
 
 int hpfg_version(void);
 const char* hpfg_last_error(void);
+/* Kernel-form switches for tests and A/B tools (the launch paths read no environment variables): returns the previous value (>= 0) or < 0.
+ * HPFG_OPT_CONV_THIN: 0 = the thin forward layers on the chunked conv kernel instead of the whole-tile kernel;
+ * HPFG_OPT_FIRST_MFMA: 0 = the 1- / 3-channel first layer as a VALU loop instead of the MFMA form (bit-identical outputs). */
+enum { HPFG_OPT_CONV_THIN = 0, HPFG_OPT_FIRST_MFMA = 1, HPFG_OPT_COUNT = 2 };
+int hpfg_set_option(int which, int value);
 
 /* ---- forward ------------------------------------------------------------------------------------------- */
 /* nn.Conv2d(Cin<=4 -> 16, k3, p1) on the network input + BN partial sums (encoder.in_conv, unet.py:18-19,72). */
 int hpfg_conv3x3_first_fwd(const HpfgAct* x, const float* w_oihw, const float* bias, float* out, float* stat_partials,
                            int N, int H, int W, int Cin, int Cout, void* stream);
 int hpfg_conv_first_rows(int N, int H, int W);            /* rows of stat_partials hpfg_conv3x3_first_fwd writes (persistent grid) */
+/* the same layer with its BatchNorm sums added to a layer accumulator (HpfgConvArgs.stat_acc / stat_shards) as well as / instead of rows of partial sums */
+int hpfg_conv3x3_first_fwd_acc(const HpfgAct* x, const float* w_oihw, const float* bias, float* out, float* stat_partials, long long* stat_acc,
+                               int stat_shards, int N, int H, int W, int Cin, int Cout, void* stream);
 /* nn.Conv2d k3/k1 (+ fused producer BN/LeakyReLU/Dropout/MaxPool/Upsample/cat on load) + BN partial sums.
  * Also serves dgrad: a0 = dZ (mode DZ/PLAIN), wpk = wpk_dgrad. */
 int hpfg_conv_fwd(const HpfgConvArgs* args, void* stream);
@@ -138,6 +169,41 @@ int hpfg_conv_stat_rows(const HpfgConvArgs* args);         /* rows hpfg_conv_fwd
  * (unet.py:19,23).  Either partials (float [nblk][2][C]) or pre-reduced sums (double [2][C], e.g. after an all-reduce). */
 int hpfg_bn_fwd_finalize(const float* partials, int nblk, const double* sums, double count, const float* gamma, const float* beta,
                          float* running_mean, float* running_var, float momentum, float eps, float* bn, int C, void* stream);
+/* The same for EVERY BatchNorm layer of a forward pass in one launch, from the layers' sum accumulators (HpfgConvArgs.stat_acc): the forward
+ * consumers derive scale / shift themselves (HpfgAct.bn_acc), so this call follows the LAST conv of the forward and writes the table rows
+ * the backward kernels read, plus running_mean / running_var (momentum, unbiased variance).  Device array of descriptors + host copy. */
+typedef struct HpfgBnAccDesc {
+  const long long* acc;     /* [HPFG_ACC_WORDS(C, shards)] */
+  const float* gamma;
+  const float* beta;
+  float* running_mean;      /* both or neither */
+  float* running_var;
+  float* bn;                /* table [HPFG_BN_ROWS][C]: rows mean, rstd, scale, shift are written */
+  int32_t C;
+  float count;              /* N * H * W */
+  int32_t shards;
+  int32_t reserved;
+} HpfgBnAccDesc;
+int hpfg_bn_acc_finalize(const HpfgBnAccDesc* table_dev, const HpfgBnAccDesc* table_host, int nlayers, float momentum, float eps, void* stream);
+/* Backward counterpart.  With HpfgAct.bn_acc on a DZ source every dZ consumer (dgrad, fused dgrad + wgrad, wgrad) derives k1, k2, k3 from the
+ * layer's BACKWARD accumulator -- sum(g), sum(g * xhat), added there by the dgrad epilogue that completed the layer's gradient
+ * (HpfgConvArgs.bwd_stats + stat_acc) or by hpfg_bn_bwd_reduce[_pool]_acc -- so no hpfg_bn_bwd_finalize launch sits on the chain of backward.
+ * This call follows the last dZ consumer of the listed layers: dgamma / dbeta (native_batch_norm_backward), the k1 .. k3 table rows, and the
+ * accumulators are zeroed for the next pass. */
+typedef struct HpfgBnAccBwdDesc {
+  long long* acc;           /* [HPFG_ACC_WORDS(C, shards)]: read, then zeroed */
+  const float* gamma;
+  float* bn;                /* table: rows mean, rstd are read, k1, k2, k3 written */
+  float* dgamma;            /* or NULL */
+  float* dbeta;             /* or NULL */
+  int32_t C;
+  float count;
+  int32_t shards;
+  int32_t reserved;
+} HpfgBnAccBwdDesc;
+int hpfg_bn_acc_bwd_finalize(const HpfgBnAccBwdDesc* table_dev, const HpfgBnAccBwdDesc* table_host, int nlayers, void* stream);
+int hpfg_bn_bwd_reduce_acc(const HpfgAct* g, int N, int H, int W, long long* acc, int shards, void* stream);
+int hpfg_bn_bwd_reduce_pool_acc(const HpfgAct* g, const float* dP, int dp_pstride, int N, int Hp, int Wp, long long* acc, int shards, void* stream);
 int hpfg_reduce_partials(const float* partials, int nblk, int C, double* sums, void* stream);
 /* eval-mode BatchNorm (model.eval(), val.py:268-287): table rows from the running statistics */
 int hpfg_bn_eval_table(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
@@ -147,9 +213,10 @@ long hpfg_wpk16_elems(int Kchannels, int NchannelsPad, int taps, int kc);   /* b
 int hpfg_pack_weights(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, void* stream);
 /* The same launch also advances two per-forward device counters (nn.BatchNorm2d's num_batches_tracked += 1 of a train-mode forward,
  * model/unet.py:14-27 via torch; and the engine's dropout seed word, so that a replayed hipGraph draws fresh nn.Dropout masks):
- * counters[0..n_counters) += 1 (int64), *seed_word = (*seed_word + seed_add) & 0x7fffffff.  Either may be absent (0 / NULL). */
+ * counters[0..n_counters) += 1 (int64), *seed_word = (*seed_word + seed_add) & 0x7fffffff.  Either may be absent (0 / NULL).
+ * zero_words[0..n_zero) = 0: the BatchNorm sum accumulators (HpfgConvArgs.stat_acc) of the pass this launch precedes. */
 int hpfg_pack_weights_bump(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, long long* counters, int n_counters,
-                           int32_t* seed_word, int seed_add, void* stream);
+                           int32_t* seed_word, int seed_add, long long* zero_words, long n_zero, void* stream);
 /* evaluate a virtual activation into memory (tests, projection-neck inputs): out [N,H,W,a0.C+a1.C] */
 int hpfg_act_materialize(const HpfgAct* a0, const HpfgAct* a1, int N, int H, int W, float* out, void* stream);
 /* the dropout keep-mask the loaders use, as bytes [n_elems] (tests feed it to the oracle) */

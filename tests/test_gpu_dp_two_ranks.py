@@ -147,11 +147,16 @@ def test_peer_gradient_exchange_averages_the_shard_gradients(tmp_path, step):
     assert maxerr(r0[0], s0[0]) < 1e-6 and maxerr(r1[0], s1[0]) < 1e-6
 
 
-@pytest.mark.parametrize("step,sync_bn,overlap", [("mt", 0, 0), ("cps", 0, 0), ("mt", 1, 0), ("mt", 0, 1)])
+@pytest.mark.parametrize("step,sync_bn,overlap", [("mt", 0, 0), ("cps", 0, 0), ("mt", 1, 0), ("mt", 0, 1), ("mt", 1, 1), ("cps", 1, 1), ("hpfg", 1, 1)])
 def test_peer_gradient_exchange_makes_the_step_one_graph(tmp_path, step, sync_bn, overlap):
     """No host-launched collective left (sync_bn = 1: BatchNorm / loss sums through the mailboxes as well): forward + loss + backward + exchange +
     update captured as ONE hipGraph -- and equal to the eager two-rank run of the same two iterations with the host-launched all-reduce."""
     common = dict(HPFG_TEST_STEP=step, HPFG_TEST_SYNC_BN=sync_bn, HPFG_TEST_P2P=sync_bn, HPFG_TEST_STEPS=2)
+    # (mt, 1, 1) is what `bench.py --gpus N` runs by default: BatchNorm / loss sums through the mailboxes + bucketed peer-window gradients,
+    # one graph.  Two trainable networks (cps, hpfg) with overlap = 1: the second network back-propagates on a forked stream, so its buckets
+    # must NOT fork again inside a capture (hipStreamEndCapture faults on such an edge, ROCm 7.2) -- one exchange after both have joined;
+    # two exchanges of DIFFERENT sizes back to back (U-Net+ 3.66 M floats after U-Net ... : the window layout comes from the capacity).
+    # hpfg + sync_bn: Dense_Loss's feature gather goes through the peer windows too (heads._GatherRows), so cfg3's global-batch mode captures.
     # overlap = 1: the decoder bucket is exchanged on a side stream beside the encoder half of backward, still inside the one graph
     g0, g1 = _two_ranks(tmp_path, f"og_{step}{sync_bn}{overlap}", HPFG_TEST_GRAPH=1, HPFG_TEST_P2P_GRADS=1, HPFG_TEST_OVERLAP=overlap, **common)
     e0, e1 = _two_ranks(tmp_path, f"oe_{step}{sync_bn}{overlap}", HPFG_TEST_GRAPH=0, HPFG_TEST_FIXED=1, HPFG_TEST_OVERLAP=0, **common)

@@ -179,7 +179,7 @@ def test_whole_network_fused_and_thin_kernels_equal_the_separate_kernels(monkeyp
 
     def run(fused, thin):
         monkeypatch.setenv("HPFG_FUSED_BWD", fused)
-        monkeypatch.setenv("HPFG_CONV_THIN", thin)
+        L.load().hpfg_set_option(L.OPT_CONV_THIN, int(thin))      # (the last run below leaves the default, 1, in place)
         reset_dropout_streams()
         torch.manual_seed(3)
         m = UNet(1, 4).to(DEV)

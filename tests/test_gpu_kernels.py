@@ -342,7 +342,7 @@ def test_first_conv_mfma_form_equals_the_valu_form(N, H, W, cin, monkeypatch):
     with_stats = H % 16 == 0 and W % 16 == 0
     res = []
     for form in ("0", "1"):
-        monkeypatch.setenv("HPFG_FIRST_MFMA", form)
+        lib.hpfg_set_option(L.OPT_FIRST_MFMA, int(form))
         out = torch.full((N, H, W, 16), float("nan"), device=DEV)
         part = torch.full((nblk * 2 * 16,), float("nan"), device=DEV)
         L.check(lib.hpfg_conv3x3_first_fwd(C.byref(a), L.ptr(w), L.ptr(b), L.ptr(out), L.ptr(part) if with_stats else None, N, H, W, cin, 16, stream(DEV)), "first")

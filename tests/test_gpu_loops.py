@@ -115,3 +115,65 @@ def test_hpfg_loop_with_label_repeat(tmp_path):
     for path, net in ((a.model1_save_path, m1), (a.model2_save_path, m2), (a.ema_model_save_path, e)):
         _check_ckpt(path, net)
     assert sum("_dice" in ln for ln in a.logger.lines) >= 6           # three networks evaluated at iterations 2 and 4
+
+
+class _Writer:
+    def __init__(self):
+        self.rows = []
+
+    def add_scalar(self, name, value, itr):
+        self.rows.append((name, float(value), int(itr)))
+
+
+def _mt_run(tmp, graph, writer=None):
+    from hpfg_amd.model import reset_dropout_streams
+    reset_dropout_streams()
+    a = _args(tmp, total_itrs=5, step_size=1000, hipgraph=graph, log_every=4)
+    if writer is not None:
+        a.writer = writer
+    torch.manual_seed(1337)
+    m = build_model(a).to(DEV)
+    e = _teacher(m)
+    lab, unl, _ = build_loader(a)
+    log = Mean_Teacher(m, e, lab, unl, None, a)
+    torch.cuda.synchronize()
+    return log.cpu(), m.flat_params.detach().cpu().clone(), e.flat_params.detach().cpu().clone()
+
+
+def test_mean_teacher_loop_graphed_equals_eager_bitwise(tmp_path):
+    """The drop-in loop captures its step at iteration 2 and replays it from then on (the path bench.py times): same losses, same student
+    and teacher parameters, bit for bit, as the eager launches of the same six iterations -- dropout seeds, learning-rate law, EMA included."""
+    w = _Writer()
+    lg, pg, eg = _mt_run(tmp_path / "g", True, w)
+    le, pe, ee = _mt_run(tmp_path / "e", False)
+    assert lg.shape == (6,) and torch.equal(lg, le), (lg, le)
+    assert torch.equal(pg, pe) and torch.equal(eg, ee)
+    # the reference's per-iteration scalars (2017_03_NIPS_Mean-Teacher_ACDC.py:111-113), delivered every log_every iterations and at the end
+    names = {n for n, _, _ in w.rows}
+    assert names == {"mean_teacher/loss", "mean_teacher/lr", "mean_teacher/consistency_weight"}
+    its = sorted({i for _, _, i in w.rows})
+    assert its == [1, 2, 3, 4, 5, 6]
+    loss = [v for n, v, i in sorted(w.rows, key=lambda r: r[2]) if n == "mean_teacher/loss"]
+    assert max(abs(a - float(b)) for a, b in zip(loss, lg)) < 1e-6
+    lrs = [v for n, v, i in sorted(w.rows, key=lambda r: r[2]) if n == "mean_teacher/lr"]
+    assert 0 < lrs[1] < lrs[0] < 0.01          # read after lr_scheduler.step(), as the reference does (:108-110)
+
+
+def test_hpfg_loop_scalars(tmp_path):
+    """main.py:216-222: the seven scalar names of the HPFG driver, and loss == loss_sup + loss_semi."""
+    a = _args(tmp_path, model="unet_plus", unlabel_batch_size=4, weight_decay=5e-4, total_itrs=3, step_size=1000, log_every=2)
+    a.model1, a.model2 = _opt(weight_decay=5e-4), _opt(weight_decay=5e-4)
+    a.writer = _Writer()
+    torch.manual_seed(1)
+    m1, m2 = build_model(a).to(DEV), build_model(a).to(DEV)
+    e = _teacher(m2)
+    lab, unl, _ = build_loader(a)
+    log = HPFG(m1, m2, e, lab, unl, None, a)
+    assert log.shape == (4,) and torch.isfinite(log).all()
+    names = {n for n, _, _ in a.writer.rows}
+    assert names == {"HPFG/loss", "HPFG/loss_semi", "HPFG/loss_sup", "HPFG/lr1", "HPFG/lr2", "HPFG/consistency_weight_cps", "HPFG/consistency_weight_mt"}
+    by = {}
+    for n, v, i in a.writer.rows:
+        by.setdefault(i, {})[n] = v
+    for i, d in by.items():
+        assert abs(d["HPFG/loss"] - d["HPFG/loss_sup"] - d["HPFG/loss_semi"]) < 1e-5 and d["HPFG/loss_sup"] > 0
