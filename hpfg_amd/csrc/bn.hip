@@ -128,9 +128,10 @@ __global__ __launch_bounds__(256) void bn_acc_finalize_kernel(const HpfgBnAccDes
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= d.C) return;
   const double count = (double)d.count;
+  const float ga = d.gamma[c], be = d.beta[c];
   double s1, s2;
-  hpfg_acc_read2(d.acc, d.C, d.shards, c, s1, s2);
-  const HpfgBnCoef q = hpfg_bn_coef(s1, s2, count, eps, d.gamma[c], d.beta[c]);
+  hpfg_acc_read2(d.acc, d.C, d.shards, c, s1, s2, ga + be);
+  const HpfgBnCoef q = hpfg_bn_coef(s1, s2, count, eps, ga, be);
   d.bn[HPFG_BN_MEAN * d.C + c] = q.mean;
   d.bn[HPFG_BN_RSTD * d.C + c] = q.rstd;
   d.bn[HPFG_BN_SCALE * d.C + c] = q.scale;
@@ -141,6 +142,14 @@ __global__ __launch_bounds__(256) void bn_acc_finalize_kernel(const HpfgBnAccDes
     d.running_mean[c] = (float)((1.0 - momentum) * (double)d.running_mean[c] + momentum * mean);
     d.running_var[c] = (float)((1.0 - momentum) * (double)d.running_var[c] + momentum * unb);
   }
+  // every consumer of this forward has run (the launch follows the last conv): leave the accumulator zeroed for the next forward
+  long long* acc = const_cast<long long*>(d.acc);
+  for (int s = 0; s < d.shards; ++s)
+    for (int w = 0; w < 2; ++w) {
+      long long* b = acc + ((long)((s * 2 + w) * d.C + c)) * 2;
+      b[0] = 0;
+      b[1] = 0;
+    }
 }
 
 // Backward counterpart, at the END of a backward pass (or of its decoder half): dgamma / dbeta of every listed layer from its backward sum

@@ -66,8 +66,11 @@ __device__ __forceinline__ void hpfg_acc_add(long long* acc, int C, int shard, i
   __hip_atomic_fetch_add(b, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (agent scope: correct wherever the workgroup runs; the
   __hip_atomic_fetch_add(b + 1, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  //  sharding only spreads the same-address contention)
 }
-// both sums of channel c: every 16-byte (hi, lo) load of the `shards` shards in flight before the first add
-__device__ __forceinline__ void hpfg_acc_read2(const long long* __restrict__ acc, int C, int shards, int c, double& s1, double& s2) {
+// both sums of channel c: every 16-byte (hi, lo) load of the `shards` shards in flight before the first add.  `with` = a value formed from
+// the caller's OTHER loads of this channel (gamma, beta, table rows): the empty asm below makes it an input of the point where the
+// accumulator loads are issued... it must not wait for it -- so it is only named as a dependency of the FIRST ADD, which pins those loads
+// in front of the accumulator words' consumption (one exposed memory round trip instead of two).
+__device__ __forceinline__ void hpfg_acc_read2(const long long* __restrict__ acc, int C, int shards, int c, double& s1, double& s2, float with = 0.f) {
   typedef long long i64x2 __attribute__((ext_vector_type(2)));
   i64x2 v[HPFG_ACC_MAX_SHARDS][2];
 #pragma unroll
@@ -77,6 +80,7 @@ __device__ __forceinline__ void hpfg_acc_read2(const long long* __restrict__ acc
     v[s][1] = *reinterpret_cast<const i64x2*>(acc + ((long)((sc * 2 + 1) * C + c)) * 2);
   }
   i64x2 a = {0, 0}, b = {0, 0};
+  asm volatile("" ::"v"(with), "v"(v[0][0]));      // `with` and the first accumulator word are both needed HERE: their loads were issued above
 #pragma unroll
   for (int s = 0; s < HPFG_ACC_MAX_SHARDS; ++s) {
     if (s < shards) {
@@ -147,10 +151,12 @@ __device__ __forceinline__ void hpfg_dz_rows_to_lds(const HpfgAct& a, float* t, 
       v[0] = tb[HPFG_BN_SCALE * st];
       v[1] = tb[HPFG_BN_SHIFT * st];
       if (a.bn_acc) {
+        // every load of this channel goes out before the first is consumed: ONE exposed round trip (the compiler otherwise requests
+        // gamma / mean / rstd only after the accumulator words have arrived -- a second one, ~2 us per kernel launch)
+        const float mean = tb[HPFG_BN_MEAN * st], rstd = tb[HPFG_BN_RSTD * st], ga = a.bn_gamma[a.bn_coff + c];
         double sg, sgx;
-        hpfg_acc_read2(a.bn_acc, st, a.bn_shards, a.bn_coff + c, sg, sgx);
-        const HpfgBnBwdCoef q = hpfg_bn_bwd_coef(sg, sgx, (double)a.bn_count, (double)tb[HPFG_BN_MEAN * st], (double)tb[HPFG_BN_RSTD * st],
-                                                 (double)a.bn_gamma[a.bn_coff + c]);
+        hpfg_acc_read2(a.bn_acc, st, a.bn_shards, a.bn_coff + c, sg, sgx, mean + rstd + ga);
+        const HpfgBnBwdCoef q = hpfg_bn_bwd_coef(sg, sgx, (double)a.bn_count, (double)mean, (double)rstd, (double)ga);
         v[2] = q.k1;
         v[3] = q.k2;
         v[4] = q.k3;
@@ -170,9 +176,10 @@ __device__ __forceinline__ void hpfg_bn_rows_to_lds(const HpfgAct& a, float* t, 
     float sc, sh;
     if (a.bn_acc) {
       const int cc = a.bn_coff + c;
+      const float ga = a.bn_gamma[cc], be = a.bn_beta[cc];      // (requested WITH the accumulator words: one round trip, see hpfg_dz_rows_to_lds)
       double s1, s2;
-      hpfg_acc_read2(a.bn_acc, a.bn_stride, a.bn_shards, cc, s1, s2);
-      const HpfgBnCoef q = hpfg_bn_coef(s1, s2, (double)a.bn_count, a.bn_eps, a.bn_gamma[cc], a.bn_beta[cc]);
+      hpfg_acc_read2(a.bn_acc, a.bn_stride, a.bn_shards, cc, s1, s2, ga + be);
+      const HpfgBnCoef q = hpfg_bn_coef(s1, s2, (double)a.bn_count, a.bn_eps, ga, be);
       sc = q.scale;
       sh = q.shift;
     } else {

@@ -152,9 +152,10 @@ __global__ __launch_bounds__(64 * NW, WGS) void conv_thin_kernel(HpfgConvArgs p,
       float sc = 0.f, sh = 0.f;
       if (ch < aS.C) {
         const int cc = aS.bn_coff + ch;
+        const float ga = aS.bn_gamma[cc], be = aS.bn_beta[cc];      // (requested with the accumulator words: one round trip)
         double s1, s2;
-        hpfg_acc_read2(aS.bn_acc, aS.bn_stride, aS.bn_shards, cc, s1, s2);
-        const HpfgBnCoef q = hpfg_bn_coef(s1, s2, (double)aS.bn_count, aS.bn_eps, aS.bn_gamma[cc], aS.bn_beta[cc]);
+        hpfg_acc_read2(aS.bn_acc, aS.bn_stride, aS.bn_shards, cc, s1, s2, ga + be);
+        const HpfgBnCoef q = hpfg_bn_coef(s1, s2, (double)aS.bn_count, aS.bn_eps, ga, be);
         sc = q.scale;
         sh = q.shift;
       }

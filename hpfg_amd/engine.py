@@ -147,8 +147,7 @@ class UNetEngine:
         # per-rank statistics only (the global-batch data-parallel mode exchanges the sums inside its finalize kernels and keeps them).
         self.bn_layers = [s for s in self.order if s.bn]      # (encoder layers first: build_specs order)
         self._n_enc_bn = sum(1 for s in self.bn_layers if s.name.startswith("encoder."))
-        self.bn_acc_mode = int(os.environ.get("HPFG_BN_ACC", "1"))      # 0 off; 1 on; 2 / 3: timing experiments (atomics only / + consumer prologues, finalize launches kept)
-        self.bn_acc_on = self.bn_acc_mode != 0
+        self.bn_acc_on = os.environ.get("HPFG_BN_ACC", "1") != "0"      # 0: the per-layer finalize launches (the path the global-batch data-parallel mode keeps)
         # shards: the producers' same-address atomics want many (ONE shard: +0.3 ms per step, two: +0.09), every consumer workgroup's prologue
         # wants few (32 bytes per channel and shard).  Measured in the step (profiles/r04_bn_acc.txt): 8 everywhere beats 4 and beats 8 / 4 / 2 by
         # channel count -- the contention costs more than the prologue reads.
@@ -160,8 +159,11 @@ class UNetEngine:
             assert s.cout == s.cout_pad
             self.acc_of[s.name] = self.acc_all[off:off + self.acc_shards[s.name] * 4 * s.cout]
             off += self.acc_shards[s.name] * 4 * s.cout
-        self._acc_live = False
+        self._acc_live, self._acc_dirty = False, False
         self._acc_tables: Dict[bool, tuple] = {}
+        # set by the model for the network that runs on the step's ORIGIN stream (the single trainable network of a step): its weight packing
+        # (22 us) runs on the side stream beside the first conv, which reads the OIHW weights directly and needs nothing the launch produces
+        self.pack_overlap = False
         # the same for the backward sums (sum g, sum g * xhat): added by the dgrad epilogue / the reduction pass that completes a layer's
         # gradient, read by every dZ consumer's prologue (k1 .. k3 derived there), turned into dgamma / dbeta -- and zeroed again -- by ONE
         # launch per backward (hpfg_bn_acc_bwd_finalize) instead of 18 finalize launches on the critical chain
@@ -228,7 +230,7 @@ class UNetEngine:
         a = L.Act()
         a.z, a.bn, a.mode, a.C = L.ptr(self.z[name]), L.ptr(self.bn[name]), mode, s.cout
         a.Hs, a.Ws, a.pstride, a.bn_stride, a.bn_coff = s.h, s.w, s.cout, s.cout, 0
-        if self._acc_live and self.bn_acc_mode != 2 and mode in (L.ACT_BNACT, L.ACT_BNACT_POOL):      # the forward consumers form scale / shift from the sums themselves
+        if self._acc_live and mode in (L.ACT_BNACT, L.ACT_BNACT_POOL):      # the forward consumers form scale / shift from the sums themselves
             a.bn_acc, a.bn_gamma, a.bn_beta = L.ptr(self.acc_of[name]), L.ptr(self.params[f"{s.bn}.weight"]), L.ptr(self.params[f"{s.bn}.bias"])
             a.bn_count, a.bn_eps, a.bn_shards = float(self.N * s.h * s.w), BN_EPS, self.acc_shards[name]
         if mode == L.ACT_BNACT and s.drop_p > 0 and self.dropout_on:
@@ -307,17 +309,16 @@ class UNetEngine:
             self._pack_tables[key] = (descs, dev)
         return self._pack_tables[key]
 
-    def pack(self, with_dgrad: bool = True, counters: Optional[torch.Tensor] = None, seed_add: int = 0, zero_acc: bool = False):
+    def pack(self, with_dgrad: bool = True, counters: Optional[torch.Tensor] = None, seed_add: int = 0):
         """counters: int64 tensor whose elements the same launch advances by one (num_batches_tracked of the network's BatchNorm layers);
-        seed_add: advance of the engine's dropout seed word (hpfg_pack_weights_bump); zero_acc: the launch also zeroes the BatchNorm sum
-        accumulators of the forward it precedes."""
+        seed_add: advance of the engine's dropout seed word (hpfg_pack_weights_bump)."""
         host, dev = self._pack_table(self.math, with_dgrad)
         if counters is not None:
             assert counters.dtype == torch.int64 and counters.is_contiguous() and counters.device == self.dev
         self._run("pack_weights", lambda: L.check(self.lib.hpfg_pack_weights_bump(
             dev.data_ptr(), host, len(self.packed), L.ptr(counters) if counters is not None else None,
             counters.numel() if counters is not None else 0, L.ptr(self.seed_dev), int(seed_add),
-            L.ptr(self.acc_all) if zero_acc else None, self.acc_all.numel() if zero_acc else 0, self._stream()), "pack_weights"))
+            None, 0, self._stream()), "pack_weights"))
 
     def _finalize_bwd_all(self, lo: int, hi: int):
         """hpfg_bn_acc_bwd_finalize for BatchNorm layers [lo, hi) of self.bn_layers (encoder layers come first): dgamma / dbeta (+ the k rows)
@@ -387,7 +388,14 @@ class UNetEngine:
         counters, self.bump_counters = self.bump_counters, None
         self._acc_live = bool(train and self.bn_acc_on and self.math == L.MATH_BF16X3 and self.peer is None and not (self.world > 1 or self.force_sync)
                               and not self._skip_fin)
-        self.pack(with_dgrad=bool(train and needs_grad), counters=counters, seed_add=1 if seed_step == SEED_BUMP else 0, zero_acc=self._acc_live)
+        if self._acc_live:
+            if self._acc_dirty:          # a forward that never reached its finalize launch (an exception): start from zero (hpfg_bn_acc_finalize zeroes otherwise)
+                self.acc_all.zero_()
+            self._acc_dirty = True
+        self._pack_args = dict(with_dgrad=bool(train and needs_grad), counters=counters, seed_add=1 if seed_step == SEED_BUMP else 0)
+        if not (self.pack_overlap and train):
+            self.pack(**self._pack_args)
+            self._pack_args = None
         if self.marks is not None:
             self.marks.calib(self._stream())
         if train and self.peer is not None and (self.world > 1 or self.force_sync):
@@ -409,10 +417,24 @@ class UNetEngine:
                 seed_step: Optional[int] = None, needs_grad: bool = True) -> torch.Tensor:
         """x: [N,C,H,W] fp32 on the device (any strides).  Returns logits as an [N,H,W,ncls] tensor (fresh allocation)."""
         logits = self._fwd_begin(x, train, dropout, seed_step, needs_grad)
-        for s in self.order:
+        for i, s in enumerate(self.order):
+            if i == 0 and self._pack_args is not None:
+                # one fork / join against the stream this forward runs on (the step's origin stream: UNet sets pack_overlap only there -- a fork
+                # of a forked stream inside a capture faults in hipStreamEndCapture on ROCm 7.2): [pack] beside [first conv]
+                main = torch.cuda.current_stream(self.dev)
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.dev)
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    self.pack(**self._pack_args)
+                self._pack_args = None
+                self._fwd_layer(s, logits, train, track_running)
+                main.wait_stream(self._side)
+                continue
             self._fwd_layer(s, logits, train, track_running)
-        if self._acc_live and self.bn_acc_mode == 1:
+        if self._acc_live:
             self._finalize_all(track_running)
+            self._acc_dirty = False
         self.bwd_ready = bool(train and needs_grad)
         return logits
 
@@ -428,7 +450,7 @@ class UNetEngine:
             if acc:
                 self._run("fwd:" + s.name, lambda: L.check(self.lib.hpfg_conv3x3_first_fwd_acc(
                     C.byref(a0), L.ptr(self.params[f"{s.name}.weight"]), L.ptr(self.params[f"{s.name}.bias"]), L.ptr(out),
-                    L.ptr(self.partials) if self.bn_acc_mode > 1 else None, L.ptr(self.acc_of[s.name]), self.acc_shards[s.name], self.N, s.h, s.w, s.cin,
+                    None, L.ptr(self.acc_of[s.name]), self.acc_shards[s.name], self.N, s.h, s.w, s.cin,
                     s.cout, st), "conv3x3_first_fwd_acc"))
             else:
                 self._run("fwd:" + s.name, lambda: L.check(self.lib.hpfg_conv3x3_first_fwd(
@@ -436,14 +458,14 @@ class UNetEngine:
                     L.ptr(self.partials) if want_stats else None, self.N, s.h, s.w, s.cin, s.cout, st), "conv3x3_first_fwd"))
             nblk = self.lib.hpfg_conv_first_rows(self.N, s.h, s.w)
         else:
-            ca = self._conv_args(s, out, want_stats and (not acc or self.bn_acc_mode > 1))
+            ca = self._conv_args(s, out, want_stats and not acc)
             if acc:
                 ca.stat_acc, ca.stat_shards = L.ptr(self.acc_of[s.name]), self.acc_shards[s.name]
             self._run("fwd:" + s.name, lambda: L.check(self.lib.hpfg_conv_fwd(C.byref(ca), st), f"conv_fwd[{s.name}]"))
-            if want_stats and (not acc or self.bn_acc_mode > 1):
+            if want_stats and not acc:
                 nblk = self.lib.hpfg_conv_stat_rows(C.byref(ca))
         if s.bn:
-            if train and acc and self.bn_acc_mode == 1:
+            if train and acc:
                 pass
             elif train:
                 self._finalize_bn(s, nblk, track_running)
@@ -697,8 +719,8 @@ class UNetEngine:
         st = self._stream()
         N = self.N
         sp = self.specs
-        self._accb_live = bool(self.bn_acc_mode == 1 and self.math == L.MATH_BF16X3 and self.peer is None and not (self.world > 1 or self.force_sync)
-                               and not self._skip_fin and os.environ.get("HPFG_BN_ACC_BWD", "1") == "1")
+        self._accb_live = bool(self.bn_acc_on and self.math == L.MATH_BF16X3 and self.peer is None and not (self.world > 1 or self.force_sync)
+                               and not self._skip_fin)
         if self._accb_live:
             if self._accb_dirty:          # a backward pass that did not reach its finalize launch (an exception): start from zero
                 self.accb_all.zero_()

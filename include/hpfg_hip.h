@@ -173,7 +173,7 @@ int hpfg_bn_fwd_finalize(const float* partials, int nblk, const double* sums, do
  * consumers derive scale / shift themselves (HpfgAct.bn_acc), so this call follows the LAST conv of the forward and writes the table rows
  * the backward kernels read, plus running_mean / running_var (momentum, unbiased variance).  Device array of descriptors + host copy. */
 typedef struct HpfgBnAccDesc {
-  const long long* acc;     /* [HPFG_ACC_WORDS(C, shards)] */
+  const long long* acc;     /* [HPFG_ACC_WORDS(C, shards)]: read, then ZEROED for the next forward (every consumer has run by then) */
   const float* gamma;
   const float* beta;
   float* running_mean;      /* both or neither */

@@ -100,3 +100,128 @@ def test_mean_teacher_25_iterations_then_dice(oracle_run, math):
         d_got = losses_ref.mean_foreground_dice(got.argmax(1).numpy(), ye.numpy(), 4)
         d_ref = losses_ref.mean_foreground_dice(ref.argmax(1).numpy(), ye.numpy(), 4)
         assert abs(d_got - d_ref) < 1e-3, (who, d_got, d_ref)
+
+
+# ---- long horizon: the precision credit of the default math mode must not rest on 25 iterations -------------------
+LONG_MT, LONG_HPFG = 500, 200
+
+
+@pytest.fixture(scope="module")
+def oracle_long():
+    """500 Mean-Teacher iterations of the fp32 CPU oracle (about 30 s on the GPU box's 16 threads): loss trace + held-out predictions."""
+    global ITERS
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    keep, ITERS = ITERS, LONG_MT
+    try:
+        losses, st, ema_st = _train_oracle("f32")
+    finally:
+        ITERS = keep
+    xe, ye = synth_batch(777, 16, HW, HW)
+    with torch.no_grad():
+        return {"losses": losses, "xe": xe, "ye": ye, "student": unet_ref.unet_forward(st, xe, False), "teacher": unet_ref.unet_forward(ema_st, xe, False)}
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "f32"])
+def test_mean_teacher_500_iterations_loss_trace_and_dice(oracle_long, math):
+    """BASELINE.json: "mean Dice vs CPU ref ... within 1e-3".  500 iterations from the same weights, batches and dropout masks: the WHOLE loss
+    trace stays within a flat 1e-3 of the fp32 oracle's (measured: 1.5e-4 in bf16x3) and the held-out mean foreground Dice of student and EMA
+    teacher within 1e-3 (measured: 2e-5; the loss falls 0.96 -> 0.009, Dice 0.998).  The logits themselves are NOT compared at this horizon:
+    training is a chaotic map -- the fp64-ACCUMULATING oracle (summation order only) ends 0.2 away from the fp32 oracle on them, as the device
+    does (tools/long_parity.py prints that control: profiles/r04_long_parity.txt) -- which is exactly why the metric is Dice."""
+    from copy import deepcopy
+    torch.manual_seed(1337)
+    m = UNet(1, 4).to(DEV)
+    m.math = math
+    ema = deepcopy(m)
+    for p in ema.parameters():
+        p.requires_grad = False
+    m.train()
+    ema.train()
+    step = MeanTeacherStep(m, ema, AttrDict(dict(ARGS)))
+    got = []
+    for k in range(1, LONG_MT + 1):
+        xl, yl, xu, ms, mt = _batch(k)
+        m.external_dropout_masks, ema.external_dropout_masks = _device_masks(ms), _device_masks(mt)
+        got.append(step.step(xl.to(DEV), yl.to(DEV), xu.to(DEV), k, cons_w=CONS_W)["loss"])
+    got, ref = torch.stack(got).cpu().numpy(), oracle_long["losses"]
+    assert ref[-25:].mean() < 0.05 < ref[:5].mean()                  # it trains to convergence
+    assert np.abs(ref - got).max() < 1e-3, (np.abs(ref - got).max(), int(np.abs(ref - got).argmax()))
+    m.eval()
+    ema.eval()
+    m.external_dropout_masks = ema.external_dropout_masks = None
+    xe, ye = oracle_long["xe"], oracle_long["ye"]
+    for net, who in ((m, "student"), (ema, "teacher")):
+        with torch.no_grad():
+            o = net(xe.to(DEV)).cpu()
+        d_got = losses_ref.mean_foreground_dice(o.argmax(1).numpy(), ye.numpy(), 4)
+        d_ref = losses_ref.mean_foreground_dice(oracle_long[who].argmax(1).numpy(), ye.numpy(), 4)
+        assert d_ref > 0.9 and abs(d_got - d_ref) < 1e-3, (who, d_got, d_ref)
+
+
+def test_hpfg_200_iterations_loss_trace_and_dice():
+    """The same for the HPFG step (main.py:125-212: two U-Net+ students, EMA teacher, CutMix pseudo-labels, Dense_Loss, backbone EMA) in the
+    default math mode: 200 iterations past the `cur_itrs >= 1000` gate of the consistency term, loss trace within a flat 1e-3, held-out Dice
+    of both students and the teacher within 1e-3 of the fp32 oracle's."""
+    import os
+    from copy import deepcopy
+
+    from hpfg_amd.model import UNet_Plus
+    from hpfg_amd.train import HPFGStep
+    from hpfg_amd.utils import BoxMaskGenerator
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    nl = nu = 4
+    first = 1000
+    gen = BoxMaskGenerator(prop_range=(0.25, 0.5), n_boxes=4, random_aspect_ratio=True, prop_by_area=True, within_bounds=True, invert=True)
+
+    def batches():
+        rng = np.random.RandomState(11)
+        for k in range(LONG_HPFG):
+            xl, yl = synth_batch(3000 + k, nl, HW, HW)
+            xl1, yl1 = synth_batch(4000 + k, nl, HW, HW)
+            xu, _ = synth_batch(5000 + k, nu, HW, HW)
+            cm = torch.tensor(gen.generate_params(nu, (HW, HW), rng=rng), dtype=torch.float)
+            torch.manual_seed(6000 + k)
+            yield first + k, xl, yl, xl1, yl1, xu, cm, [unet_ref.draw_dropout_masks(nl + nu, HW, HW) for _ in range(3)]
+
+    # fp32 oracle
+    torch.manual_seed(1)
+    sa, sb = unet_ref.init_state(None, 1, 4, True), unet_ref.init_state(None, 1, 4, True)
+    se, ba, bb, ref = unet_ref.clone_state(sb), {}, {}, []
+    for cur, xl, yl, xl1, yl1, xu, cm, (ma, mb, mt) in batches():
+        lr = laws_ref.medical_lr(cur, 0.01, 30000)
+        ref.append(steps_ref.hpfg_step(sa, sb, se, ba, bb, xl, yl.long(), xl1, yl1.long(), xu, cm, cur, lr, lr, 0.1, 200.0, 0.99, 0.9, 5e-4, ma, mb, mt)["loss"])
+    # HIP path
+    torch.manual_seed(1)
+    m1, m2 = UNet_Plus(1, 4).to(DEV), UNet_Plus(1, 4).to(DEV)
+    ema = deepcopy(m2)
+    for p in ema.parameters():
+        p.requires_grad = False
+    m1.train(), m2.train()
+    a = AttrDict(dict(ARGS, batch_size=nl, unlabel_batch_size=nu))
+    a.model1, a.model2 = AttrDict(dict(ARGS, weight_decay=5e-4)), AttrDict(dict(ARGS, weight_decay=5e-4))
+    st = HPFGStep(m1, m2, ema, a)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(first - 1):
+            st.lr_scheduler1.step()
+            st.lr_scheduler2.step()
+    got = []
+    for cur, xl, yl, xl1, yl1, xu, cm, (ma, mb, mt) in batches():
+        m1.external_dropout_masks, m2.external_dropout_masks, ema.external_dropout_masks = _device_masks(ma), _device_masks(mb), _device_masks(mt)
+        got.append(st.step(xl.to(DEV), yl.to(DEV), xl1.to(DEV), yl1.to(DEV), xu.to(DEV), cm.to(DEV), cur)["loss"])
+    got, ref = torch.stack(got).cpu().numpy(), np.array(ref)
+    assert ref[-10:].mean() < ref[:5].mean() - 0.3
+    assert np.abs(ref - got).max() < 1e-3, (np.abs(ref - got).max(), int(np.abs(ref - got).argmax()))
+    xe, ye = synth_batch(778, 16, HW, HW)
+    for net, state, who in ((m1, sa, "model1"), (m2, sb, "model2"), (ema, se, "teacher")):
+        net.eval()
+        net.external_dropout_masks = None
+        with torch.no_grad():
+            o = net(xe.to(DEV))
+            o = (o[0] if isinstance(o, (tuple, list)) else o).cpu()
+            r = unet_ref.unet_forward(state, xe, False, plus=True)
+            r = r[0] if isinstance(r, (tuple, list)) else r
+        d_got = losses_ref.mean_foreground_dice(o.argmax(1).numpy(), ye.numpy(), 4)
+        d_ref = losses_ref.mean_foreground_dice(r.argmax(1).numpy(), ye.numpy(), 4)
+        assert abs(d_got - d_ref) < 1e-3, (who, d_got, d_ref)
