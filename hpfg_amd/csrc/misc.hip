@@ -184,23 +184,24 @@ __device__ inline void up_taps(int lo, int L, int* idx, float* wgt, int& cnt) {
 // two 72 KB workgroups per CU keep too few loads in flight; this gather form runs 8 workgroups per CU and its re-reads hit L2.)
 // Optionally the per-channel sums of each workgroup's outputs go to csum[blockIdx][C]: the bias gradient of the 1x1 conv that
 // produced the low-res tensor (model/unet.py:50) is sum_p dU, and the slab reduction adds the rows in a fixed order.
-constexpr int UPB_MAXDIM = 512, UPB_TAPS = 6;
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dUp, int dup_ps, float* __restrict__ dU, int N, int Hl, int Wl,
+constexpr int UPB_MAXDIM = 512, UPB_TAPS = 5;      // a x2 align-corners map sends at most 5 (on average 4) outputs per axis to one source
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void upsample_bwd_kernel(const float* __restrict__ dUp, int dup_ps, float* __restrict__ dU, int N, int Hl, int Wl,
                                                            int C, float* __restrict__ csum, int xcd_aware) {
   __shared__ short t_idx[UPB_MAXDIM][UPB_TAPS];
   __shared__ float t_w[UPB_MAXDIM][UPB_TAPS];
-  __shared__ unsigned char t_cnt[UPB_MAXDIM];
   __shared__ float red[256 * 4];
+  // every row / column gets exactly UPB_TAPS entries: unused ones repeat the last valid index with weight 0, so that the gather below is
+  // 25 unconditional loads -- ALL in flight before the first is used.  (With run-time tap counts the loops issued load, wait, multiply 16
+  // times in a row: the kernel was bound by sixteen L2 round trips per thread, 2 TB/s on a stream that fits L2.)
   for (int e = threadIdx.x; e < Hl + Wl; e += 256) {
     int idx[8], cnt;
     float wgt[8];
     if (e < Hl) up_taps(e, Hl, idx, wgt, cnt);
     else up_taps(e - Hl, Wl, idx, wgt, cnt);
-    if (cnt > UPB_TAPS) cnt = UPB_TAPS;      // cannot happen for a x2 align-corners map (at most 3 + 3 outputs reach one source)
-    t_cnt[e] = (unsigned char)cnt;
-    for (int k = 0; k < cnt; ++k) {
-      t_idx[e][k] = (short)idx[k];
-      t_w[e][k] = wgt[k];
+    if (cnt > UPB_TAPS) cnt = UPB_TAPS;      // cannot happen for a x2 align-corners map
+    for (int k = 0; k < UPB_TAPS; ++k) {
+      t_idx[e][k] = (short)(k < cnt ? idx[k] : idx[cnt - 1]);
+      t_w[e][k] = k < cnt ? wgt[k] : 0.f;
     }
   }
   __syncthreads();
@@ -220,15 +221,29 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
     int q = (int)(i % Q);
     long pp = i / Q;
     int xl = (int)(pp % Wl), yl = (int)((pp / Wl) % Hl), n = (int)(pp / ((long)Wl * Hl));
-    const int ny = t_cnt[yl], nx = t_cnt[Hl + xl];
+    int iy[UPB_TAPS], ix[UPB_TAPS];
+    float wy[UPB_TAPS], wx[UPB_TAPS];
+#pragma unroll
+    for (int k = 0; k < UPB_TAPS; ++k) {
+      iy[k] = t_idx[yl][k];
+      wy[k] = t_w[yl][k];
+      ix[k] = t_idx[Hl + xl][k] * dup_ps;
+      wx[k] = t_w[Hl + xl][k];
+    }
+    f32x4 v[UPB_TAPS][UPB_TAPS];
+#pragma unroll
+    for (int a = 0; a < UPB_TAPS; ++a) {
+      const float* row = dUp + ((long)(n * Ho + iy[a]) * Wo) * dup_ps + q * 4;
+#pragma unroll
+      for (int b = 0; b < UPB_TAPS; ++b) v[a][b] = *reinterpret_cast<const f32x4*>(row + ix[b]);
+    }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int a = 0; a < ny; ++a) {
-      const float* row = dUp + ((long)(n * Ho + t_idx[yl][a]) * Wo) * dup_ps + q * 4;
-      const float wy = t_w[yl][a];
-      for (int b = 0; b < nx; ++b) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(row + (long)t_idx[Hl + xl][b] * dup_ps);
-        acc += (wy * t_w[Hl + xl][b]) * v;
-      }
+#pragma unroll
+    for (int a = 0; a < UPB_TAPS; ++a) {          // separable: the horizontal taps of a row first, then the row's vertical weight
+      f32x4 h = wx[0] * v[a][0];
+#pragma unroll
+      for (int b = 1; b < UPB_TAPS; ++b) h += wx[b] * v[a][b];
+      acc += wy[a] * h;
     }
     *reinterpret_cast<f32x4*>(dU + pp * C + q * 4) = acc;
     csum4 += acc;
