@@ -166,7 +166,6 @@ __device__ __forceinline__ void hpfg_dz_rows_to_lds(const HpfgAct& a, float* t, 
         v[4] = tb[HPFG_BN_K3 * st];
       }
     }
-    if (a.drop_p > 0.f) v[2] *= 1.f / (1.f - a.drop_p);      // Dropout's 1 / (1 - p) on g rides in k1
 #pragma unroll
     for (int r = 0; r < 5; ++r) t[r * cmax + c] = v[r];
   }
@@ -186,11 +185,6 @@ __device__ __forceinline__ void hpfg_bn_rows_to_lds(const HpfgAct& a, float* t, 
     } else {
       sc = a.bn[a.bn_coff + HPFG_BN_SCALE * a.bn_stride + c];
       sh = a.bn[a.bn_coff + HPFG_BN_SHIFT * a.bn_stride + c];
-    }
-    if (a.mode == HPFG_ACT_BNACT && a.drop_p > 0.f) {      // Dropout's 1 / (1 - p): lrelu(y) / (1 - p) == lrelu(y / (1 - p))
-      const float ik = 1.f / (1.f - a.drop_p);
-      sc *= ik;
-      sh *= ik;
     }
     t[c] = sc;
     t[cmax + c] = sh;

@@ -159,8 +159,8 @@ __global__ __launch_bounds__(64 * NW, WGS) void conv_thin_kernel(HpfgConvArgs p,
         sc = q.scale;
         sh = q.shift;
       }
-      tabA[ch] = sc * cxa.inv_keep;          // (Dropout's 1 / (1 - p) folded into the rows: 1 without dropout)
-      tabA[16 * NA0 + ch] = sh * cxa.inv_keep;
+      tabA[ch] = sc;
+      tabA[16 * NA0 + ch] = sh;
     }
   } else if (AK0 == HPFG_KIND_DZ) {      // rows scale, shift, k1, k2, k3 (table, or k1 .. k3 derived from the backward sum accumulators)
     hpfg_dz_rows_to_lds(aS, tabA, 16 * NA0, 16 * NA0, tid, NTH);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * NW, WGS) void conv_thin_kernel(HpfgConvArgs p,
     for (int i = tid; i < G::TROWS * 16 * NA0; i += NTH) {
       const int r = i / (16 * NA0), ch = i % (16 * NA0);
       const int row = r == 0 ? HPFG_BN_SCALE : HPFG_BN_SHIFT;
-      tabA[i] = ch < aS.C ? aS.bn[aS.bn_coff + row * aS.bn_stride + ch] * cxa.inv_keep : 0.f;
+      tabA[i] = ch < aS.C ? aS.bn[aS.bn_coff + row * aS.bn_stride + ch] : 0.f;
     }
   }
   __syncthreads();                                       // tables, weight fragments
@@ -176,15 +176,10 @@ __global__ __launch_bounds__(64 * NW, WGS) void conv_thin_kernel(HpfgConvArgs p,
   for (; w < wend; w += GS) {
     const int n = w / ntiles, ty0 = ((w % ntiles) / tiles_x) * T, tx0 = ((w % ntiles) % tiles_x) * T;
     // ---- prefetched raw data -> producer chain -> bf16 hi / lo -> LDS
-    // Two instantiations of the conversion code, chosen per tile (workgroup-uniform): a tile whose 18 x 18 halo lies inside the image
-    // (73 % of the tiles at 224 x 224) needs no in-image predicate -- 8 selects + 4 clamps per piece less (loader diet)
-    const bool interior = ty0 > 0 && tx0 > 0 && ty0 + T < H && tx0 + T < W && aS.C == 16 * NA0 && (NA1 == 0 || p.a1.C == 16 * NA1);
-    auto convert = [&](auto interior_tag) {
-    constexpr bool IN = decltype(interior_tag)::value;
 #pragma unroll
     for (int c = 0; c < NA0; ++c) {
       const int c0 = c * 16 + gsel * 8;
-      const bool chv = IN || c0 < aS.C;
+      const bool chv = c0 < aS.C;
       Tab ta;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -200,9 +195,9 @@ __global__ __launch_bounds__(64 * NW, WGS) void conv_thin_kernel(HpfgConvArgs p,
       for (int i = 0; i < ND; ++i) {
         const int idx = tid + i * NTH, pix = idx >> 1;
         const int gy = ty0 + pix / HP - 1, gx = tx0 + pix % HP - 1;
-        const bool ok = IN || (idx < HP * HP * 2 && chv && gy >= 0 && gy < H && gx >= 0 && gx < W);      // (a thread without a piece stores nothing)
+        const bool ok = idx < HP * HP * 2 && chv && gy >= 0 && gy < H && gx >= 0 && gx < W;
         f32x4 v0, v1;
-        finish_piece<AK0>(v0, v1, raw[c][i], ta, aS, none, cxa, n, IN ? gy : clampi(gy, 0, H - 1), IN ? gx : clampi(gx, 0, W - 1), chv ? c0 : 0, ok);
+        finish_piece<AK0>(v0, v1, raw[c][i], ta, aS, none, cxa, n, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), chv ? c0 : 0, ok);
         if (idx < HP * HP * 2) {
           bf16x8 hi, lo;
           split8(v0, v1, hi, lo);
@@ -228,16 +223,16 @@ __global__ __launch_bounds__(64 * NW, WGS) void conv_thin_kernel(HpfgConvArgs p,
       for (int i = 0; i < ND; ++i) {
         const int idx = tid + i * NTH, pix = idx >> 1;
         const int gy = ty0 + pix / HP - 1, gx = tx0 + pix % HP - 1;
-        const bool inimg = IN || (idx < HP * HP * 2 && gy >= 0 && gy < H && gx >= 0 && gx < W);
+        const bool inimg = idx < HP * HP * 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
         int y0, y1, x0, x1;
         float wy1, wx1;
-        up_coord(IN ? gy : clampi(gy, 0, H - 1), p.a1.Hs, y0, y1, wy1);
-        up_coord(IN ? gx : clampi(gx, 0, W - 1), p.a1.Ws, x0, x1, wx1);
+        up_coord(clampi(gy, 0, H - 1), p.a1.Hs, y0, y1, wy1);
+        up_coord(clampi(gx, 0, W - 1), p.a1.Ws, x0, x1, wx1);
         const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
         const int o0 = (x0 - sx_base) * 16, o1 = (x1 - sx_base) * 16;
 #pragma unroll
         for (int c = 0; c < NA1; ++c) {
-          const bool ok = IN || (inimg && c * 16 + gsel * 8 < p.a1.C);
+          const bool ok = inimg && c * 16 + gsel * 8 < p.a1.C;
           const float* r0 = ldsU + c * (UBYTES / 4) + ((y0 - sy_base) * USW) * 16 + gsel * 8;
           const float* r1 = ldsU + c * (UBYTES / 4) + ((y1 - sy_base) * USW) * 16 + gsel * 8;
           const f32x4 a00 = *reinterpret_cast<const f32x4*>(r0 + o0), b00 = *reinterpret_cast<const f32x4*>(r0 + o0 + 4);
@@ -261,9 +256,6 @@ __global__ __launch_bounds__(64 * NW, WGS) void conv_thin_kernel(HpfgConvArgs p,
         }
       }
     }
-    };
-    if (interior) convert(std::true_type{});
-    else convert(std::false_type{});
     __syncthreads();
     // ---- every load of the next tile goes in flight
     {

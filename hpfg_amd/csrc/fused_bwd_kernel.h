@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
   if (GK == HPFG_KIND_DZ) hpfg_dz_rows_to_lds(aD, tabD, 16 * CO, 16 * CO, tid, NTH);      // (table rows, or k1 .. k3 from the backward sum accumulators)
   for (int i = tid; i < 2 * 16 * NA0 && AK0 != HPFG_KIND_PLAIN; i += NTH) {
     const int r = i / (16 * NA0), ch = i % (16 * NA0);
-    tabA[i] = ch < aS.C ? aS.bn[aS.bn_coff + (r == 0 ? HPFG_BN_SCALE : HPFG_BN_SHIFT) * aS.bn_stride + ch] * cxa.inv_keep : 0.f;      // (Dropout's 1 / (1 - p) folded in)
+    tabA[i] = ch < aS.C ? aS.bn[aS.bn_coff + (r == 0 ? HPFG_BN_SCALE : HPFG_BN_SHIFT) * aS.bn_stride + ch] : 0.f;
   }
 
   // ---- wgrad work split: pair (i, j) = (input tile, output tile); with fewer than 4 pairs the 9 taps are dealt over the waves
@@ -251,14 +251,10 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
     if (PFA < CI) issue(std::false_type{}, n, ty0, tx0, true);
     HPFG_TR(3)
     // ---- prefetched (and just requested) raw data -> producer chain -> bf16 hi / lo -> LDS
-    // (the dZ tile carries a halo: for a tile whose 18 x 18 region lies inside the image the in-image selects / clamps are compiled out)
-    const bool interior = ty0 > 0 && tx0 > 0 && ty0 + T < H && tx0 + T < W && aD.C == 16 * CO;
-    auto convert_dz = [&](auto interior_tag) {
-    constexpr bool IN = decltype(interior_tag)::value;
 #pragma unroll
     for (int c = 0; c < CO; ++c) {
       const int c0 = c * 16 + gsel * 8;
-      const bool chv = IN || c0 < aD.C;
+      const bool chv = c0 < aD.C;
       Tab tg;
       if (GK == HPFG_KIND_DZ) {
 #pragma unroll
@@ -274,9 +270,9 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
       for (int i = 0; i < ND; ++i) {
         const int idx = tid + i * NTH, pix = idx >> 1;
         const int gy = ty0 + pix / HP - 1, gx = tx0 + pix % HP - 1;
-        const bool ok = IN || (idx < HP * HP * 2 && chv && gy >= 0 && gy < H && gx >= 0 && gx < W);
+        const bool ok = idx < HP * HP * 2 && chv && gy >= 0 && gy < H && gx >= 0 && gx < W;
         f32x4 v0, v1;
-        finish_piece<GK>(v0, v1, rawD[c][i], tg, aD, none, cxg, n, IN ? gy : clampi(gy, 0, H - 1), IN ? gx : clampi(gx, 0, W - 1), chv ? c0 : 0, ok);
+        finish_piece<GK>(v0, v1, rawD[c][i], tg, aD, none, cxg, n, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), chv ? c0 : 0, ok);
         if (idx < HP * HP * 2) {
           bf16x8 hi, lo;
           split8(v0, v1, hi, lo);
@@ -286,9 +282,6 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
         }
       }
     }
-    };
-    if (interior) convert_dz(std::true_type{});
-    else convert_dz(std::false_type{});
     // (prefetched chunks come first: the ones requested at the top of this iteration get the time of that conversion to arrive)
 #pragma unroll
     for (int c = 0; c < NA0; ++c) {

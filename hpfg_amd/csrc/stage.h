@@ -209,7 +209,8 @@ __device__ __forceinline__ void finish_piece(f32x4& v0, f32x4& v1, const RawPiec
         h1 = ok ? h1 : 0u;
         need_ok = false;
       }
-      // (no multiply by 1 / (1 - p) here: LeakyReLU is positively homogeneous, so the callers fold it into the scale / shift rows they stage)
+      v0 = v0 * cx0.inv_keep;
+      v1 = v1 * cx0.inv_keep;
       keep_select4(v0, h0, thr);
       keep_select4(v1, h1, thr);
     }
@@ -235,7 +236,8 @@ __device__ __forceinline__ void finish_piece(f32x4& v0, f32x4& v1, const RawPiec
     if (a.drop_p > 0.f) {
       const uint32_t e = (uint32_t)(((n * a.Hs + gy) * a.Ws + gx) * a.C + c0);
       const uint32_t thr = drop_thresh(a, cx0);
-      // (1 / (1 - p) is folded into the k1 row by the callers: hpfg_dz_rows_to_lds)
+      ga = ga * cx0.inv_keep;
+      gb = gb * cx0.inv_keep;
       keep_select4(ga, a.drop_mask ? rp.dm[0] : hpfg_hash32(e >> 2, cx0.seed), thr);
       keep_select4(gb, a.drop_mask ? rp.dm[1] : hpfg_hash32((e + 4) >> 2, cx0.seed), thr);
     }

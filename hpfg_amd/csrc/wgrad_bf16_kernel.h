@@ -134,16 +134,7 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
   const int ca = ci0 + ga, cg = co0 + gg;
   const bool cva = ca < cin_total, cvg = cg < p.g.C;
   const bool a_up = CATA && ci0 >= p.a0.C;                // workgroup-uniform
-  if (!a_up) {
-    load_tables<SA>(ta, p.a0, cva ? ca : 0, true);
-    if (SA == HPFG_KIND_BNACT) {          // Dropout's 1 / (1 - p) folded into the rows (stage.h finish_piece does not multiply)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        ta.sc[h] = ta.sc[h] * cxa.inv_keep;
-        ta.sh[h] = ta.sh[h] * cxa.inv_keep;
-      }
-    }
-  }
+  if (!a_up) load_tables<SA>(ta, p.a0, cva ? ca : 0, true);
   if (GK == HPFG_KIND_DZ) {      // (table rows, or k1 .. k3 derived from the backward sum accumulators: HpfgAct.bn_acc)
     HpfgAct gs = p.g;          // this workgroup's 16 NJ output channels
     gs.bn_coff += co0;
