@@ -18,7 +18,7 @@ ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ = 
 OPT_CONV_THIN, OPT_FIRST_MFMA = 0, 1          # hpfg_set_option
 LOSS_NSUM = 32
 ACC_MAX_SHARDS = 8          # HPFG_ACC_MAX_SHARDS: a BatchNorm sum accumulator is long long [shards][2][C][2]
-VERSION = 130
+VERSION = 129
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -73,10 +73,6 @@ class AugSample(C.Structure):
 class BnAccDesc(C.Structure):
     _fields_ = [("acc", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
                 ("bn", C.c_void_p), ("C", C.c_int32), ("count", C.c_float), ("shards", C.c_int32), ("reserved", C.c_int32)]
-
-
-class UpDgradArgs(C.Structure):
-    _fields_ = [("d", ConvArgs), ("dup", C.c_void_p), ("dU", C.c_void_p), ("csum", C.c_void_p), ("dup_pstride", C.c_int32), ("C2", C.c_int32)]
 
 
 class BnAccBwdDesc(C.Structure):
@@ -193,8 +189,6 @@ PROTOTYPES = {
     "hpfg_upsample2x_bwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "hpfg_upsample2x_bwd_sums": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),
     "hpfg_upsample2x_bwd_blocks": (_i, [_i, _i, _i, _i]),
-    "hpfg_up_dgrad": (_i, [C.POINTER(UpDgradArgs), _p]),
-    "hpfg_up_dgrad_rows": (_i, [_i, _i, _i]),
     "hpfg_loss_blocks": (_i, [_i, _i, _i]),
     "hpfg_seg_loss_partials": (_i, [C.POINTER(LossArgs), _p]),
     "hpfg_seg_loss_finalize": (_i, [C.POINTER(LossArgs), _p]),

@@ -127,7 +127,6 @@ class UNetEngine:
         self.bn: Dict[str, torch.Tensor] = {s.name: torch.zeros(L.BN_ROWS, s.cout, **f32) for s in self.order if s.bn}
         nb = max(self.lib.hpfg_conv_stat_blocks(N, s.h, s.w) * 2 * s.cout_pad for s in self.order if s.bn)
         nb = max(nb, max(self.lib.hpfg_bn_bwd_blocks(N, s.h, s.w, s.cout) * 2 * s.cout for s in self.order if s.bn))
-        nb = max(nb, max(self.lib.hpfg_up_dgrad_rows(N, s.h, s.w) * 2 * s.cin for s in self.order if s.taps == 1))      # (hpfg_up_dgrad's backward-sum rows, legacy finalize path)
         self.partials = torch.empty(nb, **f32)
         self.sums = torch.empty(2 * 256, dtype=torch.float64, device=device)
         # packed weights (the first conv reads OIHW directly)
@@ -494,7 +493,7 @@ class UNetEngine:
 
     # ---------------------------------------------------------------------------------------------------------
     def _alloc_bwd(self):
-        key = (self.math, self.fused_bwd, os.environ.get("HPFG_UP_FUSE", "1"))      # what the slab layout depends on
+        key = (self.math, self.fused_bwd)      # what the slab layout depends on
         if self._bwd_alloc and self._bwd_alloc_key == key:
             return
         self._bwd_alloc_key = key
@@ -546,11 +545,8 @@ class UNetEngine:
         # bias gradients of the convs without BatchNorm (1x1 convs, out_conv): their per-block channel sums are summed by the same
         # launch, as pseudo layers {taps 1, Cin 1} (one kernel less per bias)
         self.bias_layers = [s for s in self.order if not s.bn]
-        # the 1x1 convs' bias rows come from the kernel that forms dU: the fused upsample-backward + input-gradient launch (hpfg_up_dgrad: one row per
-        # 8 x 8 tile and image) in the split-bf16 mode, the stand-alone upsample backward otherwise
-        self.up_fused = self.math == L.MATH_BF16X3 and os.environ.get("HPFG_UP_FUSE", "1") == "1"
-        self.csum_rows = {s.name: ((self.lib.hpfg_up_dgrad_rows(N, s.h, s.w) if self.up_fused else self.lib.hpfg_upsample2x_bwd_blocks(N, s.h, s.w, s.cout))
-                                   if s.taps == 1 else self.lib.hpfg_channel_sum_blocks(N * s.h * s.w, s.cout)) for s in self.bias_layers}
+        self.csum_rows = {s.name: (self.lib.hpfg_upsample2x_bwd_blocks(N, s.h, s.w, s.cout) if s.taps == 1
+                                   else self.lib.hpfg_channel_sum_blocks(N * s.h * s.w, s.cout)) for s in self.bias_layers}
         self.csum_part = {s.name: torch.empty(self.csum_rows[s.name] * s.cout, **f32) for s in self.bias_layers}
         descs = (L.SlabDesc * (len(self.order) + len(self.bias_layers)))()
         for d, s, sz in zip(descs, self.order, sizes):
@@ -700,27 +696,6 @@ class UNetEngine:
             self._fused_rows[stats_for] = rows
         self._run("dgrad:" + s.name, lambda: L.check(self.lib.hpfg_conv_fwd(C.byref(ca), self._stream()), f"dgrad[{s.name}]"))
 
-    def _up_dgrad(self, su: ConvSpec, dup: torch.Tensor, dup_ps: int, k: int, prev: str, stats_for: Optional[str]):
-        """hpfg_up_dgrad: dA[prev] = conv1x1^T(upsample^T(dup)); dU[k], the 1x1 conv's bias rows and (stats_for) the backward sums of `prev` ride along."""
-        ua = L.UpDgradArgs()
-        ca = ua.d
-        ca.math, ca.wpk, ca.out = self.math, L.ptr(self.wpk16_d[su.name]), L.ptr(self.dA[prev])
-        ca.out_pstride, ca.Cout, ca.CoutPad = su.cin, su.cin, su.cin_pad
-        ca.N, ca.H, ca.W, ca.taps = self.N, su.h, su.w, 1
-        ua.dup, ua.dup_pstride, ua.C2 = L.ptr(dup), dup_ps, su.cout
-        ua.dU, ua.csum = L.ptr(self.dU[k]), L.ptr(self.csum_part[su.name])
-        if stats_for is not None and self.fuse_bwd_stats and su.cin == su.cin_pad:
-            rows = self.lib.hpfg_up_dgrad_rows(self.N, su.h, su.w)
-            ca.bwd_stats, ca.bwd_of = 1, self._act_dz(stats_for, self.dA[prev], su.cin)
-            if self._accb_live:
-                ca.stat_acc, ca.stat_shards = L.ptr(self.accb_of[stats_for]), self.acc_shards[stats_for]
-            else:
-                if rows * 2 * su.cin > self.partials.numel():
-                    raise RuntimeError(f"up_dgrad[{su.name}]: {rows} rows of backward sums do not fit the partials workspace")
-                ca.stat_partials = L.ptr(self.partials)
-            self._fused_rows[stats_for] = rows
-        self._run("up_dgrad:" + su.name, lambda: L.check(self.lib.hpfg_up_dgrad(C.byref(ua), self._stream()), f"up_dgrad[{su.name}]"))
-
     def _slab_reduce(self, lo: int, hi: int, stream=None):
         """Sum the weight-gradient slabs of descriptors [lo, hi) into the gradient buffer (one launch)."""
         if hi <= lo:
@@ -785,23 +760,13 @@ class UNetEngine:
             else:
                 self._wgrad_dgrad(s1, g1, self.dcat[k])            # [dSkip | dUp]
                 dup, dup_ps = self.dcat[k].view(-1)[c2:], 2 * c2   # channel offset c2, pixel stride 2*c2
-            prev = enc_prefix(4) + ".4" if k == 1 else f"decoder.up{k - 1}.conv.conv_conv.4"
-            # the 1x1 conv is the only consumer of the block output below (the bottleneck also feeds the dense head of UNet_Plus)
-            stats_for = prev if (k > 1 or dfeat4 is None) else None
-            gu = self._act_plain(self.dU[k], c2, su.h, su.w)
-            if self.up_fused:
-                # ONE launch: upsample backward gathered into the A operand of the 1x1 conv's input gradient (+ dU for the weight gradient, the
-                # bias rows, the backward sums of the block below) -- instead of two dependent launches on the chain with dU in between
-                self._up_dgrad(su, dup, dup_ps, k, prev, stats_for)
-                if self._deferred is not None:
-                    self._deferred.append((su, gu))
-                else:
-                    self._wgrad(su, gu)
-                continue
             self._run("upbwd:" + su.name, lambda: L.check(self.lib.hpfg_upsample2x_bwd_sums(
                 L.ptr(dup), dup_ps, L.ptr(self.dU[k]), N, su.h, su.w, c2, L.ptr(self.csum_part[su.name]), st),
                 "upsample2x_bwd"))                               # + per-workgroup channel sums of dU: the 1x1 conv's bias gradient
-            self._wgrad_dgrad(su, gu, self.dA[prev], stats_for)
+            gu = self._act_plain(self.dU[k], c2, su.h, su.w)
+            prev = enc_prefix(4) + ".4" if k == 1 else f"decoder.up{k - 1}.conv.conv_conv.4"
+            # the 1x1 conv is the only consumer of the block output below (the bottleneck also feeds the dense head of UNet_Plus)
+            self._wgrad_dgrad(su, gu, self.dA[prev], prev if (k > 1 or dfeat4 is None) else None)
         if dfeat4 is not None:
             self.dA[enc_prefix(4) + ".4"].add_(dfeat4)
         defer = self._deferred is not None

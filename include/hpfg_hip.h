@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 130
+#define HPFG_VERSION 129
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -124,16 +124,6 @@ typedef struct HpfgFusedBwdArgs {   /* hpfg_fused_bwd: both gradients of a thin 
   float* slab;          /* [hpfg_fused_bwd_grid()][9][CinPad][CoutPad]: per-workgroup weight-gradient sums (hpfg_slab_reduce_multi) */
   int32_t Cin, CinPad, Cout, CoutPad;   /* of the layer: dW is [Cout][Cin][3][3] */
 } HpfgFusedBwdArgs;
-
-typedef struct HpfgUpDgradArgs {   /* hpfg_up_dgrad: upsample_bilinear2d backward + the 1x1 conv's input gradient in one launch (model/unet.py:50-56) */
-  HpfgConvArgs d;       /* the 1x1 dgrad as hpfg_conv_fwd takes it (wpk = wpk16_dgrad, out = dA of the block below, Cout / CoutPad = the conv's input
-                           channels, N / H / W = the LOW-resolution size, bwd_stats / bwd_of / stat_partials | stat_acc), except its source: d.a0 is
-                           ignored -- the operand dU is formed here from `dup` */
-  const float* dup;     /* gradient w.r.t. the upsampled tensor, [N, 2H, 2W, .] NHWC with dup_pstride floats per pixel (a channel slice of the concat gradient) */
-  float* dU;            /* out, or NULL: [N, H, W, C2] -- the 1x1 conv's weight gradient contracts it later */
-  float* csum;          /* out, or NULL: [hpfg_up_dgrad_rows()][C2] per-workgroup channel sums of dU (rows of the 1x1 conv's bias gradient) */
-  int32_t dup_pstride, C2;
-} HpfgUpDgradArgs;
 
 typedef struct HpfgSlabDesc {   /* one layer of hpfg_slab_reduce_multi: dw_oihw[co][ci][tap] = sum_s slab[s][tap][ci][co] */
   const float* slab;
@@ -273,9 +263,6 @@ int hpfg_upsample2x_bwd(const float* dUp, int dup_pstride, float* dU, int N, int
  * 1x1 conv in front of the upsample, model/unet.py:50; rows are summed by hpfg_slab_reduce_multi like hpfg_channel_sum_partials') */
 int hpfg_upsample2x_bwd_sums(const float* dUp, int dup_pstride, float* dU, int N, int Hl, int Wl, int C, float* csum_partials, void* stream);
 int hpfg_upsample2x_bwd_blocks(int N, int Hl, int Wl, int C);
-/* the two in one launch: dA = conv1x1^T(upsample^T(dup)) (+ dU, the bias-gradient rows and the BatchNorm-backward sums of the layer below) */
-int hpfg_up_dgrad(const HpfgUpDgradArgs* args, void* stream);
-int hpfg_up_dgrad_rows(int N, int H, int W);               /* rows of `csum` (and of stat_partials): one per 8 x 8 low-resolution tile and image */
 
 /* ---- data parallel: peer mailbox exchange (csrc/peer.h) ------------------------------------------------------------------------
  * The reference is single-device (main.py:44); under data parallel in the global-batch mode every BatchNorm layer's sums and the loss sums
