@@ -543,7 +543,7 @@ def main():
         dp = parallel.init_from_env(dev, backend=os.environ.get("HPFG_DP_BACKEND") or None)
         dp.force_sync = bool(a.force_sync)
         # N > 1 default = the mode north_star names: BatchNorm / loss sums exchanged (global-batch equivalence), gradient buckets overlapped with backward
-        dp.sync_bn = bool((world > 1 and not a.local_bn) or a.sync_bn or (a.force_sync and os.environ.get("HPFG_BENCH_LOCAL_BN", "0") != "1"))
+        dp.sync_bn = bool((world > 1 and not a.local_bn) or a.sync_bn or (a.force_sync and not a.local_bn))
         dp.overlap = bool(world > 1 or a.overlap) and not a.no_overlap
         if dp.sync_bn and not a.no_p2p:
             dp.enable_peer_exchange()

@@ -586,7 +586,7 @@ extern "C" int hpfg_upsample2x_bwd_sums(const float* dUp, int dup_pstride, float
                                         void* stream) {
   HPFG_ARG_CHECK(dUp && dU && C % 4 == 0 && C >= 4 && N > 0 && Hl > 0 && Wl > 0 && Hl + Wl <= UPB_MAXDIM, "upsample2x_bwd: bad args");
   HPFG_ARG_CHECK(!csum_partials || (C <= 256 && 256 % (C / 4) == 0), "upsample2x_bwd: channel sums need C/4 to divide 256 (C=%d)", C);
-  static const int xcd_aware = getenv("HPFG_UPB_XCD") ? atoi(getenv("HPFG_UPB_XCD")) : 1;      // 0: contiguous runs dealt to the XCDs round-robin (A/B)
+  const int xcd_aware = 1;      // (0: contiguous runs dealt to the XCDs round-robin -- an A/B of round 3, DESIGN_HISTORY.md)
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3(hpfg_upsample2x_bwd_blocks(N, Hl, Wl, C)), dim3(256), 0, (hipStream_t)stream, dUp, dup_pstride, dU, N,
                      Hl, Wl, C, csum_partials, xcd_aware);
   return hpfg_launch_status("upsample_bwd_kernel");

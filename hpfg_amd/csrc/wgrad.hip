@@ -152,13 +152,9 @@ extern "C" int hpfg_wgrad_splits(int N, int H, int W, int CinPad, int CoutPad, i
   hpfg_wg16::pick_shape(CinPad, CoutPad, &ni, &nj);
   long pairs = (long)(CinPad / (16 * ni)) * (CoutPad / (16 * nj));
   long nwork = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-  static const long resident = getenv("HPFG_WGRAD_TARGET") ? atol(getenv("HPFG_WGRAD_TARGET")) : 512;
-  long target = resident / pairs;           // exactly one resident round of workgroups (bf16x3 kernel: 2 per CU by registers)
+  const long resident = 512;                // exactly one resident round of workgroups: 2 per CU by registers (3 per CU spills 8 .. 102
+  long target = resident / pairs;           // VGPRs and costs the step +8 %, profiles/r04_bn_acc.txt)
   if (target < 1) target = 1;
-  // every workgroup writes a slab of its own (and the reduction reads it back): with fewer than `min_items` pixel tiles per workgroup the
-  // slab bytes exceed the input bytes of the launch (32-channel slices: 37 KB of slab against 39 KB of input per tile)
-  static const long min_items = getenv("HPFG_WGRAD_MIN_ITEMS") ? atol(getenv("HPFG_WGRAD_MIN_ITEMS")) : 1;
-  if (min_items > 1 && target > (nwork + min_items - 1) / min_items) target = (nwork + min_items - 1) / min_items;
   if (target > nwork) target = nwork;
   long per_block = (nwork + target - 1) / target;   // work items per workgroup
   return (int)((nwork + per_block - 1) / per_block);

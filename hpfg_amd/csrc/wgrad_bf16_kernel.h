@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
   // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (the linear workgroup id is x + S * (...), S % 8 == 0, so
   // x % 8 names the XCD and every (ci, co) pair of one pixel range already shares an L2).  Give every XCD a CONTIGUOUS range of pixel tiles,
   // swept side by side by its workgroups, so that tiles sharing a halo meet in one L2 as well.
-  const int nxcd = (!(p.math & 0x8000) && gridDim.x % 8 == 0) ? 8 : 1;      // (flag: linear mapping, A/B runs)
+  const int nxcd = gridDim.x % 8 == 0 ? 8 : 1;
   const int per_x = (nwork + nxcd - 1) / nxcd, wstep = (int)gridDim.x / nxcd;
   const int wend = ((int)blockIdx.x % nxcd + 1) * per_x < nwork ? ((int)blockIdx.x % nxcd + 1) * per_x : nwork;
   int wk = ((int)blockIdx.x % nxcd) * per_x + (int)blockIdx.x / nxcd;
@@ -454,9 +454,7 @@ inline void pick_shape(int CinPad, int CoutPad, int* ni, int* nj) {
 
 template <int AK, int GK, int TAPS>
 int launch_wgrad16_taps(const HpfgWgradArgs& a_in, hipStream_t st) {
-  static const bool linear = getenv("HPFG_WGRAD_XCD") && atoi(getenv("HPFG_WGRAD_XCD")) == 0;
   HpfgWgradArgs a = a_in;
-  if (linear) a.math |= 0x8000;
   int ni, nj;
   pick_shape(a.CinPad, a.CoutPad, &ni, &nj);
   const int tx = (a.W + TW - 1) / TW, ty = (a.H + TH - 1) / TH;

@@ -151,8 +151,7 @@ class UNetEngine:
         # shards: the producers' same-address atomics want many (ONE shard: +0.3 ms per step, two: +0.09), every consumer workgroup's prologue
         # wants few (32 bytes per channel and shard).  Measured in the step (profiles/r04_bn_acc.txt): 8 everywhere beats 4 and beats 8 / 4 / 2 by
         # channel count -- the contention costs more than the prologue reads.
-        force = int(os.environ.get("HPFG_ACC_SHARDS", "0"))
-        self.acc_shards = {s.name: (force or L.ACC_MAX_SHARDS) for s in self.bn_layers}
+        self.acc_shards = {s.name: L.ACC_MAX_SHARDS for s in self.bn_layers}
         self.acc_all = torch.zeros(sum(self.acc_shards[s.name] * 4 * s.cout for s in self.bn_layers), dtype=torch.int64, device=device)
         self.acc_of, off = {}, 0
         for s in self.bn_layers:
@@ -183,7 +182,7 @@ class UNetEngine:
         self.x: Optional[torch.Tensor] = None
         self.world = 1
         # BatchNorm-backward sums of the layer below from the dgrad epilogue (bf16x3 kernels) instead of a streaming pass of their own
-        self.fuse_bwd_stats = int(os.environ.get("HPFG_FUSE_BWD_STATS", "1"))      # 2: also the register-starved 32-channel instantiation
+        self.fuse_bwd_stats = 1      # 0: a streaming pass per layer (tests); 2: also the register-starved 32-channel instantiation
         self._fused_rows: Dict[str, int] = {}
         # thin 3x3 layers (16-pixel-aligned, <= 64 input / 32 output channels, split-bf16 math): ONE kernel produces the input gradient, the
         # weight-gradient slabs and the backward sums of the layer below from a single staging of dZ (hpfg_fused_bwd)
@@ -204,7 +203,6 @@ class UNetEngine:
         # themselves -- no collective between the kernels.  peer = the context, peer_base = first of this engine's 2 x 18 mailbox slots,
         # xepoch = device word counting this engine's train-mode forwards (the epoch of every slot use of that forward / its backward)
         self.peer, self.peer_base, self.xepoch = None, 0, None
-        self._skip_fin, self._fin_done = os.environ.get("HPFG_SKIP_FINALIZE", "0") == "1", {}
         self.marks: Optional[MarkLog] = None      # bench.py: device time stamps around every conv / dgrad / wgrad / BatchNorm launch
 
     # ---------------------------------------------------------------------------------------------------------
@@ -352,9 +350,6 @@ class UNetEngine:
                                                 "bn_acc_finalize"))
 
     def _finalize_bn(self, s: ConvSpec, nblk: int, track: bool):
-        if self._skip_fin and self._fin_done.get(s.name):      # timing experiment only (HPFG_SKIP_FINALIZE=1): stale tables
-            return
-        self._fin_done[s.name] = True
         st = self._stream()
         count = float(self.N * s.h * s.w * self.world)
         g, b = self.params[f"{s.bn}.weight"], self.params[f"{s.bn}.bias"]
@@ -386,8 +381,7 @@ class UNetEngine:
         if seed_step is not None and seed_step != SEED_BUMP:
             self.seed_dev.fill_(int(seed_step) & 0x7FFFFFFF)
         counters, self.bump_counters = self.bump_counters, None
-        self._acc_live = bool(train and self.bn_acc_on and self.math == L.MATH_BF16X3 and self.peer is None and not (self.world > 1 or self.force_sync)
-                              and not self._skip_fin)
+        self._acc_live = bool(train and self.bn_acc_on and self.math == L.MATH_BF16X3 and self.peer is None and not (self.world > 1 or self.force_sync))
         if self._acc_live:
             if self._acc_dirty:          # a forward that never reached its finalize launch (an exception): start from zero (hpfg_bn_acc_finalize zeroes otherwise)
                 self.acc_all.zero_()
@@ -600,9 +594,6 @@ class UNetEngine:
         count = float(self.N * s.h * s.w * self.world)
         gam = self.params[f"{s.bn}.weight"]
         dg, db = self.grads[f"{s.bn}.weight"], self.grads[f"{s.bn}.bias"]
-        if self._skip_fin and self._fin_done.get("b:" + s.name):
-            return g
-        self._fin_done["b:" + s.name] = True
         if self.peer is not None and (self.world > 1 or self.force_sync):
             px = self.peer.peer_desc(self.peer_base + 2 * self._bn_index(s) + 1, self.xepoch)
             self._run("bn_bfin:" + s.name, lambda: L.check(self.lib.hpfg_bn_bwd_finalize_x(
@@ -719,8 +710,7 @@ class UNetEngine:
         st = self._stream()
         N = self.N
         sp = self.specs
-        self._accb_live = bool(self.bn_acc_on and self.math == L.MATH_BF16X3 and self.peer is None and not (self.world > 1 or self.force_sync)
-                               and not self._skip_fin)
+        self._accb_live = bool(self.bn_acc_on and self.math == L.MATH_BF16X3 and self.peer is None and not (self.world > 1 or self.force_sync))
         if self._accb_live:
             if self._accb_dirty:          # a backward pass that did not reach its finalize launch (an exception): start from zero
                 self.accb_all.zero_()
@@ -782,8 +772,7 @@ class UNetEngine:
                 if hi == len(self._slab_host):          # the decoder batch: out_conv's bias sums ride along
                     csum(self._side.cuda_stream)
                 for s_, g_ in self._deferred:
-                    if os.environ.get("HPFG_SKIP_WGRAD", "0") != "1":       # timing experiment only (stale gradients): what the queued launches cost
-                        self._wgrad(s_, g_, on_side=True)
+                    self._wgrad(s_, g_, on_side=True)
                 self._slab_reduce(lo, hi, self._side.cuda_stream)
                 self._side_used = True
 

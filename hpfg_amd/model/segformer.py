@@ -25,7 +25,6 @@ Tokens are kept as [B, N, C] == NHWC throughout.  Stochastic depth and the head'
 """
 from __future__ import annotations
 
-import os
 
 import torch
 import torch.nn as nn
@@ -88,7 +87,7 @@ class PatchEmbed(nn.Module):
         self.k, self.s = patch_size, stride
 
     def forward(self, x):
-        """x NHWC [B,H,W,C] -> tokens [B, H'*W', c2]: HIP im2col, library GEMM, HIP LayerNorm."""
+        """x NHWC [B,H,W,C] -> tokens [B, H'*W', c2]: HIP im2col, split-bf16 MFMA GEMM (csrc/gemm.hip), HIP LayerNorm."""
         B, H, W, _ = x.shape
         Ho, Wo = (H + 2 * (self.k // 2) - self.k) // self.s + 1, (W + 2 * (self.k // 2) - self.k) // self.s + 1
         wt = self.proj.weight.permute(0, 2, 3, 1).reshape(self.proj.weight.shape[0], -1)          # rows ordered (u, v, c) like the patches
@@ -178,6 +177,7 @@ class SegFormerHead(nn.Module):
         for i, dim in enumerate(dims):
             self.add_module(f"linear_c{i + 1}", FFN(dim, embed_dim))
         self.linear_fuse = ConvModule(embed_dim * 4, embed_dim)
+        self.fuse_lowres = True      # False: the reference's literal concat + one GEMM (tests compare both forms with the oracle)
         self.linear_pred = nn.Conv2d(embed_dim, num_classes, 1)
         self.dropout = nn.Dropout2d(0.1)
 
@@ -187,7 +187,7 @@ class SegFormerHead(nn.Module):
         cv, bn = self.linear_fuse.conv, self.linear_fuse.bn
         wf = cv.weight.reshape(cv.weight.shape[0], -1)                           # [E, 4E]; the concat order is c4, c3, c2, c1
         E = wf.shape[1] // len(feats)
-        if os.environ.get("HPFG_HEAD_FUSE_LOWRES", "1") == "1":
+        if self.fuse_lowres:
             # linear_fuse(cat(up(y4), up(y3), up(y2), y1)) = sum_i up(W_i y_i): the bias-free 1x1 conv acts per pixel and the bilinear resize per
             # channel, so they commute -- each stage's slice of the fuse weights is applied at the stage's own resolution (1/4 .. 1/64 of the
             # pixels) and only the E-channel results are resized and added.  No [B, H*W, 4E] concat (411 MB at 32 x 56 x 56 tokens) is written,

@@ -305,8 +305,8 @@ class UNet(nn.Module):
         rank = self.dp.rank if self.dp is not None else 0
         eng.base_seed = (self.dropout_seed + 0x632BE5AB * rank) & 0x7FFFFFFF      # every data-parallel rank draws its own masks too
         eng.math = L.MATH_BF16X3 if self.math == "bf16x3" else L.MATH_F32
-        eng.defer_wgrad = bool(getattr(self, "defer_wgrad", False)) and os.environ.get("HPFG_DEFER_WGRAD", "1") == "1"
-        eng.pack_overlap = bool(getattr(self, "_alone", False)) and os.environ.get("HPFG_PACK_OVERLAP", "1") == "1"
+        eng.defer_wgrad = bool(getattr(self, "defer_wgrad", False))
+        eng.pack_overlap = bool(getattr(self, "_alone", False))
         ext = self.external_dropout_masks
         if isinstance(ext, (list, tuple)):      # tests: one mask set per forward, consumed in order (several forwards per step)
             k = getattr(self, "_ext_mask_idx", 0)

@@ -155,7 +155,7 @@ class _StepBase:
         backward node hands autograd no gradient tensors (they are written in place into the flat buffer), so autograd has nothing to
         synchronise that stream with: the step joins it explicitly before anything reads the gradients -- and, inside a capture, before
         the capture ends (an unjoined forked stream is what made hipStreamEndCapture of the HPFG step fault)."""
-        if stream is not None and self.overlap and os.environ.get("HPFG_STUDENT_OVERLAP", "1") == "1":
+        if stream is not None and self.overlap:
             torch.cuda.current_stream(self.dev).wait_stream(stream)
 
     def _attach(self, model, alone: bool = False):
@@ -176,8 +176,7 @@ class _StepBase:
         """optimizer.step(); update_ema_variables(model, ema_model, ...) -- the tail of every Mean-Teacher-family iteration
         (2017_03_NIPS_Mean-Teacher_ACDC.py:108-113) -- as ONE launch over the student's flat buffers where the optimizer offers it."""
         fs, ft = getattr(self.model, "flat_params", None), getattr(self.ema_model, "flat_params", None)
-        if (os.environ.get("HPFG_FUSE_SGD_EMA", "1") == "1" and isinstance(self.optimizer, FusedSGD) and fs is not None and ft is not None
-                and fs.numel() == ft.numel() and fs.is_cuda):
+        if isinstance(self.optimizer, FusedSGD) and fs is not None and ft is not None and fs.numel() == ft.numel() and fs.is_cuda:
             self.optimizer.step(push_lr=False, ema=(ft, fs.numel(), self.sc.view(S_ALPHA)))
         else:
             self.optimizer.step(push_lr=False)
@@ -535,7 +534,7 @@ class CPSStep(_StepBase):
         """Everything up to (not including) the gradient exchange."""
         nl = label_img.shape[0]
         x = cat_batch(label_img, unlabel_img)
-        if self.overlap and os.environ.get("HPFG_STUDENT_OVERLAP", "1") == "1":
+        if self.overlap:
             # the two students are independent until the losses: the second one's forward runs on the side stream, and autograd runs its
             # backward there too (a backward node executes on the stream of its forward), so both chains of small kernels overlap
             cur = torch.cuda.current_stream(self.dev)
@@ -629,7 +628,7 @@ class HPFGStep(_StepBase):
         nl = label_img.shape[0]
         mix_un = cutmix_blend(label_img1, img_unlabel, cutmix_mask)
         batch_mix = torch.cat([label_img, mix_un], 0)
-        split = self.overlap and os.environ.get("HPFG_STUDENT_OVERLAP", "1") == "1"
+        split = self.overlap
         if split:      # student 1 (fed the CutMix batch) is independent of student 2 and the teacher until the losses: a stream of its own,
             # forward and -- through autograd, which runs a backward node on the stream of its forward -- backward (see CPSStep)
             cur = torch.cuda.current_stream(self.dev)
@@ -724,7 +723,7 @@ class S4CVNetStep(_StepBase):
         nl = label_img.shape[0]
         x = cat_batch(label_img, unlabel_img)
         ot = self._teacher_forward(self.ema_model, noise_add(unlabel_img, noise))
-        if self.overlap and os.environ.get("HPFG_STUDENT_OVERLAP", "1") == "1":      # the U-Net on a stream of its own, forward and backward (see CPSStep)
+        if self.overlap:      # the U-Net on a stream of its own, forward and backward (see CPSStep)
             cur = torch.cuda.current_stream(self.dev)
             if getattr(self, "side2", None) is None:
                 self.side2 = torch.cuda.Stream(device=self.dev)
@@ -836,7 +835,7 @@ class GraphedStep:
             self.graphs, self.bucket_after = [self.graph], []
             # the bucket chain ends one graph and begins the next in the middle of backward: only legal while no second stream is forked
             # there, i.e. for steps with one trainable network (two students back-propagate on two streams: one exchange after both)
-            overlap = (bool(getattr(dp, "overlap", False)) and os.environ.get("HPFG_DP_CHAIN", "1") == "1"
+            overlap = (bool(getattr(dp, "overlap", False))
                        and sum(1 for m in self._models() if any(p.requires_grad for p in m.parameters())) == 1)
             if overlap:
                 # the boundary runs on autograd's device thread: ending a capture from another thread than the one that began it

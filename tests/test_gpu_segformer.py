@@ -40,14 +40,14 @@ def test_state_dict_and_golden_fixture(golden_dir):
         assert np.abs(got - ref).max() < 2e-3 * max(1.0, float(np.abs(ref).max())), (k, got, ref)
 
 
-@pytest.mark.parametrize("size,B,head", [(224, 2, "1"), (96, 3, "1"), (96, 3, "0")])
-def test_train_forward_backward_vs_oracle(size, B, head, monkeypatch):
+@pytest.mark.parametrize("size,B,head", [(224, 2, True), (96, 3, True), (96, 3, False)])
+def test_train_forward_backward_vs_oracle(size, B, head):
     """Full-size tokens (3136 / 784 / 196 / 49 queries against 49 keys at 224x224): logits, loss and every gradient tensor.
-    head: HPFG_HEAD_FUSE_LOWRES -- "1" (default) applies linear_fuse per stage at the stage's resolution and adds the resized maps, "0" is the
+    head: SegFormerHead.fuse_lowres -- True (default) applies linear_fuse per stage at the stage's resolution and adds the resized maps, False is the
     reference's literal concat + one GEMM (model/segformer.py:309-315); the oracle follows the reference's form, both must agree with it."""
-    monkeypatch.setenv("HPFG_HEAD_FUSE_LOWRES", head)
     torch.manual_seed(5)
     m = SegFormer(image_size=[size, size], in_channels=1, num_classes=4).to(DEV)
+    m.decoder.fuse_lowres = head
     st = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(size)
     x = torch.randn(B, 1, size, size, generator=g)

@@ -376,12 +376,7 @@ def test_sup224_trace_cfg1_as_written(golden_dir, math):
     with torch.no_grad():
         fin = m(xd).cpu()
     err = maxerr(fin[:, :, ::8, ::8], torch.from_numpy(d["final_eval_logits_sub"]))
-    if err >= TOL and math != "f32":          # ten SGD steps: bound the split-bf16 mode by the oracle's own sensitivity (control run, ~30 s)
-        nom = R.replay_sup224(d)["final_eval_logits"]
-        drift = max(maxerr(R.replay_sup224(d, s)["final_eval_logits"], nom) for s in R.CONTROL_SEEDS)
-        assert err < TOL + 5.0 * drift, (err, drift)
-    else:
-        assert err < TOL, err
+    assert err < TOL, err                     # flat 1e-3 in both math modes (224 x 224: >= 1568 samples per BatchNorm channel)
     want = R.unpack_labels2(d["final_pred"], fin[:, 0].numel())
     agree = float((fin.argmax(1).reshape(-1).numpy().astype(np.uint8) == want).mean())
     assert agree > 0.9995, agree

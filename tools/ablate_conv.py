@@ -1,5 +1,5 @@
 """Per-layer timing of the conv kernels of the U-Net (GPU only, diagnostics).  QUICK=1: just the launch time of each layer in LAYERS
-(default kernels; set HPFG_SMALL_BN to compare variants).  Without QUICK: a coarse ablation through the
+(default kernels).  Without QUICK: a coarse ablation through the
 HpfgConvArgs.math debug bits that still exist -- 0x100 no output stores, 0x400 staged pieces forced to zero (the loads are
 still issued since the staging became branch-free), 0x1000 no BatchNorm partial sums; 0x200 / 0x800 are no-ops kept for old logs.
 For where the time goes inside a launch use tools/trace_conv.py (in-kernel timeline) instead."""
