@@ -289,6 +289,9 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
   HPFG_ARG_CHECK((a->math & 0xff) != HPFG_MATH_BF16X3 || !(a->a0.mode == HPFG_ACT_BNACT || a->a0.mode == HPFG_ACT_BNACT_POOL || a->a0.mode == HPFG_ACT_DZ) ||
                      a->a0.C <= 256,
                  "conv_fwd(bf16x3): a BatchNorm'd source has at most 256 channels (got %d)", a->a0.C);
+  HPFG_ARG_CHECK(!a->stage_out || ((a->math & 0xff) == HPFG_MATH_BF16X3 && a->taps == 9 && hpfg_kind_of(a->a0, a->a1) > HPFG_KIND_PLAIN &&
+                                    (a->a0.C + a->a1.C) % 8 == 0 && (a->H % 16 || a->W % 16)),
+                 "conv_fwd: stage_out is a feature of the 3x3 bf16x3 kernels (non-PLAIN source, channels a multiple of 8, H or W not a multiple of 16)");
   hipStream_t st = (hipStream_t)stream;
   if (a->bwd_stats) {
     const int kind = hpfg_kind_of(a->a0, a->a1);

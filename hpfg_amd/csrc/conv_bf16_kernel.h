@@ -71,6 +71,19 @@ __device__ __forceinline__ void store_piece(unsigned char* buf, const Piece& q, 
   *reinterpret_cast<bf16x8*>(buf + q.lds + C::PLANE) = lo;
 }
 
+// HpfgConvArgs.stage_out: the staged value of an interior, in-image piece (the virtual input of a forward conv, the dZ of a dgrad) goes to
+// memory as fp32 as well; the layer's weight gradient reads it as a PLAIN source.  Halo pieces belong to a neighbouring tile's interior;
+// `on` is workgroup-uniform (output-channel slice 0 only).
+template <class C>
+__device__ __forceinline__ void stage_side_store(const HpfgConvArgs& p, bool on, const Piece& q, const f32x4& v0, const f32x4& v1, int n, int gy,
+                                                 int gx, int c0, bool ok) {
+  if (on && ok && q.ly >= 0 && q.ly < C::TH && q.lx >= 0 && q.lx < C::TW) {
+    float* d = p.stage_out + (((long)n * p.H + gy) * p.W + gx) * (p.a0.C + p.a1.C) + c0;
+    *reinterpret_cast<f32x4*>(d) = v0;
+    *reinterpret_cast<f32x4*>(d + 4) = v1;
+  }
+}
+
 template <class C>
 __device__ __forceinline__ void load_b(bf16x8 (&bh)[C::NI], bf16x8 (&bl)[C::NI], const bf16x8* wpk, int ks, int ntn, int nt0, int lane) {
 #pragma unroll
@@ -288,6 +301,11 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
   const int H = p.H, W = p.W;
   const int ntiles = tiles_x * tiles_y, nwork = ntiles * p.N;
   const ActCtx cx0 = make_ctx(p.a0);
+  // HpfgConvArgs.stage_out (the 4 x 16-pixel-tile kernels of the sizes that are not multiples of 16 only: the engine's aligned layers run the
+  // fused / thin kernels, and the aligned instantiations have no registers to spare): this workgroup also stores what it stages (slice 0 only)
+  constexpr bool SIDE = KIND != HPFG_KIND_PLAIN && C::TH == 4;
+  const bool dzw = SIDE && p.stage_out != nullptr && cb == 0;
+  (void)dzw;
 #ifdef HPFG_TRACE
   const bool tr_on = (p.math & 0x2000) && tid == 0;
   unsigned long long* tr_buf = reinterpret_cast<unsigned long long*>(p.stat_partials) + 256 * ((long)blockIdx.y * gridDim.x + blockIdx.x);
@@ -389,6 +407,7 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
       const int gyc = clampi(gy, 0, H - 1), gxc = clampi(gx, 0, W - 1);
       finish_piece<KIND>(v0, v1, raw0[i], tab, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
       store_piece<C, KIND>(lds, pc[i], v0, v1);
+      if constexpr (SIDE) stage_side_store<C>(p, dzw, pc[i], v0, v1, n, gyc, gxc, c0c, ok);
     }
   }
   // B-fragment ring: the fragments of k-step g + BD are requested while k-step g computes (BD = ring size - 1 k-steps of latency
@@ -501,6 +520,7 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
               f32x4 v0, v1;       // also on the last item (more == false): the parked piece lands in the unused buffer, no branch
               finish_piece<SK>(v0, v1, raw[i & 1], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
               store_piece<C, SK>(nxt, pc[i], v0, v1);
+              if constexpr (SIDE) stage_side_store<C>(p, dzw, pc[i], v0, v1, nn, gy, gx, c0c, ok);
             }
             if (s < C::NLD) {
               const int i = s < C::NLD ? s : 0;
@@ -551,6 +571,7 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
             v1[j] = ok ? v1[j] : 0.f;
           }
           store_piece<C>(nxt, pc[i], v0, v1);
+          if constexpr (SIDE) stage_side_store<C>(p, dzw, pc[i], v0, v1, nn, gy, gx, c0c, ok);
         }
       } else if (DEEP) {      // also on the last item: the pieces land in the unused buffer
 #pragma unroll
@@ -560,6 +581,7 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
           f32x4 v0, v1;
           finish_piece<SK>(v0, v1, raw[DEEP ? i : 0], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
           store_piece<C, SK>(nxt, pc[i], v0, v1);
+          if constexpr (SIDE) stage_side_store<C>(p, dzw, pc[i], v0, v1, nn, gy, gx, c0c, ok);
         }
       }
       HPFG_TR(7)

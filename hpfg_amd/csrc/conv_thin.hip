@@ -22,7 +22,7 @@ bool enabled() { return hpfg_opt(HPFG_OPT_CONV_THIN) != 0; }      // (tests swit
 
 // HPFG_THIN_NONE: this layer is not one of the kernel's shapes (the caller falls through to conv_bf16x3_kernel)
 int hpfg_conv_thin_try(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
-  if (!enabled() || a.taps != 9 || a.H % T || a.W % T || a.bwd_stats || a.out_split || (a.math & ~0xff)) return HPFG_THIN_NONE;
+  if (!enabled() || a.taps != 9 || a.H % T || a.W % T || a.bwd_stats || a.out_split || a.stage_out || (a.math & ~0xff)) return HPFG_THIN_NONE;
   if (a.Cout % 4 || a.out_pstride % 4 || a.CoutPad > 64) return HPFG_THIN_NONE;
   const int cin = a.a0.C + a.a1.C, ci = cin / 16, co = a.CoutPad / 16;
   if (cin % 16 || a.a0.pstride % 4) return HPFG_THIN_NONE;

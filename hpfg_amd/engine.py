@@ -187,6 +187,14 @@ class UNetEngine:
         # thin 3x3 layers (16-pixel-aligned, <= 64 input / 32 output channels, split-bf16 math): ONE kernel produces the input gradient, the
         # weight-gradient slabs and the backward sums of the layer below from a single staging of dZ (hpfg_fused_bwd)
         self.fused_bwd = os.environ.get("HPFG_FUSED_BWD", "1") == "1"
+        # HpfgConvArgs.stage_out: the separate dgrad of a 3x3 layer also stores the dZ it stages, and (act_side) its forward conv the virtual
+        # input it stages; the layer's weight gradient reads those tensors as PLAIN sources instead of deriving both again -- BatchNorm,
+        # LeakyReLU, Dropout, max-pool / bilinear taps forward, their backward for dZ -- in every (input slice x output slice) workgroup
+        self.dz_side = os.environ.get("HPFG_DZ_SIDE", "1") == "1"
+        self.act_side = os.environ.get("HPFG_ACT_SIDE", "1") == "1"
+        self.dzbuf: Dict[str, torch.Tensor] = {}
+        self.actbuf: Dict[str, torch.Tensor] = {}
+        self._act_live: set = set()      # layers whose actbuf this forward wrote
         # set by the model (UNet.defer_wgrad, which the single-network step objects switch on).  Not with two trainable networks
         # back-propagating on two streams: the fork below would then leave a FORKED stream, and an event wait between two non-origin
         # streams of a capture makes hipStreamEndCapture fault on ROCm 7.2 (tools/nested_fork_probe.py reproduces it without this code)
@@ -375,6 +383,8 @@ class UNetEngine:
         assert x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (self.N, self.in_ch, self.H, self.W), (x.shape, x.dtype, x.device)
         self.x = x
         self.train_mode = train
+        self._act_live = set()
+        self._stage_inputs = bool(train and needs_grad and self.act_side and self.math == L.MATH_BF16X3)
         self.dropout_on = train if dropout is None else dropout
         # seed_step: None = leave the seed word alone; SEED_BUMP = advance it on the device (a step being captured into a hipGraph: every
         # replay then draws new masks); otherwise the host's per-forward counter value
@@ -455,6 +465,12 @@ class UNetEngine:
             ca = self._conv_args(s, out, want_stats and not acc)
             if acc:
                 ca.stat_acc, ca.stat_shards = L.ptr(self.acc_of[s.name]), self.acc_shards[s.name]
+            if self._stage_inputs and self._side_layer(s) and s.cin % 8 == 0 and ca.a0.mode != L.ACT_PLAIN:
+                buf = self.actbuf.get(s.name)
+                if buf is None:
+                    buf = self.actbuf[s.name] = torch.empty(self.N, s.h, s.w, s.cin, dtype=torch.float32, device=self.dev)
+                ca.stage_out = L.ptr(buf)
+                self._act_live.add(s.name)
             self._run("fwd:" + s.name, lambda: L.check(self.lib.hpfg_conv_fwd(C.byref(ca), st), f"conv_fwd[{s.name}]"))
             if want_stats and not acc:
                 nblk = self.lib.hpfg_conv_stat_rows(C.byref(ca))
@@ -614,12 +630,27 @@ class UNetEngine:
         """Both gradients of layer s from the same dZ source (they only read it, so their order is free)."""
         if s.name in self.fused_grid:
             return self._fused_bwd(s, g, dgrad_out, stats_for, out2)
+        dz = None
+        if self.dz_side and self.math == L.MATH_BF16X3 and self._side_layer(s) and g.mode == L.ACT_DZ and s.cout % 8 == 0:
+            dz = self.dzbuf.get(s.name)
+            if dz is None:
+                dz = self.dzbuf[s.name] = torch.empty(self.N, s.h, s.w, s.cout, dtype=torch.float32, device=self.dev)
         if self._deferred is not None:      # decoder half: the weight gradient is queued for the side stream (see backward())
-            self._dgrad(s, g, dgrad_out, stats_for, out2)
-            self._deferred.append((s, g))
+            self._dgrad(s, g, dgrad_out, stats_for, out2, stage_out=dz)
+            self._deferred.append((s, g if dz is None else self._act_plain(dz, s.cout, s.h, s.w)))
         else:
-            self._wgrad(s, g)
-            self._dgrad(s, g, dgrad_out, stats_for, out2)
+            if dz is not None:
+                self._dgrad(s, g, dgrad_out, stats_for, out2, stage_out=dz)
+                self._wgrad(s, self._act_plain(dz, s.cout, s.h, s.w))
+            else:
+                self._wgrad(s, g)
+                self._dgrad(s, g, dgrad_out, stats_for, out2)
+
+    @staticmethod
+    def _side_layer(s: ConvSpec) -> bool:
+        """3x3 layers below the 16-pixel-aligned resolutions: separate dgrad + wgrad on the persistent conv kernel (the aligned ones run the
+        fused / thin kernels, which stage input and dZ once for both gradients already)."""
+        return s.taps == 9 and bool(s.h % 16 or s.w % 16)
 
     def _fused_bwd(self, s: ConvSpec, g: L.Act, out: torch.Tensor, stats_for: Optional[str], out2: Optional[torch.Tensor]):
         """hpfg_fused_bwd: dX into `out` (/ `out2`), the weight-gradient slabs of layer s and -- with stats_for -- the BatchNorm-backward
@@ -652,7 +683,10 @@ class UNetEngine:
         # on_side: one of the deferred batches, on the side stream the caller (backward / flush) forked
         stream = self._side.cuda_stream if on_side else torch.cuda.current_stream(self.dev).cuda_stream
         wa = L.WgradArgs()
-        wa.a0, wa.a1 = self.input_acts(s.name)
+        if s.name in self._act_live:      # the forward conv stored the input it staged
+            wa.a0, wa.a1 = self._act_plain(self.actbuf[s.name], s.cin, s.h, s.w), L.Act()
+        else:
+            wa.a0, wa.a1 = self.input_acts(s.name)
         wa.g = g
         wa.slab, wa.dw_oihw, wa.defer_reduce = L.ptr(self.slab_of[s.name]), L.ptr(self.grads[f"{s.name}.weight"]), 1
         wa.Cin, wa.CinPad, wa.Cout, wa.CoutPad = s.cin, s.cin_pad, s.cout, s.cout_pad
@@ -661,7 +695,8 @@ class UNetEngine:
         wa.math = self.math
         self._run("wgrad:" + s.name, lambda: L.check(self.lib.hpfg_wgrad(C.byref(wa), stream), f"wgrad[{s.name}]"), stream)
 
-    def _dgrad(self, s: ConvSpec, g: L.Act, out: torch.Tensor, stats_for: Optional[str] = None, out2: Optional[torch.Tensor] = None):
+    def _dgrad(self, s: ConvSpec, g: L.Act, out: torch.Tensor, stats_for: Optional[str] = None, out2: Optional[torch.Tensor] = None,
+               stage_out: Optional[torch.Tensor] = None):
         """out [N,h,w,cin] = conv-transpose of dZ with this layer's weights.
         stats_for: name of the BatchNorm layer whose activated output `out` is the COMPLETE gradient of (this conv is its only
         consumer): the bf16x3 kernel's epilogue then also leaves that layer's backward sums in self.partials, and the following
@@ -675,6 +710,8 @@ class UNetEngine:
         if out2 is not None:          # [d(skip) | d(upsampled)] into two buffers
             ca.out2, ca.out_split, ca.out_pstride, ca.out2_pstride = L.ptr(out2), s.cin // 2, s.cin // 2, s.cin // 2
         ca.N, ca.H, ca.W, ca.taps = self.N, s.h, s.w, s.taps
+        if stage_out is not None:
+            ca.stage_out = L.ptr(stage_out)
         # (not for the 32-channel slices of 16x16-pixel tiles: that instantiation is out of registers and the extra epilogue spills)
         spills = s.taps == 9 and s.cin_pad % 32 == 0 and s.h % 16 == 0 and s.w % 16 == 0
         if stats_for is not None and self.math == L.MATH_BF16X3 and self.fuse_bwd_stats and s.cin == s.cin_pad and (not spills or self.fuse_bwd_stats == 2):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 129
+#define HPFG_VERSION 130
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -101,6 +101,13 @@ typedef struct HpfgConvArgs {
                            The accumulator must be zero when the launch starts (hpfg_pack_weights_bump zeroes a region). */
   int32_t stat_shards;  /* power of two, 1 .. HPFG_ACC_MAX_SHARDS */
   int32_t reserved2;
+  float* stage_out;     /* optional, 3x3 layers on the bf16x3 kernels with a non-PLAIN source of (a0.C + a1.C) % 8 == 0 channels at sizes that are
+                           not multiples of 16 (the channel-rich 56 / 28 / 14-pixel levels; the aligned ones have fused kernels): the staging
+                           derives the virtual input of every pixel anyway (BatchNorm + LeakyReLU + Dropout [+ max-pool | + bilinear upsample and
+                           concat] in a forward conv; dZ = k1*g + k2*z + k3 in a dgrad) -- the workgroups of output-channel slice 0 also store
+                           it, fp32 [N][H][W][a0.C + a1.C] dense.  The layer's weight gradient reads the stored tensors as PLAIN sources (its
+                           input from the forward conv, its dZ from the dgrad) instead of deriving both again in every (input-channel slice x
+                           output-channel slice) workgroup */
 } HpfgConvArgs;
 #define HPFG_ACC_MAX_SHARDS 8
 #define HPFG_ACC_WORDS(C, shards) ((shards) * 2 * 2 * (C))   /* long long words of one layer accumulator */
