@@ -1,10 +1,11 @@
-"""GPU: the dZ tensor a 3x3 dgrad stores as a side effect of its staging (HpfgConvArgs.dz_out) and the weight gradient that reads it.
+"""GPU: the tensors a 3x3 conv / dgrad stores as a side effect of its staging (HpfgConvArgs.stage_out) and the weight gradient that reads them.
 
-The separate dgrad of a channel-rich layer derives dZ = k1*g + k2*z + k3 for every pixel it stages; with dz_out the workgroups of
-output-channel slice 0 store it, and the layer's weight gradient reads that one fp32 tensor as a PLAIN source instead of deriving dZ from
-(dA, z) again in every (input-channel slice) workgroup.  Same arithmetic either way, so every parameter gradient must agree with the
-path that re-derives dZ to rounding of the bf16 split (the two kernels contract their FMAs independently), and the stored tensor must be
-the dZ the oracle's BatchNorm / LeakyReLU / Dropout backward gives."""
+The separate dgrad of a channel-rich layer derives dZ = k1*g + k2*z + k3 for every pixel it stages, its forward conv the virtual input
+(BatchNorm + LeakyReLU + Dropout, max-pooled or upsampled + concatenated); with stage_out the workgroups of output-channel slice 0 store
+what they stage, and the layer's weight gradient reads the two fp32 tensors as PLAIN sources instead of deriving both again in every
+(input slice x output slice) workgroup.  Same arithmetic either way, so every parameter gradient must agree with the path that re-derives
+them to rounding (the kernels contract their FMAs independently), the stored input must be the virtual input hpfg_act_materialize gives,
+and every pixel must be written."""
 import pytest
 import torch
 
@@ -16,15 +17,17 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
 
-def _grads(dz_side, n, hw):
+def _grads(side, n, hw):
     reset_dropout_streams()
     torch.manual_seed(11)
     m = UNet(1, 4).to(DEV)
     m.train()
     x, lab = synth_batch(5, n, hw, hw, 1, 4, cell=8)
-    out = m(x.to(DEV))
+    with torch.no_grad():
+        m(x.to(DEV))          # (creates the engine; both variants draw the same masks and move the running statistics alike)
     eng = next(iter(m._engines.values()))[0]
-    eng.dz_side = dz_side
+    eng.dz_side = eng.act_side = side
+    out = m(x.to(DEV))
     Med_Sup_Loss(4)(out, lab.to(DEV)).backward()
     torch.cuda.synchronize()
     return {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}, eng
@@ -33,9 +36,12 @@ def _grads(dz_side, n, hw):
 @pytest.mark.parametrize("n,hw", [(2, 48), (3, 80)])
 def test_weight_gradients_from_the_stored_dz(n, hw):
     g1, eng = _grads(True, n, hw)
-    assert len(eng.dzbuf) >= 6, sorted(eng.dzbuf)          # every 3x3 layer below the 16-pixel-aligned level took the path
+    assert len(eng.dzbuf) >= 6 and len(eng.actbuf) >= 6, (sorted(eng.dzbuf), sorted(eng.actbuf))      # every 3x3 layer below the aligned levels
+    for name, t in eng.actbuf.items():          # the stored input == the virtual input of the layer (pooled / concatenated sources included)
+        ref = eng.materialize_input(name)
+        assert float((t - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max())), name
     g0, eng0 = _grads(False, n, hw)
-    assert not eng0.dzbuf
+    assert not eng0.dzbuf and not eng0.actbuf
     for k in g0:
         d = float((g1[k] - g0[k]).abs().max())
         assert d <= 2e-6 * max(1.0, float(g0[k].abs().max())), (k, d)
@@ -44,23 +50,24 @@ def test_weight_gradients_from_the_stored_dz(n, hw):
         assert torch.isfinite(t).all(), name
 
 
-def test_every_pixel_of_dz_is_written():
-    """Fill the side buffers with NaN, run one more backward: no NaN may survive (tiles partition the image; only slice-0 workgroups store)."""
+def test_every_pixel_of_the_side_tensors_is_written():
+    """Fill the side buffers with NaN, run one more forward + backward: no NaN may survive (tiles partition the image; only slice-0 workgroups store)."""
     reset_dropout_streams()
     torch.manual_seed(3)
     m = UNet(1, 4).to(DEV)
     m.train()
     x, lab = synth_batch(9, 2, 112, 112, 1, 4, cell=8)
-    for _ in range(2):
+    for it in range(2):
+        if it == 1:          # the buffers exist now: poison them, the second forward / backward must overwrite every element
+            eng = next(iter(m._engines.values()))[0]
+            for t in list(eng.dzbuf.values()) + list(eng.actbuf.values()):
+                t.fill_(float("nan"))
         out = m(x.to(DEV))
-        eng = next(iter(m._engines.values()))[0]
-        for t in eng.dzbuf.values():
-            t.fill_(float("nan"))
         m.zero_grad(set_to_none=True)
         Med_Sup_Loss(4)(out, lab.to(DEV)).backward()
     torch.cuda.synchronize()
-    assert eng.dzbuf
-    for name, t in eng.dzbuf.items():
+    assert eng.dzbuf and eng.actbuf
+    for name, t in list(eng.dzbuf.items()) + list(eng.actbuf.items()):
         assert torch.isfinite(t).all(), name
     for k, p in m.named_parameters():
         assert torch.isfinite(p.grad).all(), k
