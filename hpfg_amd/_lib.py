@@ -192,7 +192,6 @@ PROTOTYPES = {
     "hpfg_loss_blocks": (_i, [_i, _i, _i]),
     "hpfg_seg_loss_partials": (_i, [C.POINTER(LossArgs), _p]),
     "hpfg_seg_loss_finalize": (_i, [C.POINTER(LossArgs), _p]),
-    "hpfg_seg_loss_fwd": (_i, [C.POINTER(LossArgs), _p, _p]),
     "hpfg_seg_loss_bwd": (_i, [C.POINTER(LossArgs), _p, _p]),
     "hpfg_argmax_labels": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "hpfg_cutmix_blend": (_i, [_p, _p, _p, _p, _l, _p]),

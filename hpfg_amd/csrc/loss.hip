@@ -50,10 +50,8 @@ __device__ inline void load_px(const float* base, long pix, float* l) {
 }
 
 // All accumulators are named scalars / statically indexed arrays (runtime-indexed register arrays would spill to scratch).
-__device__ inline void loss_scalars(const HpfgLossArgs& a, const float* s);
-
 template <int C>
-__global__ __launch_bounds__(256) void loss_partials_kernel(HpfgLossArgs a, long npix_img, unsigned int* ticket) {
+__global__ __launch_bounds__(256) void loss_partials_kernel(HpfgLossArgs a, long npix_img) {
   __shared__ float red[4][NS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float nll[2] = {0.f, 0.f}, cnt[2] = {0.f, 0.f}, mse = 0.f, msk = 0.f;
@@ -142,48 +140,6 @@ __global__ __launch_bounds__(256) void loss_partials_kernel(HpfgLossArgs a, long
   }
   __syncthreads();
   if (tid < NS) a.partials[(long)blockIdx.x * NS + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-  if (!ticket) return;
-  // Single-launch form (hpfg_seg_loss_fwd, one rank): the workgroup that takes the last ticket sums the rows -- every row is complete and
-  // visible by then (release fence before each ticket, acquire after the last) -- in a FIXED order (row-major inside a thread, then thread
-  // order), so the sums do not depend on which workgroup came last; it writes `sums` and the loss scalars and hands the ticket counter back as
-  // zero.  Two launches (reduce, finalize) and their kernel boundaries leave the step's dependency chain.
-  __shared__ unsigned int last;
-  __shared__ double fin[32][NS];
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  const int nblk = (int)gridDim.x, q = tid & 7, r0 = tid >> 3;      // thread = column quad q of rows r0, r0 + 32, ...
-  double t4[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int rb = r0; rb < nblk; rb += 32 * 8) {      // eight independent 16-byte loads in flight per trip
-    f32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int r = rb + 32 * u;
-      v[u] = r < nblk ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.partials + (long)r * NS + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) t4[j] += (double)v[u][j];
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) fin[r0][4 * q + j] = t4[j];
-  __syncthreads();
-  __shared__ float tot[NS];
-  if (tid < NS) {
-    double t = 0.0;
-    for (int k = 0; k < 32; ++k) t += fin[k][tid];
-    tot[tid] = (float)t;
-    a.sums[tid] = (float)t;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    if (a.out) loss_scalars(a, tot);
-    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ sums, HpfgPeerX px) {
@@ -211,7 +167,9 @@ __device__ inline float dice_of(const float* s, int base, int C) {
   return d / (float)C;
 }
 
-__device__ inline void loss_scalars(const HpfgLossArgs& a, const float* s) {
+__global__ void loss_finalize_kernel(HpfgLossArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float* s = a.sums;
   const int C = a.C;
   float ce0 = s[1] > 0.f ? s[0] / s[1] : 0.f;
   float ce1 = s[3] > 0.f ? s[2] / s[3] : 0.f;
@@ -228,11 +186,6 @@ __device__ inline void loss_scalars(const HpfgLossArgs& a, const float* s) {
   a.out[5] = mse;
   a.out[6] = 0.f;
   a.out[7] = 0.f;
-}
-
-__global__ void loss_finalize_kernel(HpfgLossArgs a) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  loss_scalars(a, a.sums);
 }
 
 template <int C>
@@ -331,14 +284,13 @@ static int check_loss(const HpfgLossArgs* a) {
   return 0;
 }
 
-static int loss_partials_impl(const HpfgLossArgs* a, const HpfgPeerX* px, void* stream, unsigned int* ticket = nullptr) {
+static int loss_partials_impl(const HpfgLossArgs* a, const HpfgPeerX* px, void* stream) {
   if (int rc = check_loss(a)) return rc;
   HPFG_ARG_CHECK(a->partials, "seg_loss_partials: workspace missing");
   int nblk = hpfg_loss_blocks(a->N, a->H, a->W);
-  if (a->C == 4) hipLaunchKernelGGL(loss_partials_kernel<4>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a, (long)a->H * a->W, ticket);
-  else if (a->C == 3) hipLaunchKernelGGL(loss_partials_kernel<3>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a, (long)a->H * a->W, ticket);
-  else hipLaunchKernelGGL(loss_partials_kernel<2>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a, (long)a->H * a->W, ticket);
-  if (ticket) return hpfg_launch_status("loss_partials_kernel<single launch>");
+  if (a->C == 4) hipLaunchKernelGGL(loss_partials_kernel<4>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a, (long)a->H * a->W);
+  else if (a->C == 3) hipLaunchKernelGGL(loss_partials_kernel<3>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a, (long)a->H * a->W);
+  else hipLaunchKernelGGL(loss_partials_kernel<2>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a, (long)a->H * a->W);
   HpfgPeerX none;
   memset(&none, 0, sizeof(none));
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(NS), dim3(256), 0, (hipStream_t)stream, a->partials, nblk, a->sums, px ? *px : none);
@@ -356,11 +308,6 @@ extern "C" int hpfg_seg_loss_partials_x(const HpfgLossArgs* a, const HpfgPeerX* 
     for (int r = 0; r < px->world; ++r) HPFG_ARG_CHECK(px->mbox[r], "seg_loss_partials_x: mailbox of rank %d not mapped", r);
   }
   return loss_partials_impl(a, px, stream);
-}
-
-extern "C" int hpfg_seg_loss_fwd(const HpfgLossArgs* a, unsigned int* ticket, void* stream) {
-  HPFG_ARG_CHECK(a && ticket && a->out && a->world == 1, "seg_loss_fwd: needs out, a zero-initialised ticket word and world == 1");
-  return loss_partials_impl(a, nullptr, stream, ticket);
 }
 
 extern "C" int hpfg_seg_loss_finalize(const HpfgLossArgs* a, void* stream) {

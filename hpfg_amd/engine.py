@@ -74,14 +74,6 @@ def build_specs(in_ch: int, ncls: int, H: int, W: int) -> Dict[str, ConvSpec]:
     return specs
 
 
-def _side_stream(dev):
-    """Stream of the off-chain launches (queued weight gradients, weight packing).  HPFG_PRIO=1 (experiment): lowest priority."""
-    if os.environ.get("HPFG_PRIO", "0") == "1":
-        lo, hi = torch.cuda.Stream.priority_range()
-        return torch.cuda.Stream(device=dev, priority=lo)
-    return torch.cuda.Stream(device=dev)
-
-
 class MarkLog:
     """Device time stamps around selected launches (bench.py's per-kernel timings).  A stamp is a one-wave kernel that stores s_memrealtime
     (100 MHz) into a slot of `buf` (hpfg_timestamp); stamps are ordinary stream work, so they are captured into a hipGraph with the launches
@@ -171,7 +163,6 @@ class UNetEngine:
         # set by the model for the network that runs on the step's ORIGIN stream (the single trainable network of a step): its weight packing
         # (22 us) runs on the side stream beside the first conv, which reads the OIHW weights directly and needs nothing the launch produces
         self.pack_overlap = False
-        self.after_layer = None
         # the same for the backward sums (sum g, sum g * xhat): added by the dgrad epilogue / the reduction pass that completes a layer's
         # gradient, read by every dZ consumer's prologue (k1 .. k3 derived there), turned into dgamma / dbeta -- and zeroed again -- by ONE
         # launch per backward (hpfg_bn_acc_bwd_finalize) instead of 18 finalize launches on the critical chain
@@ -199,7 +190,6 @@ class UNetEngine:
         # HpfgConvArgs.stage_out: the separate dgrad of a 3x3 layer also stores the dZ it stages, and (act_side) its forward conv the virtual
         # input it stages; the layer's weight gradient reads those tensors as PLAIN sources instead of deriving both again -- BatchNorm,
         # LeakyReLU, Dropout, max-pool / bilinear taps forward, their backward for dZ -- in every (input slice x output slice) workgroup
-        self.early_flush = int(os.environ.get("HPFG_EARLY_FLUSH", "0"))
         self.dz_side = os.environ.get("HPFG_DZ_SIDE", "1") == "1"
         self.act_side = os.environ.get("HPFG_ACT_SIDE", "1") == "1"
         self.dzbuf: Dict[str, torch.Tensor] = {}
@@ -437,7 +427,7 @@ class UNetEngine:
                 # of a forked stream inside a capture faults in hipStreamEndCapture on ROCm 7.2): [pack] beside [first conv]
                 main = torch.cuda.current_stream(self.dev)
                 if self._side is None:
-                    self._side = _side_stream(self.dev)
+                    self._side = torch.cuda.Stream(device=self.dev)
                 self._side.wait_stream(main)
                 with torch.cuda.stream(self._side):
                     self.pack(**self._pack_args)
@@ -446,8 +436,6 @@ class UNetEngine:
                 main.wait_stream(self._side)
                 continue
             self._fwd_layer(s, logits, train, track_running)
-            if self.after_layer is not None and i == self.after_layer[0]:
-                self.after_layer[1]()
         if self._acc_live:
             self._finalize_all(track_running)
             self._acc_dirty = False
@@ -793,7 +781,7 @@ class UNetEngine:
             if self._deferred is not None:
                 main = torch.cuda.current_stream(self.dev)
                 if self._side is None:
-                    self._side = _side_stream(self.dev)
+                    self._side = torch.cuda.Stream(device=self.dev)
                 self._side.wait_stream(main)
                 if not self._csum_done:          # out_conv's bias sums ride along with the first batch
                     csum(self._side.cuda_stream)
@@ -824,9 +812,6 @@ class UNetEngine:
             prev = enc_prefix(4) + ".4" if k == 1 else f"decoder.up{k - 1}.conv.conv_conv.4"
             # the 1x1 conv is the only consumer of the block output below (the bottleneck also feeds the dense head of UNet_Plus)
             self._wgrad_dgrad(su, gu, self.dA[prev], prev if (k > 1 or dfeat4 is None) else None)
-            if k == self.early_flush and self._deferred is not None:      # (experiment) the 224 / 112-pixel levels' queued launches beside the 56 / 28-pixel chain
-                flush(0, 0)
-                self._deferred = []
         if dfeat4 is not None:
             self.dA[enc_prefix(4) + ".4"].add_(dfeat4)
         defer = self._deferred is not None
@@ -858,11 +843,6 @@ class UNetEngine:
             if lvl == 2 and self._deferred is not None:
                 flush(self._n_thin_enc_desc, self._n_enc_desc)
                 self._deferred = None
-        tail_first = defer and bucket_cb is None and os.environ.get("HPFG_TAIL", "1") == "1"      # (A/B switch, removed after the measurement)
-        if tail_first:
-            # the thin encoder layers' slabs come from fused kernels on THIS stream: reduce them before the join, beside the side stream's last
-            # weight gradients and slab reduction (which end after the main chain), instead of behind the join and the finalize launch
-            self._slab_reduce(0, self._n_thin_enc_desc)
         if self._side_used:
             torch.cuda.current_stream(self.dev).wait_stream(self._side)
             self._side_used = False
@@ -872,8 +852,8 @@ class UNetEngine:
         if bucket_cb is not None:
             self._slab_reduce(0, self._n_enc_desc)
             bucket_cb(1)
-        elif defer and not tail_first:
-            self._slab_reduce(0, self._n_thin_enc_desc)
-        elif not defer:
+        elif defer:
+            self._slab_reduce(0, self._n_thin_enc_desc)      # the rest was reduced on the side stream
+        else:
             self._slab_reduce(0, len(self._slab_host))
         self.bwd_ready = False

@@ -28,7 +28,7 @@ import torch
 from . import _lib as L
 from .utils import (BoxMaskGenerator, build_lr_scheduler, build_optimizer, ema_alpha, linear_rampup, seg_loss, sigmoid_rampup,
                     update_ema_variables, update_ema_variables_backbone)
-from .utils.loss import _nhwc, ensure_tickets
+from .utils.loss import _nhwc
 from .utils.optim import FusedSGD
 
 # layout of the per-step scalar block (device fp32 [32])
@@ -112,7 +112,6 @@ class _StepBase:
     def __init__(self, dev, dp=None):
         self.dev, self.dp = dev, dp
         self.sc = StepScalars(dev)
-        ensure_tickets(dev)      # (the loss kernels' ticket words must exist before a step is captured)
         if dp is not None:
             self.sc.on_push = lambda: setattr(dp, "_loss_call", 0)
         # HPFG_STEP_MARKS=1: timestamp kernels at phase boundaries of the step (tools/stream_timeline.py); off by default
@@ -121,8 +120,6 @@ class _StepBase:
         # kernel chains (and, data parallel, their small BatchNorm collectives) overlap; joins before the loss.
         self.overlap = os.environ.get("HPFG_OVERLAP", "1") == "1"
         self.side = torch.cuda.Stream(device=dev) if self.overlap else None
-        if self.overlap and os.environ.get("HPFG_PRIO", "0") == "1":      # (experiment)
-            self.side = torch.cuda.Stream(device=dev, priority=torch.cuda.Stream.priority_range()[1])
 
     def _mark(self, i):
         if self.marks is not None:
@@ -300,17 +297,9 @@ class MeanTeacherStep(_StepBase):
         nl = label_img.shape[0]
         x = cat_batch(label_img, unlabel_img)
         self._mark(0)
-        k = int(os.environ.get("HPFG_TEACHER_AT", "-1"))      # (experiment) the teacher's forward forks behind layer k of the student's
-        if k >= 0 and self.overlap:
-            box = []
-            self.model._after_layer = (k, lambda: box.append(self._teacher_forward(self.ema_model, x)))
-            out = self.model(x)
-            self.model._after_layer = None
-            t_out = box[0]
-        else:
-            t_out = self._teacher_forward(self.ema_model, x)
-            self._mark(1)
-            out = self.model(x)
+        t_out = self._teacher_forward(self.ema_model, x)
+        self._mark(1)
+        out = self.model(x)
         self._mark(4)
         self._join_teacher(t_out)
         return self._loss_bwd(out, t_out, target_label, nl)
@@ -886,12 +875,7 @@ class GraphedStep:
             with torch.cuda.graph(self.graph_b, pool=self.graph.pool(), capture_error_mode="thread_local"):
                 self.s.device_update()
         else:
-            kw = {}
-            if os.environ.get("HPFG_PRIO", "0") == "1":      # (experiment) the step's chain on a high-priority stream
-                lo, hi = torch.cuda.Stream.priority_range()
-                print("priority range", lo, hi, flush=True)
-                kw["stream"] = torch.cuda.Stream(priority=hi)
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local", **kw):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.out = self.s.device_step(*self.static)
         self._freeze_seed_updates(False)
 

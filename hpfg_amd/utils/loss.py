@@ -32,30 +32,6 @@ def _labels_u8(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return t.contiguous()
 
 
-import os
-_ONE_LAUNCH = os.environ.get("HPFG_LOSS_ONE", "1") == "1"      # (A/B switch, removed after the measurement)
-_TICKETS = {}      # device index -> [ring of zero-initialised ticket words, next word]
-_TICKET_RING = 64
-
-
-def ensure_tickets(dev) -> bool:
-    """The ring of ticket words hpfg_seg_loss_fwd needs on `dev` (the kernel hands a word back as zero; every call takes the next word, so calls
-    in flight on different streams never share one).  Created outside a stream capture only: the step objects call this when they are built."""
-    if dev.index not in _TICKETS:
-        if torch.cuda.is_current_stream_capturing():
-            return False
-        _TICKETS[dev.index] = [torch.zeros(_TICKET_RING, dtype=torch.int32, device=dev), 0]
-        torch.cuda.current_stream(dev).synchronize()
-    return True
-
-
-def _ticket(dev) -> int:
-    ring = _TICKETS[dev.index]
-    k = ring[1]
-    ring[1] = (k + 1) % _TICKET_RING
-    return ring[0].data_ptr() + 4 * k
-
-
 class _SegLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, coef, labels0, labels1, t_logits, n_lab, is_prob, dp, t_is_prob=False, cons_mask=None):
@@ -96,16 +72,11 @@ class _SegLossFn(torch.autograd.Function):
             dp.bump(epoch, st)          # the ranks' loss sums are added by the reduction kernel itself (peer mailboxes)
             px = dp.peer_desc(slot, epoch)
             L.check(lib.hpfg_seg_loss_partials_x(C.byref(a), C.byref(px), st), "seg_loss_partials_x")
-            L.check(lib.hpfg_seg_loss_finalize(C.byref(a), st), "seg_loss_finalize")
-        elif dp is not None and (dp.world_size > 1 or dp.force_sync):
+        else:
             L.check(lib.hpfg_seg_loss_partials(C.byref(a), st), "seg_loss_partials")
-            dp.allreduce_sum(sums)
-            L.check(lib.hpfg_seg_loss_finalize(C.byref(a), st), "seg_loss_finalize")
-        elif _ONE_LAUNCH and ensure_tickets(dev):      # one rank: partial sums, their total and the loss scalars in ONE launch (the last workgroup finishes the job)
-            L.check(lib.hpfg_seg_loss_fwd(C.byref(a), _ticket(dev), st), "seg_loss_fwd")
-        else:      # (first loss call of the process inside a stream capture: no ticket ring yet)
-            L.check(lib.hpfg_seg_loss_partials(C.byref(a), st), "seg_loss_partials")
-            L.check(lib.hpfg_seg_loss_finalize(C.byref(a), st), "seg_loss_finalize")
+            if dp is not None and (dp.world_size > 1 or dp.force_sync):
+                dp.allreduce_sum(sums)
+        L.check(lib.hpfg_seg_loss_finalize(C.byref(a), st), "seg_loss_finalize")
         ctx.args, ctx.keep = a, (x, t, labels0, labels1, coef, sums, cm)
         ctx.shape = (N, H, W, Cc)
         return out

@@ -348,10 +348,6 @@ int hpfg_loss_blocks(int N, int H, int W);
 int hpfg_seg_loss_partials(const HpfgLossArgs* a, void* stream);   /* softmax + CE/Dice/MSE partial sums */
 int hpfg_seg_loss_partials_x(const HpfgLossArgs* a, const HpfgPeerX* px, void* stream);   /* + the cross-rank sum of `sums` (peer mailbox) */
 int hpfg_seg_loss_finalize(const HpfgLossArgs* a, void* stream);   /* sums -> loss scalars (device) */
-/* partials + sums + scalars in ONE launch (one rank, world == 1): the workgroup that finishes last sums the rows in a fixed order and writes
- * `sums` and `out`.  `ticket`: one device word, zero before the first call; the kernel hands it back as zero, so calls that are ordered on a
- * stream can share it (concurrent calls on different streams need a word each). */
-int hpfg_seg_loss_fwd(const HpfgLossArgs* a, unsigned int* ticket, void* stream);
 int hpfg_seg_loss_bwd(const HpfgLossArgs* a, const float* grad_scale_dev /* NULL = 1 */, void* stream);   /* dlogits */
 /* pseudo-labels: argmax over classes of teacher logits, optionally CutMix-blended with labels (main.py:177-178) */
 int hpfg_argmax_labels(const float* logits, int N, int H, int W, int C, const uint8_t* mix_labels, const float* mix_mask,
