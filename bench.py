@@ -286,7 +286,8 @@ def layer_costs(eng, tag):
     """(family, algorithmic bytes, flops) of one bracketed launch `tag` = "<pass>:<conv name>" of engine `eng`.
     Bytes: the tensors the pass must move given what is stored: fwd = stored input + raw output + weights (a pooled
     input is the full-resolution producer, a concat input the skip tensor + the quarter-resolution 1x1 output); dgrad = dA + z + dX;
-    wgrad = dA + z + stored input; fused backward = dA + z + stored input + dX.  FLOPs: 2 x taps x Cin x Cout per output pixel and pass."""
+    wgrad = dA + z + stored input; fused backward = dA + z + stored input + dX.  Layers with side tensors (HpfgConvArgs.stage_out): the
+    forward conv also writes its staged input, the dgrad its dZ, and the weight gradient reads those two tensors instead.  FLOPs: 2 x taps x Cin x Cout per output pixel and pass."""
     kind, name = tag.split(":", 1) if ":" in tag else (tag, "")
     s = eng.specs.get(name)
     if s is None or kind not in ("fwd", "dgrad", "wgrad", "fused_bwd"):
@@ -311,12 +312,15 @@ def layer_costs(eng, tag):
         cls = "channel-rich 3x3 (>= 32 channels in and out)"
     else:
         cls = "thin 3x3 (< 32 channels in or out: the 224 x 224 / 112 x 112 layers and out_conv)"
+    # HpfgConvArgs.stage_out: a forward conv / dgrad that also stores what it staged, a weight gradient that reads the stored tensors instead
+    act_st = px * s.cin * 4 if name in getattr(eng, "_act_live", ()) else 0
+    dz_st = o_b if name in getattr(eng, "dzbuf", {}) else 0
     if kind == "fwd":
-        return f"forward conv, {cls}", x_b + o_b + w_b, fl
+        return f"forward conv, {cls}", x_b + o_b + w_b + act_st, fl
     if kind == "dgrad":
-        return f"input gradient (separate dgrad), {cls}", 2 * o_b + px * s.cin * 4 + w_b, fl
+        return f"input gradient (separate dgrad), {cls}", 2 * o_b + px * s.cin * 4 + w_b + dz_st, fl
     if kind == "wgrad":
-        return f"weight gradient (separate wgrad), {cls}", 2 * o_b + x_b, fl
+        return f"weight gradient (separate wgrad), {cls}", (dz_st or 2 * o_b) + (act_st or x_b), fl
     dx = 0 if s.idx == 0 else px * s.cin * 4
     return f"fused dgrad + wgrad, {cls}", 2 * o_b + x_b + dx + w_b, fl * (1 if s.idx == 0 else 2)
 
