@@ -52,5 +52,11 @@ for a, b in zip(fe, wr):
 out = {"workload": sys.argv[4] if len(sys.argv) > 4 else "mt",
        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --no-graph --steps 2` (tools/profile_round.sh); FETCH_SIZE x 2 per MI355X_MICROARCH.md",
        "families": {k: {"launches_per_step": v[1], "hbm_bytes_per_step": int(v[0]), "hbm_bytes_per_launch": int(v[0] / v[1])} for k, v in acc.items()}}
+import subprocess  # noqa: E402
+out["command"] = "bench.py --no-graph --steps 2 --warmup 1 (under rocprofv3 --pmc, tools/profile_round.sh)"
+try:
+    out["commit"] = "commit " + subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+except Exception:
+    out["commit"] = "commit n/a"
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
