@@ -299,8 +299,13 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
                    "conv_fwd: bwd_stats is a dgrad feature of the bf16x3 kernels (DZ or PLAIN source)");
     HPFG_ARG_CHECK((a->stat_partials || a->stat_acc) && a->bwd_of.z && a->bwd_of.bn && !a->bias,
                    "conv_fwd: bwd_stats needs stat_partials or stat_acc, bwd_of.z / .bn and no bias");
-    HPFG_ARG_CHECK(a->bwd_of.C == a->Cout && a->Cout == a->CoutPad && a->bwd_of.Hs == a->H && a->bwd_of.Ws == a->W && a->bwd_of.pstride % 4 == 0,
-                   "conv_fwd: bwd_of must describe a layer with C == Cout == CoutPad (%d/%d/%d) at the output size", a->bwd_of.C, a->Cout, a->CoutPad);
+    const int up = a->bwd_stats == 2 ? 2 : 1;      // 2: `out` is the gradient w.r.t. MaxPool2d(2) of bwd_of's activation (bwd_of at twice the size)
+    HPFG_ARG_CHECK(a->bwd_stats == 1 || a->bwd_stats == 2, "conv_fwd: bwd_stats must be 0, 1 or 2");
+    HPFG_ARG_CHECK(a->bwd_of.C == a->Cout && a->Cout == a->CoutPad && a->bwd_of.Hs == up * a->H && a->bwd_of.Ws == up * a->W && a->bwd_of.pstride % 4 == 0,
+                   "conv_fwd: bwd_of must describe a layer with C == Cout == CoutPad (%d/%d/%d) at the output size (twice it for bwd_stats == 2)",
+                   a->bwd_of.C, a->Cout, a->CoutPad);
+    HPFG_ARG_CHECK(a->bwd_stats == 1 || (a->taps == 9 && (a->H % 16 || a->W % 16) && a->bwd_of.aux && a->bwd_of.aux_pstride % 4 == 0 && a->bwd_of.drop_p == 0.f && !a->out_split),
+                   "conv_fwd: bwd_stats == 2 (max-pool backward in the epilogue) needs a 3x3 dgrad at a size that is not a multiple of 16, bwd_of.aux (the gradient so far) and no dropout behind bwd_of");
   }
   if ((a->math & 0xff) == HPFG_MATH_BF16X3) {
     {      // the thin 16-pixel-aligned layers have a kernel of their own

@@ -110,13 +110,18 @@ __device__ __forceinline__ void conv16_load_bias(const HpfgConvArgs& p, f32x4 (&
 // BatchNorm layer p.bwd_of, and (s1, s2) collect that layer's backward sums  sum(g), sum(g * xhat)  with
 // g = out * dropout * LeakyReLU'(bn(z))  -- the separate streaming pass over (dA, z) of hpfg_bn_bwd_reduce, done while the tile is
 // still in registers (it costs one read of z instead of a read of both tensors, and a launch).
-template <class C, bool BWD_OK = false>
+template <class C, int BWD_OK = 0>      // 0: forward statistics; 1: dgrad with p.bwd_stats == 1; 2: ... == 2 (max-pool backward epilogue)
 __device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (&acc)[C::MI][C::NI], f32x4 (&s1)[C::NI], f32x4 (&s2)[C::NI],
                                                   const f32x4 (&bias)[C::NI], int lane, int wm, int nt0, int n, int ty0, int tx0,
                                                   bool reload_bias = false) {
   const int H = p.H, W = p.W;
   const bool vec = (p.Cout & 3) == 0 && (p.out_pstride & 3) == 0 && (p.out2_pstride & 3) == 0;
   const bool bwd = BWD_OK && p.bwd_stats;
+  // bwd_stats == 2: the tile is dP, the gradient w.r.t. MaxPool2d(2) of bwd_of's activated output (bwd_of at 2H x 2W, its gradient so far -- the
+  // skip path -- in bwd_of.aux).  The epilogue is the max-pool backward: it finds the window's arg-max from the raw output (first maximum in
+  // row-major window order, like the forward kernel and torch), adds dP there IN PLACE, and takes the BatchNorm-backward sums of the completed
+  // gradient from the registers -- the pass hpfg_bn_bwd_reduce_pool makes in a launch of its own; `out` is not written.
+  const bool pool = BWD_OK == 2 && bwd;
   ActCtx bcx;
   if (bwd) bcx = make_ctx(p.bwd_of);
 #pragma unroll
@@ -136,7 +141,7 @@ __device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (
     // bwd: request the z values of all MI pixel tiles of this channel group before the first one is used (one exposed round trip per
     // channel group instead of one per tile when the scheduler would otherwise pair each load with its use)
     f32x4 zq[C::MI];
-    if (bwd) {
+    if (bwd && !pool) {
 #pragma unroll
       for (int m = 0; m < C::MI; ++m) {
         const int pxl = (wm * C::MI + m) * 16 + (lane & 15);
@@ -148,6 +153,49 @@ __device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (
     for (int m = 0; m < C::MI; ++m) {
       const int pxl = (wm * C::MI + m) * 16 + (lane & 15);
       const int gy = ty0 + pxl / C::TW, gx = tx0 + pxl % C::TW;
+      if (pool) {
+        if (gy < H && gx < W && co < p.Cout) {
+          const f32x4 v = acc[m][j];
+          float* dA = const_cast<float*>(p.bwd_of.aux);
+          const long p00 = ((long)n * p.bwd_of.Hs + 2 * gy) * p.bwd_of.Ws + 2 * gx;
+          f32x4 z4[4], g4[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const long off = p00 + (k >> 1) * p.bwd_of.Ws + (k & 1);
+            z4[k] = *reinterpret_cast<const f32x4*>(p.bwd_of.z + off * p.bwd_of.pstride + co);
+            g4[k] = *reinterpret_cast<const f32x4*>(dA + off * p.bwd_of.aux_pstride + co);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float y[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = z4[k][r] * tsc[r] + tsh[r];
+            float best = lrelu(y[0]);
+            int bi = 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+              const float a = lrelu(y[k]);
+              if (a > best) {
+                best = a;
+                bi = k;
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              g4[k][r] += bi == k ? v[r] : 0.f;
+              const float gg = y[k] > 0.f ? g4[k][r] : HPFG_LEAKY * g4[k][r];
+              s1[j][r] += gg;
+              s2[j][r] += gg * z4[k][r];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const long off = p00 + (k >> 1) * p.bwd_of.Ws + (k & 1);
+            *reinterpret_cast<f32x4*>(dA + off * p.bwd_of.aux_pstride + co) = g4[k];
+          }
+        }
+        continue;
+      }
       if (gy < H && gx < W && co < p.Cout) {
         f32x4 v = acc[m][j] + b;
         float* o = (p.out_split && co >= p.out_split) ? p.out2 + ((n * H + gy) * W + gx) * p.out2_pstride + (co - p.out_split)
@@ -185,7 +233,7 @@ __device__ __forceinline__ void conv16_store_tile(const HpfgConvArgs& p, f32x4 (
 
 // Reduce the per-lane partial sums over the 16 pixel lanes and the WM waves that share output channels; row `row` of
 // stat_partials ([rows][2][CoutPad]) receives this workgroup's sum(z), sum(z^2).
-template <class C, bool BWD = false>
+template <class C, int BWD = 0>
 __device__ __forceinline__ void conv16_flush_stats(const HpfgConvArgs& p, f32x4 (&s1)[C::NI], f32x4 (&s2)[C::NI], float* ldsf, int tid, int lane, int wm,
                                                    int wn, int cb, int row) {
   if ((!p.stat_partials && !p.stat_acc) || (p.math & 0x1000)) return;
@@ -281,7 +329,7 @@ constexpr int wg_per_cu() {
 
 // BWD: the dgrad variant whose epilogue also produces the BatchNorm-backward sums of the layer below (p.bwd_stats); a separate
 // instantiation so that the plain kernels keep their register budget.
-template <class C, int KIND, bool BWD = false>
+template <class C, int KIND, int BWD = 0>
 __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   static_assert(C::TAPS == 9, "persistent kernel is the 3x3 path");
   constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
@@ -616,7 +664,7 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
 }
 
 // 1x1: one tile per workgroup, K = 32 input channels per MFMA step, no halo.
-template <class C, int KIND, bool BWD = false>
+template <class C, int KIND, int BWD = 0>
 __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   static_assert(C::TAPS == 1, "1x1 path");
   constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
@@ -728,8 +776,18 @@ int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   if constexpr (C::TAPS == 9) {
     dim3 grid((unsigned)persistent_grid<C, KIND>(a), a.CoutPad / C::BN);
     if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLAIN) {
+      if constexpr (C::TH == 4) {      // (the max-pool-backward epilogue: an instantiation of its own, for the sizes that are not multiples of 16)
+        if (a.bwd_stats == 2) {
+          hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND, 2>), grid, dim3(256), 0, st, a, tx, ty);
+          return hpfg_launch_status("conv_bf16x3_kernel<bwd stats + pool>");
+        }
+      }
+      if (a.bwd_stats == 2) {
+        hpfg_set_error("conv_fwd: bwd_stats == 2 is built for H or W not a multiple of 16");
+        return -1;
+      }
       if (a.bwd_stats) {
-        hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND, true>), grid, dim3(256), 0, st, a, tx, ty);
+        hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND, 1>), grid, dim3(256), 0, st, a, tx, ty);
         return hpfg_launch_status("conv_bf16x3_kernel<bwd stats>");
       }
     }
@@ -738,7 +796,7 @@ int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
     dim3 grid(tx * ty, a.N, a.CoutPad / C::BN);
     if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLAIN) {
       if (a.bwd_stats) {
-        hipLaunchKernelGGL((conv1x1_bf16x3_kernel<C, KIND, true>), grid, dim3(256), 0, st, a, tx, ty);
+        hipLaunchKernelGGL((conv1x1_bf16x3_kernel<C, KIND, 1>), grid, dim3(256), 0, st, a, tx, ty);
         return hpfg_launch_status("conv1x1_bf16x3_kernel<bwd stats>");
       }
     }

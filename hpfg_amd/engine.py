@@ -190,6 +190,8 @@ class UNetEngine:
         # HpfgConvArgs.stage_out: the separate dgrad of a 3x3 layer also stores the dZ it stages, and (act_side) its forward conv the virtual
         # input it stages; the layer's weight gradient reads those tensors as PLAIN sources instead of deriving both again -- BatchNorm,
         # LeakyReLU, Dropout, max-pool / bilinear taps forward, their backward for dZ -- in every (input slice x output slice) workgroup
+        self.pool_fuse = int(os.environ.get("HPFG_POOL_FUSE", "1"))      # 1: the conv kernel's dgrads only, 2: the fused thin kernel's too
+        self._pool_done: set = set()
         self.dz_side = os.environ.get("HPFG_DZ_SIDE", "1") == "1"
         self.act_side = os.environ.get("HPFG_ACT_SIDE", "1") == "1"
         self.dzbuf: Dict[str, torch.Tensor] = {}
@@ -626,25 +628,26 @@ class UNetEngine:
                 L.ptr(self.partials), nblk, None, count, L.ptr(gam), L.ptr(self.bn[s.name]), L.ptr(dg), L.ptr(db), s.cout, 1.0, st), "bn_bwd_finalize"))
         return g
 
-    def _wgrad_dgrad(self, s: ConvSpec, g: L.Act, dgrad_out: torch.Tensor, stats_for: Optional[str] = None, out2: Optional[torch.Tensor] = None):
+    def _wgrad_dgrad(self, s: ConvSpec, g: L.Act, dgrad_out: torch.Tensor, stats_for: Optional[str] = None, out2: Optional[torch.Tensor] = None,
+                     pool_of: Optional[str] = None):
         """Both gradients of layer s from the same dZ source (they only read it, so their order is free)."""
         if s.name in self.fused_grid:
-            return self._fused_bwd(s, g, dgrad_out, stats_for, out2)
+            return self._fused_bwd(s, g, dgrad_out, stats_for, out2, pool_of)
         dz = None
         if self.dz_side and self.math == L.MATH_BF16X3 and self._side_layer(s) and g.mode == L.ACT_DZ and s.cout % 8 == 0:
             dz = self.dzbuf.get(s.name)
             if dz is None:
                 dz = self.dzbuf[s.name] = torch.empty(self.N, s.h, s.w, s.cout, dtype=torch.float32, device=self.dev)
         if self._deferred is not None:      # decoder half: the weight gradient is queued for the side stream (see backward())
-            self._dgrad(s, g, dgrad_out, stats_for, out2, stage_out=dz)
+            self._dgrad(s, g, dgrad_out, stats_for, out2, stage_out=dz, pool_of=pool_of)
             self._deferred.append((s, g if dz is None else self._act_plain(dz, s.cout, s.h, s.w)))
         else:
             if dz is not None:
-                self._dgrad(s, g, dgrad_out, stats_for, out2, stage_out=dz)
+                self._dgrad(s, g, dgrad_out, stats_for, out2, stage_out=dz, pool_of=pool_of)
                 self._wgrad(s, self._act_plain(dz, s.cout, s.h, s.w))
             else:
                 self._wgrad(s, g)
-                self._dgrad(s, g, dgrad_out, stats_for, out2)
+                self._dgrad(s, g, dgrad_out, stats_for, out2, pool_of=pool_of)
 
     @staticmethod
     def _side_layer(s: ConvSpec) -> bool:
@@ -652,7 +655,7 @@ class UNetEngine:
         fused / thin kernels, which stage input and dZ once for both gradients already)."""
         return s.taps == 9 and bool(s.h % 16 or s.w % 16)
 
-    def _fused_bwd(self, s: ConvSpec, g: L.Act, out: torch.Tensor, stats_for: Optional[str], out2: Optional[torch.Tensor]):
+    def _fused_bwd(self, s: ConvSpec, g: L.Act, out: torch.Tensor, stats_for: Optional[str], out2: Optional[torch.Tensor], pool_of: Optional[str] = None):
         """hpfg_fused_bwd: dX into `out` (/ `out2`), the weight-gradient slabs of layer s and -- with stats_for -- the BatchNorm-backward
         sums of the layer below, from one read of (dA, z) and one read of the layer input."""
         fa = L.FusedBwdArgs()
@@ -674,6 +677,15 @@ class UNetEngine:
             if self._accb_live:
                 ca.stat_partials, ca.stat_acc, ca.stat_shards = None, L.ptr(self.accb_of[stats_for]), self.acc_shards[stats_for]
             self._fused_rows[stats_for] = rows
+        elif pool_of is not None and self.fuse_bwd_stats and self.pool_fuse >= 2 and s.cin == s.cin_pad and out2 is None and out is not None:
+            # (see _dgrad: the max-pool backward into layer pool_of's gradient + its sums in this kernel's epilogue; `out` is not written)
+            if rows * 2 * s.cin > self.partials.numel():
+                raise RuntimeError(f"fused_bwd[{s.name}]: {rows} rows of backward sums do not fit the partials workspace")
+            ca.bwd_stats, ca.bwd_of, ca.stat_partials = 2, self._act_dz(pool_of, self.dA[pool_of], self.dA_ps[pool_of]), L.ptr(self.partials)
+            if self._accb_live:
+                ca.stat_partials, ca.stat_acc, ca.stat_shards = None, L.ptr(self.accb_of[pool_of]), self.acc_shards[pool_of]
+            self._fused_rows[pool_of] = rows
+            self._pool_done.add(pool_of)
         self._last_fused[s.name] = fa      # (bench.py re-launches it alone)
         self._run("fused_bwd:" + s.name, lambda: L.check(self.lib.hpfg_fused_bwd(C.byref(fa), self._stream()), f"fused_bwd[{s.name}]"))
 
@@ -696,7 +708,7 @@ class UNetEngine:
         self._run("wgrad:" + s.name, lambda: L.check(self.lib.hpfg_wgrad(C.byref(wa), stream), f"wgrad[{s.name}]"), stream)
 
     def _dgrad(self, s: ConvSpec, g: L.Act, out: torch.Tensor, stats_for: Optional[str] = None, out2: Optional[torch.Tensor] = None,
-               stage_out: Optional[torch.Tensor] = None):
+               stage_out: Optional[torch.Tensor] = None, pool_of: Optional[str] = None):
         """out [N,h,w,cin] = conv-transpose of dZ with this layer's weights.
         stats_for: name of the BatchNorm layer whose activated output `out` is the COMPLETE gradient of (this conv is its only
         consumer): the bf16x3 kernel's epilogue then also leaves that layer's backward sums in self.partials, and the following
@@ -722,6 +734,18 @@ class UNetEngine:
             if self._accb_live:
                 ca.stat_partials, ca.stat_acc, ca.stat_shards = None, L.ptr(self.accb_of[stats_for]), self.acc_shards[stats_for]
             self._fused_rows[stats_for] = rows
+        elif pool_of is not None and self.math == L.MATH_BF16X3 and self.fuse_bwd_stats and s.cin == s.cin_pad and self._side_layer(s) and out2 is None:
+            # `out` would be dP, the gradient w.r.t. MaxPool2d(2) of layer pool_of's activation: the epilogue scatters it into that layer's
+            # gradient (arg-max of the 2 x 2 window) and takes the BatchNorm-backward sums of the completed gradient -- hpfg_bn_bwd_reduce_pool's
+            # pass, without its launch on the chain
+            ca.bwd_stats, ca.bwd_of, ca.stat_partials = 2, self._act_dz(pool_of, self.dA[pool_of], self.dA_ps[pool_of]), L.ptr(self.partials)
+            rows = self.lib.hpfg_conv_stat_rows(C.byref(ca))
+            if rows <= 0 or rows * 2 * s.cin > self.partials.numel():
+                raise RuntimeError(f"dgrad[{s.name}]: {rows} rows of backward sums do not fit the partials workspace")
+            if self._accb_live:
+                ca.stat_partials, ca.stat_acc, ca.stat_shards = None, L.ptr(self.accb_of[pool_of]), self.acc_shards[pool_of]
+            self._fused_rows[pool_of] = rows
+            self._pool_done.add(pool_of)
         self._run("dgrad:" + s.name, lambda: L.check(self.lib.hpfg_conv_fwd(C.byref(ca), self._stream()), f"dgrad[{s.name}]"))
 
     def _slab_reduce(self, lo: int, hi: int, stream=None):
@@ -758,6 +782,7 @@ class UNetEngine:
         # returned (round 1; removed); this is one of each.  Not with the data-parallel buckets: the decoder's gradients must be final at the
         # bucket boundary.
         self._deferred = [] if (self.defer_wgrad and bucket_cb is None) else None
+        self._pool_done = set()
         # ---- out_conv
         s = sp["decoder.out_conv"]
         g = self._act_plain(dlogits, self.ncls, s.h, s.w)
@@ -830,7 +855,7 @@ class UNetEngine:
             p = enc_prefix(lvl)
             s2, s1 = sp[f"{p}.4"], sp[f"{p}.0"]
             # a block output below the bottleneck also fed the max-pool of the next level: its dP is folded in by the reduction pass
-            g2 = self._bn_backward(s2, self.dP[lvl + 1] if lvl < 4 else None)
+            g2 = self._bn_backward(s2, self.dP[lvl + 1] if (lvl < 4 and s2.name not in self._pool_done) else None)
             self._wgrad_dgrad(s2, g2, self.dA[s1.name], s1.name)
             g1 = self._bn_backward(s1)
             if lvl == 0:
@@ -838,8 +863,8 @@ class UNetEngine:
                     self._fused_bwd(s1, g1, None, None, None)
                 else:
                     self._wgrad(s1, g1)
-            if lvl > 0:
-                self._wgrad_dgrad(s1, g1, self.dP[lvl])
+            if lvl > 0:      # (pool_fuse: the max-pool backward into the block output below rides in this dgrad's epilogue)
+                self._wgrad_dgrad(s1, g1, self.dP[lvl], pool_of=(enc_prefix(lvl - 1) + ".4") if self.pool_fuse else None)
             if lvl == 2 and self._deferred is not None:
                 flush(self._n_thin_enc_desc, self._n_enc_desc)
                 self._deferred = None

@@ -82,7 +82,11 @@ typedef struct HpfgConvArgs {
   int32_t taps;         /* 9 (3x3, pad 1) or 1 (1x1) */
   int32_t math;         /* HPFG_MATH_F32: exact fp32 MFMA, wpk = fp32 fragments; HPFG_MATH_BF16X3: split-bf16 MFMA (hi*hi+hi*lo+lo*hi,
                            fp32 accumulate), wpk = the wpk16_* buffer of hpfg_pack_weights */
-  int32_t bwd_stats;    /* dgrad only (BF16X3, DZ or PLAIN source): 1 = `out` is the COMPLETE gradient w.r.t. the activated output of the
+  int32_t bwd_stats;    /* dgrad only (BF16X3, DZ or PLAIN source).  2 (3x3): `out` would be the gradient w.r.t. MaxPool2d(2) of bwd_of's activated
+                           output (bwd_of at 2H x 2W, its gradient so far in bwd_of.aux, no dropout behind it): the epilogue adds the tile at the
+                           arg-max of each 2 x 2 window into bwd_of.aux IN PLACE (unet.py:37 backward), accumulates the backward sums of the
+                           completed gradient as below, and does not write `out` -- hpfg_bn_bwd_reduce_pool without its launch.
+                           1 = `out` is the COMPLETE gradient w.r.t. the activated output of the
                            BatchNorm layer described by `bwd_of`; stat_partials then receives that layer's backward sums
                            sum(g), sum(g*xhat)  (g = out * LeakyReLU' * dropout) instead of sum(z), sum(z*z) -- what hpfg_bn_bwd_reduce
                            would compute in a pass of its own; feed the rows to hpfg_bn_bwd_finalize */
