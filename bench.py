@@ -318,6 +318,10 @@ def layer_costs(eng, tag):
     if kind == "fwd":
         return f"forward conv, {cls}", x_b + o_b + w_b + act_st, fl
     if kind == "dgrad":
+        from hpfg_amd.engine import enc_prefix
+        pool_of = next((enc_prefix(lv - 1) + ".4" for lv in range(1, 5) if name == enc_prefix(lv) + ".0"), None)
+        if pool_of in getattr(eng, "_pool_done", ()):      # max-pool backward in the epilogue: z, the gradient so far (read + written) at 2H x 2W; no dP
+            return f"input gradient (separate dgrad), {cls}", 2 * o_b + 3 * 4 * px * s.cin * 4 + w_b + dz_st, fl
         return f"input gradient (separate dgrad), {cls}", 2 * o_b + px * s.cin * 4 + w_b + dz_st, fl
     if kind == "wgrad":
         return f"weight gradient (separate wgrad), {cls}", (dz_st or 2 * o_b) + (act_st or x_b), fl

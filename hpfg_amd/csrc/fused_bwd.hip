@@ -11,19 +11,14 @@ int launch(const HpfgFusedBwdArgs& a, hipStream_t st, bool grid_only) {
   if (grid_only) return grid;
   const int tx = a.d.W / T, ty = a.d.H / T;
   if constexpr (NODG) {
-    hipLaunchKernelGGL((fused_bwd_kernel<CI, CO, AK, GK, 0, NW, WGS, PFA, PFPOS, BMAX, true>), dim3(grid), dim3(64 * NW), 0, st, a, tx, ty);
+    hipLaunchKernelGGL((fused_bwd_kernel<CI, CO, AK, GK, false, NW, WGS, PFA, PFPOS, BMAX, true>), dim3(grid), dim3(64 * NW), 0, st, a, tx, ty);
   } else if (a.d.bwd_stats) {
-    if constexpr (AK == HPFG_KIND_BNACT) {
-      if (a.d.bwd_stats != 1) return -3;
-      hipLaunchKernelGGL((fused_bwd_kernel<CI, CO, AK, GK, 1, NW, WGS, PFA, PFPOS, BMAX>), dim3(grid), dim3(64 * NW), 0, st, a, tx, ty);
-    } else if constexpr (AK == HPFG_KIND_POOL) {
-      if (a.d.bwd_stats != 2) return -3;
-      hipLaunchKernelGGL((fused_bwd_kernel<CI, CO, AK, GK, 2, NW, WGS, PFA, PFPOS, BMAX>), dim3(grid), dim3(64 * NW), 0, st, a, tx, ty);
-    } else {
+    if constexpr (AK == HPFG_KIND_BNACT)
+      hipLaunchKernelGGL((fused_bwd_kernel<CI, CO, AK, GK, true, NW, WGS, PFA, PFPOS, BMAX>), dim3(grid), dim3(64 * NW), 0, st, a, tx, ty);
+    else
       return -3;
-    }
   } else {
-    hipLaunchKernelGGL((fused_bwd_kernel<CI, CO, AK, GK, 0, NW, WGS, PFA, PFPOS, BMAX>), dim3(grid), dim3(64 * NW), 0, st, a, tx, ty);
+    hipLaunchKernelGGL((fused_bwd_kernel<CI, CO, AK, GK, false, NW, WGS, PFA, PFPOS, BMAX>), dim3(grid), dim3(64 * NW), 0, st, a, tx, ty);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -87,23 +82,19 @@ extern "C" int hpfg_fused_bwd(const HpfgFusedBwdArgs* a, void* stream) {
     HPFG_ARG_CHECK((d.stat_partials || d.stat_acc) && d.bwd_of.z && d.bwd_of.bn, "fused_bwd: bwd_stats needs stat_partials or stat_acc, and bwd_of.z / .bn");
     HPFG_ARG_CHECK(!d.stat_acc || (d.stat_shards >= 1 && d.stat_shards <= HPFG_ACC_MAX_SHARDS && (d.stat_shards & (d.stat_shards - 1)) == 0),
                    "fused_bwd: bad stat_shards %d", d.stat_shards);
-    const int up = d.bwd_stats == 2 ? 2 : 1;      // 2: the max-pool backward epilogue (HpfgConvArgs.bwd_stats), bwd_of at twice the layer's size
-    HPFG_ARG_CHECK(d.bwd_stats == 1 || d.bwd_stats == 2, "fused_bwd: bwd_stats must be 0, 1 or 2");
-    HPFG_ARG_CHECK(d.bwd_of.C == d.Cout && d.Cout == d.CoutPad && d.bwd_of.Hs == up * d.H && d.bwd_of.Ws == up * d.W && d.bwd_of.pstride % 4 == 0,
-                   "fused_bwd: bwd_of must describe a layer with C == Cin == CinPad at the layer's size (twice it for bwd_stats == 2)");
-    // the epilogue takes the scale / shift rows (and, bwd_stats == 1, z) of that layer from the staged input tile
-    HPFG_ARG_CHECK(a->xa0.mode == (up == 2 ? HPFG_ACT_BNACT_POOL : HPFG_ACT_BNACT) && a->xa1.mode == 0 && d.bwd_of.z == a->xa0.z && d.bwd_of.bn == a->xa0.bn &&
+    HPFG_ARG_CHECK(d.bwd_of.C == d.Cout && d.Cout == d.CoutPad && d.bwd_of.Hs == d.H && d.bwd_of.Ws == d.W && d.bwd_of.pstride % 4 == 0,
+                   "fused_bwd: bwd_of must describe a layer with C == Cin == CinPad at the layer's size");
+    // the epilogue takes z and the scale / shift rows of that layer from the staged input tile
+    HPFG_ARG_CHECK(a->xa0.mode == HPFG_ACT_BNACT && a->xa1.mode == 0 && d.bwd_of.z == a->xa0.z && d.bwd_of.bn == a->xa0.bn &&
                        d.bwd_of.bn_coff == a->xa0.bn_coff && d.bwd_of.pstride == a->xa0.pstride,
-                   "fused_bwd: bwd_of must be the producer of this layer's (BNACT / BNACT_POOL) input");
-    HPFG_ARG_CHECK(up == 1 || (d.bwd_of.aux && d.bwd_of.aux_pstride % 4 == 0 && d.bwd_of.drop_p == 0.f && !d.out_split),
-                   "fused_bwd: bwd_stats == 2 needs bwd_of.aux (the gradient so far), no dropout behind bwd_of and one destination");
+                   "fused_bwd: bwd_of must be the producer of this layer's (BNACT) input");
   } else {
     HPFG_ARG_CHECK(!d.stat_partials && !d.stat_acc, "fused_bwd: stat_partials / stat_acc without bwd_stats");
   }
   const int r = dispatch(*a, (hipStream_t)stream, false);
   HPFG_ARG_CHECK(r != -2, "fused_bwd: no instantiation for CinPad %d, CoutPad %d, input kind %d, dZ kind %d", a->CinPad, a->CoutPad,
                  hpfg_kind_of(a->xa0, a->xa1), hpfg_kind_of(a->d.a0, a->d.a1));
-  HPFG_ARG_CHECK(r != -3, "fused_bwd: bwd_stats == 1 needs a BNACT input, bwd_stats == 2 a max-pooled one");
+  HPFG_ARG_CHECK(r != -3, "fused_bwd: bwd_stats needs a BNACT input");
   HPFG_ARG_CHECK(r == 0, "fused_bwd: launch failed");
   return 0;
 }

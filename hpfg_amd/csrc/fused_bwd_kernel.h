@@ -59,7 +59,7 @@ struct Split {
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
 };
 
-template <int CI, int CO, int AK, int GK, int NW, int BWD, int BMAX = 48>
+template <int CI, int CO, int AK, int GK, int NW, bool BWD, int BMAX = 48>
 struct Geo {
   static constexpr bool CATK = AK == HPFG_KIND_CAT;
   static constexpr int AK0 = CATK ? HPFG_KIND_BNACT : AK;          // loader kind of the chunks read through xa0 (concat: the skip half)
@@ -70,7 +70,7 @@ struct Geo {
   static constexpr int KS = 5 * CO;                                          // dgrad k-steps (2 taps x 16 channels each)
   static constexpr bool BREG = KS * CI * 8 <= BMAX;                            // dgrad weight fragments: registers (few) or LDS
   static constexpr int BFR = BREG ? 0 : KS * CI * 2 * 1024;
-  static constexpr bool ZLDS = BWD == 1 && AK == HPFG_KIND_BNACT;                 // raw z of the input tile for the epilogue of the layer below
+  static constexpr bool ZLDS = BWD && AK == HPFG_KIND_BNACT;                 // raw z of the input tile for the epilogue of the layer below
   static constexpr int ZPS = 64 * CI + 32;                                   // bytes per pixel of that tile
   static constexpr int ZL = ZLDS ? T * T * ZPS : 0;
   static constexpr int OFF_STAT = CO * DCH + CI * ACH, OFF_TABD = OFF_STAT + STAT, OFF_TABA = OFF_TABD + TABD, OFF_B = OFF_TABA + TABA,
@@ -88,14 +88,11 @@ __device__ __forceinline__ bf16x8 tr8(const unsigned char* p0, const unsigned ch
 // wider layers: per-thread staging registers and accumulators halve, which is what lets a whole tile be prefetched); WGS = workgroups per CU
 // to compile for; NODG = weight gradient only (the first layer: nothing to back-propagate into the network input); PFA = how many of the CI input chunks are prefetched a tile ahead together with dZ (the rest is requested when the tile
 // starts); PFPOS = where in the tile loop that prefetch is issued
-// BWD: 0 none; 1 = the BatchNorm-backward sums of the layer below from the epilogue (d.bwd_stats == 1, BNACT input); 2 = the input is
-// MaxPool2d(2) of the layer below: the epilogue is the max-pool backward into that layer's gradient + its sums (d.bwd_stats == 2, POOL input)
-template <int CI, int CO, int AK, int GK, int BWD, int NW, int WGS, int PFA, int PFPOS, int BMAX = 48, bool NODG = false>
+template <int CI, int CO, int AK, int GK, bool BWD, int NW, int WGS, int PFA, int PFPOS, int BMAX = 48, bool NODG = false>
 __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArgs p, int tiles_x, int tiles_y) {
   using C = Cfg<16, 16, 4, 1, CI, 9, 16>;               // (weight-fragment indexing of the dgrad side: CI output-channel tiles, K = 2 taps x 16 channels)
   using G = Geo<CI, CO, AK, GK, NW, BWD, BMAX>;
-  static_assert(BWD != 1 || AK == HPFG_KIND_BNACT, "the backward sums of the layer below need its raw output as this layer's input");
-  static_assert(BWD != 2 || AK == HPFG_KIND_POOL, "the max-pool backward epilogue belongs to a layer behind MaxPool2d(2)");
+  static_assert(!BWD || AK == HPFG_KIND_BNACT, "the backward sums of the layer below need its raw output as this layer's input");
   using SP = Split<NW>;
   constexpr int AK0 = G::AK0, NA0 = G::NA0, NA1 = G::NA1, NTH = SP::NTH, ND = SP::ND, NA = SP::NA, MI = SP::MI;
   __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
@@ -419,50 +416,9 @@ __global__ __launch_bounds__(64 * NW, WGS) void fused_bwd_kernel(HpfgFusedBwdArg
         const int pxl = (wave * MI + m) * 16 + (lane & 15);
         const int pix = (n * H + ty0 + pxl / T) * W + tx0 + pxl % T;
         const f32x4 v = acc[m][j];
-        if (BWD == 2) {      // v = dP of this pooled pixel: add it at the window's arg-max into the gradient of the layer below, in place (conv16_store_tile)
-          const HpfgAct& lb = p.d.bwd_of;
-          float* dA = const_cast<float*>(lb.aux);
-          const long p00 = ((long)n * lb.Hs + 2 * (ty0 + pxl / T)) * lb.Ws + 2 * (tx0 + pxl % T);
-          f32x4 z4[4], g4[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const long off = p00 + (k >> 1) * lb.Ws + (k & 1);
-            z4[k] = *reinterpret_cast<const f32x4*>(lb.z + off * lb.pstride + co);
-            g4[k] = *reinterpret_cast<const f32x4*>(dA + off * lb.aux_pstride + co);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float y[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) y[k] = z4[k][r] * tsc[r] + tsh[r];
-            float best = lrelu(y[0]);
-            int bi = 0;
-#pragma unroll
-            for (int k = 1; k < 4; ++k) {
-              const float a = lrelu(y[k]);
-              if (a > best) {
-                best = a;
-                bi = k;
-              }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              g4[k][r] += bi == k ? v[r] : 0.f;
-              const float gg = y[k] > 0.f ? g4[k][r] : HPFG_LEAKY * g4[k][r];
-              s1[j][r] += gg;
-              s2[j][r] += gg * z4[k][r];
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const long off = p00 + (k >> 1) * lb.Ws + (k & 1);
-            *reinterpret_cast<f32x4*>(dA + off * lb.aux_pstride + co) = g4[k];
-          }
-          continue;
-        }
         float* o = (p.d.out_split && co >= p.d.out_split) ? p.d.out2 + pix * p.d.out2_pstride + (co - p.d.out_split) : p.d.out + pix * p.d.out_pstride + co;
         *reinterpret_cast<f32x4*>(o) = v;
-        if (BWD == 1) {
+        if (BWD) {
           const f32x4 z = *reinterpret_cast<const f32x4*>(ldsZ + pxl * G::ZPS + co * 4);
           uint32_t km = 0xFu;
           if (p.d.bwd_of.drop_p > 0.f) km = keep4(p.d.bwd_of, bcx, (uint32_t)(pix * p.d.bwd_of.C + co));

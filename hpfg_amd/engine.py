@@ -190,7 +190,8 @@ class UNetEngine:
         # HpfgConvArgs.stage_out: the separate dgrad of a 3x3 layer also stores the dZ it stages, and (act_side) its forward conv the virtual
         # input it stages; the layer's weight gradient reads those tensors as PLAIN sources instead of deriving both again -- BatchNorm,
         # LeakyReLU, Dropout, max-pool / bilinear taps forward, their backward for dZ -- in every (input slice x output slice) workgroup
-        self.pool_fuse = int(os.environ.get("HPFG_POOL_FUSE", "1"))      # 1: the conv kernel's dgrads only, 2: the fused thin kernel's too
+        # the max-pool backward + BatchNorm-backward sums of a block output ride in the epilogue of the dgrad that produces dP (56 / 28 / 14-pixel levels)
+        self.pool_fuse = os.environ.get("HPFG_POOL_FUSE", "1") == "1"
         self._pool_done: set = set()
         self.dz_side = os.environ.get("HPFG_DZ_SIDE", "1") == "1"
         self.act_side = os.environ.get("HPFG_ACT_SIDE", "1") == "1"
@@ -632,7 +633,7 @@ class UNetEngine:
                      pool_of: Optional[str] = None):
         """Both gradients of layer s from the same dZ source (they only read it, so their order is free)."""
         if s.name in self.fused_grid:
-            return self._fused_bwd(s, g, dgrad_out, stats_for, out2, pool_of)
+            return self._fused_bwd(s, g, dgrad_out, stats_for, out2)      # (pool_of: the fused kernel's variant measured mixed, profiles/r04_schedule_experiments.txt)
         dz = None
         if self.dz_side and self.math == L.MATH_BF16X3 and self._side_layer(s) and g.mode == L.ACT_DZ and s.cout % 8 == 0:
             dz = self.dzbuf.get(s.name)
@@ -655,7 +656,7 @@ class UNetEngine:
         fused / thin kernels, which stage input and dZ once for both gradients already)."""
         return s.taps == 9 and bool(s.h % 16 or s.w % 16)
 
-    def _fused_bwd(self, s: ConvSpec, g: L.Act, out: torch.Tensor, stats_for: Optional[str], out2: Optional[torch.Tensor], pool_of: Optional[str] = None):
+    def _fused_bwd(self, s: ConvSpec, g: L.Act, out: torch.Tensor, stats_for: Optional[str], out2: Optional[torch.Tensor]):
         """hpfg_fused_bwd: dX into `out` (/ `out2`), the weight-gradient slabs of layer s and -- with stats_for -- the BatchNorm-backward
         sums of the layer below, from one read of (dA, z) and one read of the layer input."""
         fa = L.FusedBwdArgs()
@@ -677,15 +678,6 @@ class UNetEngine:
             if self._accb_live:
                 ca.stat_partials, ca.stat_acc, ca.stat_shards = None, L.ptr(self.accb_of[stats_for]), self.acc_shards[stats_for]
             self._fused_rows[stats_for] = rows
-        elif pool_of is not None and self.fuse_bwd_stats and self.pool_fuse >= 2 and s.cin == s.cin_pad and out2 is None and out is not None:
-            # (see _dgrad: the max-pool backward into layer pool_of's gradient + its sums in this kernel's epilogue; `out` is not written)
-            if rows * 2 * s.cin > self.partials.numel():
-                raise RuntimeError(f"fused_bwd[{s.name}]: {rows} rows of backward sums do not fit the partials workspace")
-            ca.bwd_stats, ca.bwd_of, ca.stat_partials = 2, self._act_dz(pool_of, self.dA[pool_of], self.dA_ps[pool_of]), L.ptr(self.partials)
-            if self._accb_live:
-                ca.stat_partials, ca.stat_acc, ca.stat_shards = None, L.ptr(self.accb_of[pool_of]), self.acc_shards[pool_of]
-            self._fused_rows[pool_of] = rows
-            self._pool_done.add(pool_of)
         self._last_fused[s.name] = fa      # (bench.py re-launches it alone)
         self._run("fused_bwd:" + s.name, lambda: L.check(self.lib.hpfg_fused_bwd(C.byref(fa), self._stream()), f"fused_bwd[{s.name}]"))
 
