@@ -378,6 +378,49 @@ def probe_families(wl, it, reps=6):
     return fams, longest, calib
 
 
+def probe_solo_forward(wl, family, calib, reps=4):
+    """The dominant forward family WITHOUT a second network beside it: train-mode forwards of the step's first network alone on the stream (the
+    teacher's / second student's launches of the same layers run side by side with these in the step, and each then sees half the chip), bracketed
+    by the same device time stamps.  Returns (us per forward, launches, flops, bytes) of `family`, or None where the workload has no such network."""
+    import numpy as np
+    import torch
+    from hpfg_amd.engine import MarkLog
+    from hpfg_amd.train import cat_batch
+    if wl.name not in ("mt", "sup") or not family.startswith("forward conv"):
+        return None
+    m = wl.models[0]
+    x = wl.inputs[0] if wl.name == "sup" else cat_batch(wl.inputs[0], wl.inputs[2])
+    engs = [e for pool in m._engines.values() for e in pool]
+    logs = {id(e): MarkLog(wl.dev) for e in engs}
+    acc = {}
+    try:
+        for r in range(reps):
+            for e in engs:
+                e.marks = logs[id(e)] if r >= 1 else None
+                logs[id(e)].n, logs[id(e)].spans = 0, []
+            with torch.no_grad():
+                m(x)
+            torch.cuda.synchronize(wl.dev)
+            if r >= 1:
+                for e in engs:
+                    for i, (tag, us) in enumerate(logs[id(e)].read_us()):
+                        acc.setdefault((id(e), i, tag), []).append(us)
+    finally:
+        for e in engs:
+            e.marks = None
+    eng_of = {id(e): e for e in engs}
+    us = fl = by = 0.0
+    n = 0
+    for (eid, _, tag), v in acc.items():
+        fam, b, f = layer_costs(eng_of[eid], tag)
+        if fam == family:
+            us += max(float(np.mean(v)) - calib, 0.0)
+            fl += f
+            by += b
+            n += 1
+    return (us, n, fl, by) if n else None
+
+
 def roofline_objects(wl, fams, longest, calib, math):
     passes = 3.0 if math == "bf16x3" else 16.0      # bf16 MFMA-equivalents per product (exact-fp32 MFMA runs at 1/16 of the bf16 rate)
     total = sum(f["us"] for f in fams.values())
@@ -414,6 +457,17 @@ def roofline_objects(wl, fams, longest, calib, math):
                         for k, f in sorted(fams.items(), key=lambda kv: -kv[1]["us"])}
     if longest is not None:
         roof["longest_launch"] = obj(f"{longest['tag']} ({longest['family']})", longest["us"], longest["bytes"], longest["flops"])
+    try:
+        solo = probe_solo_forward(wl, name, calib)
+    except Exception as e:
+        print(f"[bench] solo probe failed ({type(e).__name__}: {e})", file=sys.stderr)
+        solo = None
+    if solo is not None:      # the same family with nothing beside it: what the kernels do with the whole chip (NOT the step's schedule)
+        us, n, fl, by = solo
+        roof["alone_on_the_chip"] = {"launches": n, "avg_launch_us": round(us / n, 2), "mfma_frac": round(fl * passes / (us * 1e-6) / 2.5e15, 4),
+                                     "hbm_frac": round(by / (us * 1e-6) / 8e12, 4),
+                                     "note": "train-mode forwards of the step's first network alone on one stream, same brackets; `frac` above is measured "
+                                             "in the step, where the other network's launches of the same layers share the chip"}
     return roof
 
 

@@ -191,10 +191,10 @@ class UNetEngine:
         # input it stages; the layer's weight gradient reads those tensors as PLAIN sources instead of deriving both again -- BatchNorm,
         # LeakyReLU, Dropout, max-pool / bilinear taps forward, their backward for dZ -- in every (input slice x output slice) workgroup
         # the max-pool backward + BatchNorm-backward sums of a block output ride in the epilogue of the dgrad that produces dP (56 / 28 / 14-pixel levels)
-        self.pool_fuse = os.environ.get("HPFG_POOL_FUSE", "1") == "1"
+        self.pool_fuse = True
         self._pool_done: set = set()
-        self.dz_side = os.environ.get("HPFG_DZ_SIDE", "1") == "1"
-        self.act_side = os.environ.get("HPFG_ACT_SIDE", "1") == "1"
+        self.dz_side = True      # (attributes, not environment switches: tests and A/B tools set them on the engine)
+        self.act_side = True
         self.dzbuf: Dict[str, torch.Tensor] = {}
         self.actbuf: Dict[str, torch.Tensor] = {}
         self._act_live: set = set()      # layers whose actbuf this forward wrote

@@ -71,3 +71,32 @@ def test_every_pixel_of_the_side_tensors_is_written():
         assert torch.isfinite(t).all(), name
     for k, p in m.named_parameters():
         assert torch.isfinite(p.grad).all(), k
+
+
+@pytest.mark.parametrize("n,hw", [(2, 48), (2, 112)])
+def test_max_pool_backward_in_the_dgrad_epilogue(n, hw):
+    """HpfgConvArgs.bwd_stats == 2: the dgrad that would produce dP adds it at the window's arg-max into the gradient of the block output below
+    and takes that layer's BatchNorm-backward sums in its epilogue (hpfg_bn_bwd_reduce_pool without its launch).  Same adds on the same values:
+    every parameter gradient agrees with the separate-launch path to the rounding of the differently ordered sums."""
+    def run(fuse):
+        reset_dropout_streams()
+        torch.manual_seed(21)
+        m = UNet(1, 4).to(DEV)
+        m.train()
+        x, lab = synth_batch(6, n, hw, hw, 1, 4, cell=8)
+        with torch.no_grad():
+            m(x.to(DEV))
+        eng = next(iter(m._engines.values()))[0]
+        eng.pool_fuse = fuse
+        out = m(x.to(DEV))
+        Med_Sup_Loss(4)(out, lab.to(DEV)).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}, eng
+
+    g1, e1 = run(True)
+    assert len(e1._pool_done) == 4, e1._pool_done          # every pooled level here (at 224 x 224 the 112-pixel level runs the fused thin kernel: 3)
+    g0, e0 = run(False)
+    assert not e0._pool_done
+    for k in g0:
+        d = float((g1[k] - g0[k]).abs().max())
+        assert d <= 5e-5 * max(1e-3, float(g0[k].abs().max())), (k, d, float(g0[k].abs().max()))
