@@ -37,13 +37,17 @@ class _Linear(torch.autograd.Function):
     """y = relu?(x W^T + b); x [R,K] contiguous, W [M,K] contiguous (an nn.Linear weight or a flattened 1x1 conv weight)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu: bool):
+    def forward(ctx, x, w, b, relu: bool, wp=None, bp=None):
+        """wp / bp (optional): the Parameters behind w / b of a network in ``direct_grads`` mode (one zero_grad + one backward per step): backward
+        then WRITES dW / db into their .grad views of the flat gradient buffer -- no temporary, no AccumulateGrad add per tensor (16 small
+        launches per U-Net+ and step on the chain of backward) -- and hands autograd nothing for them."""
         x, w = x.contiguous(), w.contiguous()
         R, K = x.shape
         M = w.shape[0]
         y = gemm(x, K, 1, w, 1, K, R, M, K, bias=b, relu=relu)
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.relu = relu
+        ctx.direct = (wp, bp) if (wp is not None and bp is not None and wp.grad is not None and bp.grad is not None) else None
         return y
 
     @staticmethod
@@ -54,14 +58,20 @@ class _Linear(torch.autograd.Function):
         lib = L.load()
         dy = dy.contiguous()
         if ctx.relu:
-            dy = dy.clone()
+            if ctx.direct is None:
+                dy = dy.clone()      # (direct mode: dy is the next layer's freshly made dx and has no other reader -- masked in place)
             L.check(lib.hpfg_relu_bwd(L.ptr(dy), L.ptr(y), dy.numel(), _st(dy)), "relu_bwd")
         dx = gemm(dy, M, 1, w, K, 1, R, K, M) if ctx.needs_input_grad[0] else None              # dY W
+        scratch = torch.empty(lib.hpfg_col_sum_splits(R) * M, dtype=torch.float32, device=dy.device)
+        if ctx.direct is not None:
+            wp, bp = ctx.direct
+            gemm(dy, 1, M, x, K, 1, M, K, R, out=wp.grad.view(M, K))                             # dY^T X, straight into the flat gradient buffer
+            L.check(lib.hpfg_col_sum2(L.ptr(dy), R, M, M, L.ptr(bp.grad), L.ptr(scratch), _st(dy)), "col_sum2")
+            return dx, None, None, None, None, None
         dw = gemm(dy, 1, M, x, K, 1, M, K, R)                                                    # dY^T X
         db = torch.empty(M, dtype=torch.float32, device=dy.device)
-        scratch = torch.empty(lib.hpfg_col_sum_splits(R) * M, dtype=torch.float32, device=dy.device)
         L.check(lib.hpfg_col_sum2(L.ptr(dy), R, M, M, L.ptr(db), L.ptr(scratch), _st(dy)), "col_sum2")
-        return dx, dw, db, None
+        return dx, dw, db, None, None, None
 
 
 class _NeckPool(torch.autograd.Function):
@@ -89,15 +99,20 @@ class _NeckPool(torch.autograd.Function):
         return dx.permute(0, 3, 1, 2), None
 
 
-def projection_neck(m, x: torch.Tensor, s: int = 4):
+def projection_neck(m, x: torch.Tensor, s: int = 4, direct: bool = False):
     """x: [N,C,H,W] (any strides).  Returns (g [N,128], d [N,128,s*s]) like projection_conv.forward (unet.py:139-152); d is a view of
-    [N, s*s, 128] memory (position-major), which Dense_Loss consumes without a copy."""
+    [N, s*s, 128] memory (position-major), which Dense_Loss consumes without a copy.
+    direct: the network is in ``direct_grads`` mode and its neck parameters' .grad are views of the flat gradient buffer: see _Linear."""
     if not x.is_cuda:
         raise RuntimeError("hpfg_amd necks run on the HIP library only (no CPU fallback)")
     gap, pool = _NeckPool.apply(x.float(), s)
-    g = _Linear.apply(_Linear.apply(gap, m.mlp["0"].weight, m.mlp["0"].bias, True), m.mlp["2"].weight, m.mlp["2"].bias, False)
-    w0, w2 = m.mlp_conv["0"].weight, m.mlp_conv["2"].weight
-    d = _Linear.apply(_Linear.apply(pool, w0.flatten(1), m.mlp_conv["0"].bias, True), w2.flatten(1), m.mlp_conv["2"].bias, False)
+
+    def lin(x_, layer, relu, flat=False):
+        w, b = layer.weight, layer.bias
+        return _Linear.apply(x_, w.flatten(1) if flat else w, b, relu, w if direct else None, b if direct else None)
+
+    g = lin(lin(gap, m.mlp["0"], True), m.mlp["2"], False)
+    d = lin(lin(pool, m.mlp_conv["0"], True, True), m.mlp_conv["2"], False, True)
     N = x.shape[0]
     return g, d.view(N, s * s, d.shape[1]).permute(0, 2, 1)
 

@@ -256,10 +256,9 @@ class UNet(nn.Module):
         (slots backward never writes, e.g. biases in front of a train-mode BatchNorm, stay at their initial zero), which is what
         a zero_grad() + one backward() per step amounts to.  The fused step classes switch it on; loops that accumulate several
         backward passes into .grad must leave it off."""
-        if getattr(self, "direct_grads", False):
-            n = self._backbone_numel
-            if n < self._flat_grad.numel():
-                self._flat_grad[n:].zero_()          # projection-neck gradients still come from torch autograd
+        if getattr(self, "direct_grads", False):      # (the projection necks' backward overwrites its slots too: heads._Linear)
+            if os.environ.get("HPFG_NECK_AB", "1") != "1" and self._backbone_numel < self._flat_grad.numel():
+                self._flat_grad[self._backbone_numel:].zero_()
             return
         self._flat_grad.zero_()
 
@@ -378,6 +377,9 @@ class UNet_Plus(UNet):
     def forward(self, x):
         self._prepare_head_grads()
         logits, feat = self._run(x, True)
-        high = heads.projection_neck(self.dense_projection_high, feat)
-        head = heads.projection_neck(self.dense_projection_head, logits)
+        if getattr(self, "skip_necks", False):      # set by a step that discards them (HPFG's first student, main.py:152): nothing to compute, no gradient
+            return logits, None, None
+        direct = bool(getattr(self, "direct_grads", False)) and torch.is_grad_enabled() and os.environ.get("HPFG_NECK_AB", "1") == "1"
+        high = heads.projection_neck(self.dense_projection_high, feat, direct=direct)
+        head = heads.projection_neck(self.dense_projection_head, logits, direct=direct)
         return logits, high, head

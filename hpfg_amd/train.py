@@ -598,6 +598,12 @@ class HPFGStep(_StepBase):
         self.optimizer1._lr_dev = self.sc.view(S_LR1)
         self.optimizer2._lr_dev = self.sc.view(S_LR2)
         self._set_grad_scale(self.optimizer1, self.optimizer2)
+        if hasattr(model1, "dense_projection_high") and os.environ.get("HPFG_NECK_AB", "1") == "1":
+            # main.py:152 discards the first student's neck outputs: their parameters never get a gradient (torch's SGD then skips them: no
+            # weight decay, no momentum), so the necks are not computed at all and the optimizer stops at the backbone
+            model1.skip_necks = True
+            if isinstance(self.optimizer1, FusedSGD):
+                self.optimizer1.active_numel = model1._backbone_numel
         self.dense_loss = Dense_Loss(args.batch_size + args.unlabel_batch_size, self.dev)
         self.dense_loss.dp = dp      # global-batch mode: NT-Xent over the gathered features of all ranks (main.py:172 contrasts the whole batch)
         self.mask_generator = BoxMaskGenerator(prop_range=(0.25, 0.5), n_boxes=4, random_aspect_ratio=True, prop_by_area=True,

@@ -23,6 +23,9 @@ class FusedSGD(torch.optim.Optimizer):
         self._lr_host = torch.zeros(1, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(1)
         self._lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.grad_scale = 1.0
+        # torch.optim.SGD skips a parameter whose .grad is None (no weight decay, no momentum).  A step that never back-propagates into a
+        # trailing part of the flat buffer (HPFG's first student: its projection necks' outputs are discarded, main.py:152) says so here.
+        self.active_numel = None
 
     def zero_grad(self, set_to_none: bool = False):
         self.model.zero_flat_grad()          # one memset; p.grad views stay attached
@@ -44,14 +47,15 @@ class FusedSGD(torch.optim.Optimizer):
         if push_lr:
             self.push_lr()
         st = torch.cuda.current_stream(flat.device).cuda_stream
+        n_sgd = flat.numel() if self.active_numel is None else int(self.active_numel)
         if ema is not None:
             t, n_ema, alpha_dev = ema
-            assert t.is_cuda and t.dtype == torch.float32 and t.numel() == flat.numel() and 0 <= n_ema <= flat.numel()
-            L.check(L.load().hpfg_sgd_ema_step(L.ptr(flat), L.ptr(grad), L.ptr(self._mom), flat.numel(), L.ptr(self._lr_dev), float(g["momentum"]),
+            assert t.is_cuda and t.dtype == torch.float32 and t.numel() == flat.numel() and 0 <= n_ema <= n_sgd
+            L.check(L.load().hpfg_sgd_ema_step(L.ptr(flat), L.ptr(grad), L.ptr(self._mom), n_sgd, L.ptr(self._lr_dev), float(g["momentum"]),
                                                float(g["weight_decay"]), float(self.grad_scale), L.ptr(t), int(n_ema), L.ptr(alpha_dev), st),
                     "sgd_ema_step")
             return
-        L.check(L.load().hpfg_sgd_step(L.ptr(flat), L.ptr(grad), L.ptr(self._mom), flat.numel(), L.ptr(self._lr_dev), float(g["momentum"]),
+        L.check(L.load().hpfg_sgd_step(L.ptr(flat), L.ptr(grad), L.ptr(self._mom), n_sgd, L.ptr(self._lr_dev), float(g["momentum"]),
                                        float(g["weight_decay"]), float(self.grad_scale), st), "sgd_step")
 
     def state_dict(self):
