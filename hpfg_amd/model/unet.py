@@ -257,8 +257,6 @@ class UNet(nn.Module):
         a zero_grad() + one backward() per step amounts to.  The fused step classes switch it on; loops that accumulate several
         backward passes into .grad must leave it off."""
         if getattr(self, "direct_grads", False):      # (the projection necks' backward overwrites its slots too: heads._Linear)
-            if os.environ.get("HPFG_NECK_AB", "1") != "1" and self._backbone_numel < self._flat_grad.numel():
-                self._flat_grad[self._backbone_numel:].zero_()
             return
         self._flat_grad.zero_()
 
@@ -379,7 +377,7 @@ class UNet_Plus(UNet):
         logits, feat = self._run(x, True)
         if getattr(self, "skip_necks", False):      # set by a step that discards them (HPFG's first student, main.py:152): nothing to compute, no gradient
             return logits, None, None
-        direct = bool(getattr(self, "direct_grads", False)) and torch.is_grad_enabled() and os.environ.get("HPFG_NECK_AB", "1") == "1"
+        direct = bool(getattr(self, "direct_grads", False)) and torch.is_grad_enabled()
         high = heads.projection_neck(self.dense_projection_high, feat, direct=direct)
         head = heads.projection_neck(self.dense_projection_head, logits, direct=direct)
         return logits, high, head

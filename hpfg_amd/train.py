@@ -598,7 +598,7 @@ class HPFGStep(_StepBase):
         self.optimizer1._lr_dev = self.sc.view(S_LR1)
         self.optimizer2._lr_dev = self.sc.view(S_LR2)
         self._set_grad_scale(self.optimizer1, self.optimizer2)
-        if hasattr(model1, "dense_projection_high") and os.environ.get("HPFG_NECK_AB", "1") == "1":
+        if hasattr(model1, "dense_projection_high"):
             # main.py:152 discards the first student's neck outputs: their parameters never get a gradient (torch's SGD then skips them: no
             # weight decay, no momentum), so the necks are not computed at all and the optimizer stops at the backbone
             model1.skip_necks = True
