@@ -481,7 +481,7 @@ extern "C" int hpfg_bn_bwd_pool_blocks(int N, int Hp, int Wp, int C) {
   const int PL = 256 / (C / 4);
   long want = (npool + (long)PL * 2 - 1) / ((long)PL * 2);      // 2 windows = 8 pixels per thread: one trip of the kernel's loop
   if (want < 1) want = 1;
-  return (int)(want > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : want);
+  return (int)(want > 2 * BWD_MAX_BLOCKS ? 2 * BWD_MAX_BLOCKS : want);      // (224 -> 112 at 16 images: 1568 -- one full trip each, not one and a half)
 }
 
 static int bn_bwd_reduce_pool_impl(const HpfgAct* g, const float* dP, int dp_pstride, int N, int Hp, int Wp, float* partials, long long* acc, int shards,

@@ -127,6 +127,7 @@ class UNetEngine:
         self.bn: Dict[str, torch.Tensor] = {s.name: torch.zeros(L.BN_ROWS, s.cout, **f32) for s in self.order if s.bn}
         nb = max(self.lib.hpfg_conv_stat_blocks(N, s.h, s.w) * 2 * s.cout_pad for s in self.order if s.bn)
         nb = max(nb, max(self.lib.hpfg_bn_bwd_blocks(N, s.h, s.w, s.cout) * 2 * s.cout for s in self.order if s.bn))
+        nb = max(nb, max(self.lib.hpfg_bn_bwd_pool_blocks(N, s.h // 2, s.w // 2, s.cout) * 2 * s.cout for s in self.order if s.bn))
         self.partials = torch.empty(nb, **f32)
         self.sums = torch.empty(2 * 256, dtype=torch.float64, device=device)
         # packed weights (the first conv reads OIHW directly)

@@ -242,6 +242,8 @@ def test_hpfg_trace(golden_dir, math):
     args.model1 = _opt_args(weight_decay=5e-4)
     args.model2 = _opt_args(weight_decay=5e-4)
     st = HPFGStep(m1, m2, ema, args)
+    necks0 = {k: v.detach().clone() for k, v in m1.state_dict().items() if k.startswith("dense_projection")}
+    necks2 = {k: v.detach().clone() for k, v in m2.state_dict().items() if k.startswith("dense_projection")}
     # the fixture was produced with a constant lr of 0.01 (no scheduler stepping): pin the schedulers' effect
     xl, yl, xl1, yl1, xu = (torch.from_numpy(d[k]).to(DEV) for k in ("xl", "yl", "xl1", "yl1", "xu"))
     rows = []
@@ -261,6 +263,10 @@ def test_hpfg_trace(golden_dir, math):
     assert maxerr(r["logits1"].cpu(), torch.from_numpy(d["logits1_last"])) < tol
     assert maxerr(r["logits2"].cpu(), torch.from_numpy(d["logits2_last"])) < tol
     assert maxerr(r["t_logits"].cpu(), torch.from_numpy(d["t_logits_last"])) < tol
+    # main.py:152 discards the first student's neck outputs: no gradient -> torch's SGD leaves those parameters alone (no weight decay either);
+    # the second student's necks train
+    assert necks0 and all(torch.equal(v, m1.state_dict()[k]) for k, v in necks0.items())
+    assert any(not torch.equal(v, m2.state_dict()[k]) for k, v in necks2.items())
 
 
 @pytest.mark.parametrize("math", ["f32", "bf16x3"])
