@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional
 
 import torch

@@ -19,7 +19,6 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from copy import deepcopy
 from typing import Dict, Optional
 
 import numpy as np
