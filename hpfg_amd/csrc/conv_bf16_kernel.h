@@ -825,6 +825,9 @@ int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
     // on 256->128 @28; a 128-wide slice (two channel tiles per wave, shallow B ring) is slower again.
     // (round 4: 8-wave workgroups for the <= 256-workgroup layers -- two k-groups per staged chunk, or 128-wide slices -- sped those launches up
     // by 10-25 % and the step down by 2 %: such a workgroup owns its CU and the other stream's kernels lose their share; profiles/r04_conv8_lever_b.txt)
+    // (round 4: the same 64 x 64 tile as 2 x 2 waves of 2 pixel tiles x 2 channel tiles -- half the LDS reads of A fragments, which the SQ
+    // counters make the longest of the kernel's three pipes, but a B ring of 3 instead of 9 k-steps -- measured +7 % on the step,
+    // profiles/r04_schedule_experiments.txt)
     if (cp % 64 == 0) return launch_cfg<Cfg<4, 16, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only);
     if (cp % 32 == 0) return launch_cfg<Cfg<4, 16, 2, 2, 1, TAPS, 32>, KIND>(a, st, rows_only);
     return launch_cfg<Cfg<4, 16, 4, 1, 1, TAPS, 32>, KIND>(a, st, rows_only);
