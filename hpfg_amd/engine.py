@@ -804,9 +804,19 @@ class UNetEngine:
                 if not self._csum_done:          # out_conv's bias sums ride along with the first batch
                     csum(self._side.cuda_stream)
                     self._csum_done = True
-                for s_, g_ in self._deferred:
-                    self._wgrad(s_, g_, on_side=True)
-                self._slab_reduce(lo, hi, self._side.cuda_stream)
+                split = hi == self._n_enc_desc and lo + 2 < hi and len(self._deferred) == hi - lo
+                if split:      # the deeper levels first, their slabs reduced beside the last level's weight gradients: the serial piece at the stream's
+                    # end -- it finished AFTER the main chain -- shrinks from 58 to ~20 us (with the reduction below: mt -0.8 %)
+                    for s_, g_ in self._deferred[:-2]:
+                        self._wgrad(s_, g_, on_side=True)
+                    self._slab_reduce(lo + 2, hi, self._side.cuda_stream)
+                    for s_, g_ in self._deferred[-2:]:
+                        self._wgrad(s_, g_, on_side=True)
+                    self._slab_reduce(lo, lo + 2, self._side.cuda_stream)
+                else:
+                    for s_, g_ in self._deferred:
+                        self._wgrad(s_, g_, on_side=True)
+                    self._slab_reduce(lo, hi, self._side.cuda_stream)
                 self._side_used = True
 
         # ---- decoder blocks, last to first
@@ -861,6 +871,11 @@ class UNetEngine:
             if lvl == 2 and self._deferred is not None:
                 flush(self._n_thin_enc_desc, self._n_enc_desc)
                 self._deferred = None
+        tail_first = defer and bucket_cb is None
+        if tail_first:
+            # the thin encoder layers' slabs come from fused kernels on THIS stream: reduce them before the join, beside the side stream's last
+            # launches, instead of behind the join and the finalize launch
+            self._slab_reduce(0, self._n_thin_enc_desc)
         if self._side_used:
             torch.cuda.current_stream(self.dev).wait_stream(self._side)
             self._side_used = False
@@ -870,7 +885,7 @@ class UNetEngine:
         if bucket_cb is not None:
             self._slab_reduce(0, self._n_enc_desc)
             bucket_cb(1)
-        elif defer:
+        elif defer and not tail_first:
             self._slab_reduce(0, self._n_thin_enc_desc)      # the rest was reduced on the side stream
         else:
             self._slab_reduce(0, len(self._slab_host))
