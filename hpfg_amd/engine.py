@@ -885,8 +885,7 @@ class UNetEngine:
         if bucket_cb is not None:
             self._slab_reduce(0, self._n_enc_desc)
             bucket_cb(1)
-        elif defer and not tail_first:
-            self._slab_reduce(0, self._n_thin_enc_desc)      # the rest was reduced on the side stream
-        else:
+        elif not defer:
             self._slab_reduce(0, len(self._slab_host))
+        # (defer: the thin layers' slabs were reduced in front of the join above, everything else on the side stream)
         self.bwd_ready = False
