@@ -840,9 +840,6 @@ class UNetEngine:
             prev = enc_prefix(4) + ".4" if k == 1 else f"decoder.up{k - 1}.conv.conv_conv.4"
             # the 1x1 conv is the only consumer of the block output below (the bottleneck also feeds the dense head of UNet_Plus)
             self._wgrad_dgrad(su, gu, self.dA[prev], prev if (k > 1 or dfeat4 is None) else None)
-            if self._deferred and k == int(os.environ.get("HPFG_EARLY", "0")):      # (experiment) an early batch of the queued launches
-                flush(0, 0)
-                self._deferred = []
         if dfeat4 is not None:
             self.dA[enc_prefix(4) + ".4"].add_(dfeat4)
         defer = self._deferred is not None
