@@ -164,6 +164,7 @@ class UNetEngine:
         # set by the model for the network that runs on the step's ORIGIN stream (the single trainable network of a step): its weight packing
         # (22 us) runs on the side stream beside the first conv, which reads the OIHW weights directly and needs nothing the launch produces
         self.pack_overlap = False
+        self.after_layer = None      # (layer index, callable): the step enqueues another network's forward behind that layer (graph submission order)
         # the same for the backward sums (sum g, sum g * xhat): added by the dgrad epilogue / the reduction pass that completes a layer's
         # gradient, read by every dZ consumer's prologue (k1 .. k3 derived there), turned into dgamma / dbeta -- and zeroed again -- by ONE
         # launch per backward (hpfg_bn_acc_bwd_finalize) instead of 18 finalize launches on the critical chain
@@ -440,6 +441,8 @@ class UNetEngine:
                 main.wait_stream(self._side)
                 continue
             self._fwd_layer(s, logits, train, track_running)
+            if self.after_layer is not None and i == self.after_layer[0]:
+                self.after_layer[1]()
         if self._acc_live:
             self._finalize_all(track_running)
             self._acc_dirty = False

@@ -304,6 +304,7 @@ class UNet(nn.Module):
         eng.math = L.MATH_BF16X3 if self.math == "bf16x3" else L.MATH_F32
         eng.defer_wgrad = bool(getattr(self, "defer_wgrad", False))
         eng.pack_overlap = bool(getattr(self, "_alone", False))
+        eng.after_layer = getattr(self, "_after_layer", None)
         ext = self.external_dropout_masks
         if isinstance(ext, (list, tuple)):      # tests: one mask set per forward, consumed in order (several forwards per step)
             k = getattr(self, "_ext_mask_idx", 0)

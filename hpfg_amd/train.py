@@ -281,6 +281,7 @@ class MeanTeacherStep(_StepBase):
         self.lr_scheduler = build_lr_scheduler(args=args, optimizer=self.optimizer)
         self.optimizer._lr_dev = self.sc.view(S_LR1)
         self._set_grad_scale(self.optimizer)
+        self.teacher_after = 7      # the teacher's launches enter the step behind this layer of the student's forward (see device_fwd_bwd)
 
     def host_scalars(self, cur_itrs, cons_w=None):
         a = self.args
@@ -296,9 +297,36 @@ class MeanTeacherStep(_StepBase):
         nl = label_img.shape[0]
         x = cat_batch(label_img, unlabel_img)
         self._mark(0)
-        t_out = self._teacher_forward(self.ema_model, x)
-        self._mark(1)
-        out = self.model(x)
+        if self.overlap:
+            # A captured graph submits its nodes in creation order and the earlier-submitted network wins the CUs layer by layer: with the
+            # teacher captured first the student -- whose forward also stores the side tensors and is what the loss waits for -- started 120 us
+            # late and finished 130 - 170 us behind the teacher (in-graph stamps, tools/stream_timeline.py).  So the student's nodes come
+            # first and the teacher's enter behind its 8th layer, forked from an event recorded at the step's start (no data dependency on
+            # the student): both now end within ~30 us of each other, the loss starts ~60 us earlier (profiles/r04_schedule_experiments.txt).
+            cur = torch.cuda.current_stream(self.dev)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._mark(1)
+            box = []
+
+            def teacher():
+                with torch.cuda.stream(self.side), torch.no_grad():
+                    self.side.wait_event(ev)
+                    self._mark(2)
+                    box.append(self.ema_model(x))
+                    self._mark(3)
+
+            self.model._after_layer = (self.teacher_after, teacher)
+            out = self.model(x)
+            self.model._after_layer = None
+            if not box:
+                teacher()
+            t_out = box[0]
+            self._pending_join = True
+        else:
+            t_out = self._teacher_forward(self.ema_model, x)
+            self._mark(1)
+            out = self.model(x)
         self._mark(4)
         self._join_teacher(t_out)
         return self._loss_bwd(out, t_out, target_label, nl)
