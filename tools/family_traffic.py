@@ -23,7 +23,7 @@ def load(d, name):
 
 def fam(n):
     if "conv_bf16x3_kernel" in n:
-        m = re.search(r">, (\d), (true|false)", n)
+        m = re.search(r">, (\d), (true|false|\d)>", n)      # (kind, backward-epilogue variant)
         kind = int(m.group(1)) if m else -1
         if kind in (1, 2, 3):
             return "forward conv, channel-rich 3x3 (>= 32 channels in and out)"
