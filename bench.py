@@ -289,11 +289,15 @@ def layer_costs(eng, tag):
     wgrad = dA + z + stored input; fused backward = dA + z + stored input + dX.  Layers with side tensors (HpfgConvArgs.stage_out): the
     forward conv also writes its staged input, the dgrad its dZ, and the weight gradient reads those two tensors instead.  FLOPs: 2 x taps x Cin x Cout per output pixel and pass."""
     kind, name = tag.split(":", 1) if ":" in tag else (tag, "")
+    mult = 1
+    for base in ("fwd", "pack_weights", "bn_fin_all"):      # "fwdx2:<conv>": ONE launch for the layer in 2 networks (hpfg_conv_fwd_multi)
+        if kind.startswith(base + "x") and kind[len(base) + 1:].isdigit():
+            kind, mult = base, int(kind[len(base) + 1:])
     s = eng.specs.get(name)
     if s is None or kind not in ("fwd", "dgrad", "wgrad", "fused_bwd"):
         return {"bn_fin": "BatchNorm forward finalize", "bn_red": "BatchNorm backward reduction (+ max-pool backward)", "bn_bfin": "BatchNorm backward finalize",
                 "upbwd": "bilinear upsample backward", "slab_reduce": "weight-gradient slab reduction", "pack_weights": "weight packing",
-                "csum": "bias-gradient channel sums"}.get(kind, kind), 0.0, 0.0
+                "csum": "bias-gradient channel sums"}.get(kind, kind), 0.0, 0.0, 0.0
     N = eng.N
     px = N * s.h * s.w
     if name.startswith("decoder.up") and name.endswith("conv.conv_conv.0"):
@@ -312,21 +316,28 @@ def layer_costs(eng, tag):
         cls = "channel-rich 3x3 (>= 32 channels in and out)"
     else:
         cls = "thin 3x3 (< 32 channels in or out: the 224 x 224 / 112 x 112 layers and out_conv)"
-    # HpfgConvArgs.stage_out: a forward conv / dgrad that also stores what it staged, a weight gradient that reads the stored tensors instead
+    # The ALGORITHMIC bytes are SURVEY.md section 8(d)'s model and nothing else: a conv reads its logical input once and writes its raw output
+    # once; backward per conv reads (dA, z) [+ the input for the weight gradient] and writes dX.  What this build moves BESIDE that -- the side
+    # tensors of HpfgConvArgs.stage_out (a forward conv / dgrad also stores what it staged), the max-pool backward riding in a dgrad epilogue,
+    # the weight-gradient slabs written for the fixed-order reduction -- is returned separately as overhead bytes.
     act_st = px * s.cin * 4 if name in getattr(eng, "_act_live", ()) else 0
     dz_st = o_b if name in getattr(eng, "dzbuf", {}) else 0
+    slab = 0
+    if hasattr(eng, "slab_of") and name in getattr(eng, "slab_of", {}):
+        S = eng.fused_grid.get(name) or eng.lib.hpfg_wgrad_splits(N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps)
+        slab = S * s.taps * s.cin_pad * s.cout_pad * 4
     if kind == "fwd":
-        return f"forward conv, {cls}", x_b + o_b + w_b + act_st, fl
+        return f"forward conv, {cls}", mult * (x_b + o_b + w_b), mult * fl, act_st
     if kind == "dgrad":
         from hpfg_amd.engine import enc_prefix
         pool_of = next((enc_prefix(lv - 1) + ".4" for lv in range(1, 5) if name == enc_prefix(lv) + ".0"), None)
-        if pool_of in getattr(eng, "_pool_done", ()):      # max-pool backward in the epilogue: z, the gradient so far (read + written) at 2H x 2W; no dP
-            return f"input gradient (separate dgrad), {cls}", 2 * o_b + 3 * 4 * px * s.cin * 4 + w_b + dz_st, fl
-        return f"input gradient (separate dgrad), {cls}", 2 * o_b + px * s.cin * 4 + w_b + dz_st, fl
+        # max-pool backward in the epilogue: z and the gradient so far (read + written) at 2H x 2W instead of writing dP
+        pool_x = (3 * 4 - 1) * px * s.cin * 4 if pool_of in getattr(eng, "_pool_done", ()) else 0
+        return f"input gradient (separate dgrad), {cls}", 2 * o_b + px * s.cin * 4 + w_b, fl, dz_st + pool_x
     if kind == "wgrad":
-        return f"weight gradient (separate wgrad), {cls}", (dz_st or 2 * o_b) + (act_st or x_b), fl
+        return f"weight gradient (separate wgrad), {cls}", 2 * o_b + x_b, fl, slab
     dx = 0 if s.idx == 0 else px * s.cin * 4
-    return f"fused dgrad + wgrad, {cls}", 2 * o_b + x_b + dx + w_b, fl * (1 if s.idx == 0 else 2)
+    return f"fused dgrad + wgrad, {cls}", 2 * o_b + x_b + dx + w_b, fl * (1 if s.idx == 0 else 2), slab
 
 
 def probe_families(wl, it, reps=6):
@@ -367,12 +378,13 @@ def probe_families(wl, it, reps=6):
         if tag == "calib":
             continue
         us = max(float(np.mean(v)) - calib, 0.0)
-        fam, b, fl = layer_costs(eng_of[eid], tag)
-        f = fams.setdefault(fam, dict(us=0.0, launches=0, bytes=0.0, flops=0.0))
+        fam, b, fl, ov = layer_costs(eng_of[eid], tag)
+        f = fams.setdefault(fam, dict(us=0.0, launches=0, bytes=0.0, flops=0.0, overhead=0.0))
         f["us"] += us
         f["launches"] += 1
         f["bytes"] += b
         f["flops"] += fl
+        f["overhead"] += ov
         if b > 0 and (longest is None or us > longest["us"]):
             longest = dict(tag=tag, us=us, bytes=b, flops=fl, family=fam)
     return fams, longest, calib
@@ -412,7 +424,7 @@ def probe_solo_forward(wl, family, calib, reps=4):
     us = fl = by = 0.0
     n = 0
     for (eid, _, tag), v in acc.items():
-        fam, b, f = layer_costs(eng_of[eid], tag)
+        fam, b, f, _ = layer_costs(eng_of[eid], tag)
         if fam == family:
             us += max(float(np.mean(v)) - calib, 0.0)
             fl += f
@@ -451,7 +463,12 @@ def roofline_objects(wl, fams, longest, calib, math):
                 break
         except Exception:
             pass
+    roof["overhead_bytes_per_launch"] = int(top["overhead"] / top["launches"])
+    roof["bytes_model"] = ("algorithmic_bytes_per_launch = SURVEY.md section 8(d) only (logical input + raw output + weights; backward: dA, z [, input] + dX); "
+                           "overhead_bytes_per_launch = what this build moves beside it (side tensors, max-pool backward in a dgrad epilogue, "
+                           "weight-gradient slabs)")
     roof["families"] = {k: {"us_per_step": round(f["us"], 1), "launches": f["launches"], "share": round(f["us"] / total, 4),
+                            **({"overhead_MB_per_step": round(f["overhead"] / 1e6, 1)} if f.get("overhead") else {}),
                             **({"GBps": round(f["bytes"] / (f["us"] * 1e-6) / 1e9, 1), "TFLOPs_bf16_passes": round(f["flops"] * passes / (f["us"] * 1e-6) / 1e12, 1)}
                                if f["bytes"] > 0 and f["us"] > 0 else {})}
                         for k, f in sorted(fams.items(), key=lambda kv: -kv[1]["us"])}

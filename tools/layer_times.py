@@ -43,6 +43,6 @@ for (ei, i, tag), v in acc.items():
     if tag == "calib":
         continue
     us = float(np.mean(v)) - calib
-    fam, b, fl = bench.layer_costs(engines[ei], tag)
+    fam, b, fl, _ = bench.layer_costs(engines[ei], tag)
     extra = f"  {b / us / 1e3:7.1f} GB/s  {3 * fl / us / 1e6:7.1f} TF(x3)" if b > 0 and us > 0 else ""
     print(f"eng{ei} {tag:52s} {us:7.1f} us{extra}")
