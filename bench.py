@@ -289,10 +289,6 @@ def layer_costs(eng, tag):
     wgrad = dA + z + stored input; fused backward = dA + z + stored input + dX.  Layers with side tensors (HpfgConvArgs.stage_out): the
     forward conv also writes its staged input, the dgrad its dZ, and the weight gradient reads those two tensors instead.  FLOPs: 2 x taps x Cin x Cout per output pixel and pass."""
     kind, name = tag.split(":", 1) if ":" in tag else (tag, "")
-    mult = 1
-    for base in ("fwd", "pack_weights", "bn_fin_all"):      # "fwdx2:<conv>": ONE launch for the layer in 2 networks (hpfg_conv_fwd_multi)
-        if kind.startswith(base + "x") and kind[len(base) + 1:].isdigit():
-            kind, mult = base, int(kind[len(base) + 1:])
     s = eng.specs.get(name)
     if s is None or kind not in ("fwd", "dgrad", "wgrad", "fused_bwd"):
         return {"bn_fin": "BatchNorm forward finalize", "bn_red": "BatchNorm backward reduction (+ max-pool backward)", "bn_bfin": "BatchNorm backward finalize",
@@ -327,7 +323,7 @@ def layer_costs(eng, tag):
         S = eng.fused_grid.get(name) or eng.lib.hpfg_wgrad_splits(N, s.h, s.w, s.cin_pad, s.cout_pad, s.taps)
         slab = S * s.taps * s.cin_pad * s.cout_pad * 4
     if kind == "fwd":
-        return f"forward conv, {cls}", mult * (x_b + o_b + w_b), mult * fl, act_st
+        return f"forward conv, {cls}", x_b + o_b + w_b, fl, act_st
     if kind == "dgrad":
         from hpfg_amd.engine import enc_prefix
         pool_of = next((enc_prefix(lv - 1) + ".4" for lv in range(1, 5) if name == enc_prefix(lv) + ".0"), None)

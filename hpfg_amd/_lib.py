@@ -18,8 +18,7 @@ ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ = 
 OPT_CONV_THIN, OPT_FIRST_MFMA = 0, 1          # hpfg_set_option
 LOSS_NSUM = 32
 ACC_MAX_SHARDS = 8          # HPFG_ACC_MAX_SHARDS: a BatchNorm sum accumulator is long long [shards][2][C][2]
-VERSION = 140
-MAX_NETS = 3          # HPFG_MAX_NETS: networks per multi-network launch (hpfg_conv_fwd_multi)
+VERSION = 130
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -92,10 +91,6 @@ class PackDesc(C.Structure):
                 ("CoutPad", C.c_int32), ("CinPad", C.c_int32), ("taps", C.c_int32), ("kc", C.c_int32)]
 
 
-class PackBump(C.Structure):
-    _fields_ = [("counters", C.c_void_p), ("seed_word", C.c_void_p), ("n_counters", C.c_int32), ("seed_add", C.c_int32)]
-
-
 class LossArgs(C.Structure):
     _fields_ = [("logits", C.c_void_p), ("t_logits", C.c_void_p), ("labels0", C.c_void_p), ("labels1", C.c_void_p),
                 ("coef", C.c_void_p), ("partials", C.c_void_p), ("sums", C.c_void_p), ("out", C.c_void_p),
@@ -117,9 +112,6 @@ PROTOTYPES = {
     "hpfg_set_option": (_i, [_i, _i]),
     "hpfg_conv3x3_first_fwd": (_i, [C.POINTER(Act), _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "hpfg_conv_fwd": (_i, [C.POINTER(ConvArgs), _p]),
-    "hpfg_conv_fwd_multi": (_i, [C.POINTER(ConvArgs), _i, _p]),
-    "hpfg_conv3x3_first_fwd_acc_multi": (_i, [C.POINTER(Act), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), _i, _i, _i, _i, _i, _i, _i, _p]),
-    "hpfg_pack_weights_multi": (_i, [_p, C.POINTER(PackDesc), _i, C.POINTER(PackBump), _i, _p]),
     "hpfg_conv_stat_blocks": (_i, [_i, _i, _i]),
     "hpfg_conv_stat_rows": (_i, [C.POINTER(ConvArgs)]),
     "hpfg_bn_fwd_finalize": (_i, [_p, _i, _p, _d, _p, _p, _p, _p, _f, _f, _p, _i, _p]),
@@ -253,8 +245,6 @@ def load() -> C.CDLL:
             fn.argtypes = args
         if lib.hpfg_version() != VERSION:
             raise HipLibraryError(f"libhpfg_hip.so version {lib.hpfg_version()} != binding version {VERSION}; rebuild")
-        if os.environ.get("HPFG_EXP_INDIRECT") == "1":      # EXPERIMENT (round 5): forward convs through the indirect-argument kernels
-            lib.hpfg_set_option(OPT_FIRST_MFMA, 7)
         _lib = lib
     return _lib
 

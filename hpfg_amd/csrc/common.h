@@ -7,14 +7,6 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// kernel argument of the multi-network launches (hpfg_conv_fwd_multi): one descriptor per network of the step, selected by a grid index
-struct HpfgConvMulti {
-  HpfgConvArgs net[HPFG_MAX_NETS];
-};
-struct HpfgPackBumps {
-  HpfgPackBump net[HPFG_MAX_NETS];
-};
-
 #define HPFG_LEAKY 0.01f
 
 extern "C" void hpfg_set_error(const char* fmt, ...);

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(HpfgFirstConvArgs q, in
 // cycles in the LDS pipe; this one issues 3 four-byte gathers per 16 pixels.  The next tile's input is in flight (registers) while a tile
 // multiplies.  Same partial-sum rows (one per workgroup) and the same output as conv_first_kernel.
 template <int CIN>
-__device__ __forceinline__ void conv_first_mfma_body(const HpfgFirstConvArgs& q, int N, int H, int W, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) void conv_first_mfma_kernel(HpfgFirstConvArgs q, int N, int H, int W, int tiles_x, int tiles_y) {
   constexpr int T = 16, TP = T + 2, CO = 16, NPIX = TP * TP, KT = 9 * CIN, KS = (KT + 3) / 4, NLD = (CIN * NPIX + 255) / 256;
   const HpfgAct& x = q.x;
   const float* __restrict__ w = q.w_oihw;
@@ -239,23 +239,9 @@ __device__ __forceinline__ void conv_first_mfma_body(const HpfgFirstConvArgs& q,
   }
 }
 
-template <int CIN>
-__global__ __launch_bounds__(256) void conv_first_mfma_kernel(HpfgFirstConvArgs q, int N, int H, int W, int tiles_x, int tiles_y) {
-  conv_first_mfma_body<CIN>(q, N, H, W, tiles_x, tiles_y);
-}
-struct HpfgFirstConvMulti {
-  HpfgFirstConvArgs net[HPFG_MAX_NETS];
-};
-// the first layer of several networks in one launch (hpfg_conv3x3_first_fwd_acc_multi): blockIdx.y names the network
-template <int CIN>
-__global__ __launch_bounds__(256) void conv_first_mfma_multi_kernel(HpfgFirstConvMulti q, int N, int H, int W, int tiles_x, int tiles_y) {
-  conv_first_mfma_body<CIN>(q.net[blockIdx.y], N, H, W, tiles_x, tiles_y);
-}
-
-inline int conv_first_grid(int N, int H, int W, int nnets = 1) {
+inline int conv_first_grid(int N, int H, int W) {
   const long nwork = (long)N * ((H + 15) / 16) * ((W + 15) / 16);
-  const long cap = 1024 / nnets;
-  return (int)(nwork < cap ? nwork : cap);
+  return (int)(nwork < 1024 ? nwork : 1024);
 }
 
 }  // namespace
@@ -270,14 +256,7 @@ extern "C" int hpfg_conv_first_rows(int N, int H, int W) { return conv_first_gri
 
 static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only);
 
-static int conv_fwd_multi_impl(const HpfgConvArgs* args, int nnets, void* stream);
-extern "C" int hpfg_conv_fwd(const HpfgConvArgs* a, void* stream) {
-  if (hpfg_opt(HPFG_OPT_COUNT - 1) == 7 && a && (a->math & ~0xff) == 0 && (a->math & 0xff) == HPFG_MATH_BF16X3 && !a->stat_partials && !a->bwd_stats && !a->out_split) {
-    const int kind = hpfg_kind_of(a->a0, a->a1);
-    if (kind == HPFG_KIND_BNACT || kind == HPFG_KIND_POOL || kind == HPFG_KIND_CAT) return conv_fwd_multi_impl(a, 1, stream);      // EXPERIMENT
-  }
-  return conv_fwd_impl(a, stream, nullptr);
-}
+extern "C" int hpfg_conv_fwd(const HpfgConvArgs* a, void* stream) { return conv_fwd_impl(a, stream, nullptr); }
 
 // rows of stat_partials ([rows][2][CoutPad]) that hpfg_conv_fwd(args) fills; <0 on argument errors
 extern "C" int hpfg_conv_stat_rows(const HpfgConvArgs* a) {
@@ -286,47 +265,48 @@ extern "C" int hpfg_conv_stat_rows(const HpfgConvArgs* a) {
   return rc ? -1 : rows;
 }
 
-static int conv_args_check(const HpfgConvArgs* a);
-
-// One launch for the same layer of several networks.  Every descriptor passes hpfg_conv_fwd's own checks; the fields that select the kernel
-// and size the grid must agree (the per-network ones -- pointers, dropout seeds, stage_out / bn_acc presence -- are read at run time).
-extern "C" int hpfg_conv_fwd_multi(const HpfgConvArgs* args, int nnets, void* stream) {
-  HPFG_ARG_CHECK(args && nnets >= 1 && nnets <= HPFG_MAX_NETS, "conv_fwd_multi: 1 .. %d networks (got %d)", HPFG_MAX_NETS, nnets);
-  if (nnets == 1) return hpfg_conv_fwd(args, stream);
-  return conv_fwd_multi_impl(args, nnets, stream);
-}
-static int conv_fwd_multi_impl(const HpfgConvArgs* args, int nnets, void* stream) {
-  const HpfgConvArgs& a = args[0];
-  const int kind = hpfg_kind_of(a.a0, a.a1);
-  HPFG_ARG_CHECK((a.math & 0xff) == HPFG_MATH_BF16X3 && (a.math & ~0xff) == 0, "conv_fwd_multi: bf16x3 kernels only");
-  HPFG_ARG_CHECK(kind == HPFG_KIND_BNACT || kind == HPFG_KIND_POOL || kind == HPFG_KIND_CAT, "conv_fwd_multi: forward loader kinds only (BNACT, POOL, CAT)");
-  for (int k = 0; k < nnets; ++k) {
-    const HpfgConvArgs& b = args[k];
-    const int rc = conv_args_check(&b);
-    if (rc) return rc;
-    HPFG_ARG_CHECK(!b.stat_partials && !b.bwd_stats && !b.out_split, "conv_fwd_multi: BatchNorm sums go through stat_acc; no dgrad features");
-    HPFG_ARG_CHECK(b.math == a.math && b.taps == a.taps && b.N == a.N && b.H == a.H && b.W == a.W && b.Cout == a.Cout && b.CoutPad == a.CoutPad &&
-                       b.out_pstride == a.out_pstride && hpfg_kind_of(b.a0, b.a1) == kind && b.a0.C == a.a0.C && b.a1.C == a.a1.C &&
-                       b.a0.pstride == a.a0.pstride && b.a1.pstride == a.a1.pstride && b.a0.Hs == a.a0.Hs && b.a0.Ws == a.a0.Ws &&
-                       b.a1.Hs == a.a1.Hs && b.a1.Ws == a.a1.Ws && (b.bias == nullptr) == (a.bias == nullptr),
-                   "conv_fwd_multi: network %d describes another layer shape than network 0", k);
-  }
-  hipStream_t st = (hipStream_t)stream;
-  const int r = hpfg_conv_thin_multi_try(a, nnets, st);
-  if (r != HPFG_THIN_NONE) return r;
-  switch (kind) {
-    case HPFG_KIND_BNACT: return hpfg_conv16_multi_bnact(a, nnets, st);
-    case HPFG_KIND_POOL: return hpfg_conv16_multi_pool(a, nnets, st);
-    default: return hpfg_conv16_multi_cat(a, nnets, st);
-  }
-}
-
 static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
-  {
-    const int rc = conv_args_check(a);
-    if (rc) return rc;
+  HPFG_ARG_CHECK(a && a->wpk && a->out, "conv_fwd: null pointer");
+  HPFG_ARG_CHECK(a->taps == 9 || a->taps == 1, "conv_fwd: taps must be 1 or 9 (got %d)", a->taps);
+  HPFG_ARG_CHECK(a->CoutPad % 16 == 0 && a->Cout <= a->CoutPad && a->Cout > 0, "conv_fwd: bad Cout %d / pad %d", a->Cout, a->CoutPad);
+  HPFG_ARG_CHECK(a->N > 0 && a->H > 0 && a->W > 0 && a->N < 65536, "conv_fwd: bad N/H/W");
+  HPFG_ARG_CHECK(a->a0.mode != HPFG_ACT_NONE && a->a0.C > 0, "conv_fwd: a0 empty");
+  HPFG_ARG_CHECK(a->a1.mode == HPFG_ACT_NONE || a->a0.C % 16 == 0, "conv_fwd: concat needs a0.C %% 16 == 0");
+  HPFG_ARG_CHECK(a->out_split ? (a->out_pstride >= a->out_split) : (a->out_pstride >= a->Cout), "conv_fwd: out_pstride too small");
+  HPFG_ARG_CHECK(a->out_split == 0 || (a->out2 && a->out_split % 16 == 0 && a->out_split < a->Cout && a->out2_pstride >= a->Cout - a->out_split &&
+                                       !a->bwd_stats),
+                 "conv_fwd: out_split needs out2, a multiple of 16 below Cout, and no bwd_stats");
+  HPFG_ARG_CHECK(!a->stat_acc || ((a->math & 0xff) == HPFG_MATH_BF16X3 && a->Cout == a->CoutPad && a->stat_shards >= 1 &&
+                                  a->stat_shards <= HPFG_ACC_MAX_SHARDS && (a->stat_shards & (a->stat_shards - 1)) == 0),
+                 "conv_fwd: stat_acc is a bf16x3 forward feature (Cout == CoutPad, stat_shards a power of two <= %d)", HPFG_ACC_MAX_SHARDS);
+  for (const HpfgAct* s : {&a->a0, &a->a1}) {
+    if (!s->bn_acc) continue;
+    HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && (s->mode == HPFG_ACT_BNACT || s->mode == HPFG_ACT_BNACT_POOL || s->mode == HPFG_ACT_DZ) &&
+                       s->bn_gamma && (s->bn_beta || s->mode == HPFG_ACT_DZ) && s->bn_count >= 1.f && s->C <= 256 && s->bn_shards >= 1 &&
+                       s->bn_shards <= HPFG_ACC_MAX_SHARDS,
+                   "conv_fwd: bn_acc needs a BNACT / BNACT_POOL / DZ source of the bf16x3 kernels with gamma (beta), count and at most 256 channels");
   }
+  HPFG_ARG_CHECK((a->math & 0xff) != HPFG_MATH_BF16X3 || !(a->a0.mode == HPFG_ACT_BNACT || a->a0.mode == HPFG_ACT_BNACT_POOL || a->a0.mode == HPFG_ACT_DZ) ||
+                     a->a0.C <= 256,
+                 "conv_fwd(bf16x3): a BatchNorm'd source has at most 256 channels (got %d)", a->a0.C);
+  HPFG_ARG_CHECK(!a->stage_out || ((a->math & 0xff) == HPFG_MATH_BF16X3 && a->taps == 9 && hpfg_kind_of(a->a0, a->a1) > HPFG_KIND_PLAIN &&
+                                    (a->a0.C + a->a1.C) % 8 == 0 && (a->H % 16 || a->W % 16)),
+                 "conv_fwd: stage_out is a feature of the 3x3 bf16x3 kernels (non-PLAIN source, channels a multiple of 8, H or W not a multiple of 16)");
   hipStream_t st = (hipStream_t)stream;
+  if (a->bwd_stats) {
+    const int kind = hpfg_kind_of(a->a0, a->a1);
+    HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && (kind == HPFG_KIND_DZ || kind == HPFG_KIND_PLAIN),
+                   "conv_fwd: bwd_stats is a dgrad feature of the bf16x3 kernels (DZ or PLAIN source)");
+    HPFG_ARG_CHECK((a->stat_partials || a->stat_acc) && a->bwd_of.z && a->bwd_of.bn && !a->bias,
+                   "conv_fwd: bwd_stats needs stat_partials or stat_acc, bwd_of.z / .bn and no bias");
+    const int up = a->bwd_stats == 2 ? 2 : 1;      // 2: `out` is the gradient w.r.t. MaxPool2d(2) of bwd_of's activation (bwd_of at twice the size)
+    HPFG_ARG_CHECK(a->bwd_stats == 1 || a->bwd_stats == 2, "conv_fwd: bwd_stats must be 0, 1 or 2");
+    HPFG_ARG_CHECK(a->bwd_of.C == a->Cout && a->Cout == a->CoutPad && a->bwd_of.Hs == up * a->H && a->bwd_of.Ws == up * a->W && a->bwd_of.pstride % 4 == 0,
+                   "conv_fwd: bwd_of must describe a layer with C == Cout == CoutPad (%d/%d/%d) at the output size (twice it for bwd_stats == 2)",
+                   a->bwd_of.C, a->Cout, a->CoutPad);
+    HPFG_ARG_CHECK(a->bwd_stats == 1 || (a->taps == 9 && (a->H % 16 || a->W % 16) && a->bwd_of.aux && a->bwd_of.aux_pstride % 4 == 0 && a->bwd_of.drop_p == 0.f && !a->out_split),
+                   "conv_fwd: bwd_stats == 2 (max-pool backward in the epilogue) needs a 3x3 dgrad at a size that is not a multiple of 16, bwd_of.aux (the gradient so far) and no dropout behind bwd_of");
+  }
   if ((a->math & 0xff) == HPFG_MATH_BF16X3) {
     {      // the thin 16-pixel-aligned layers have a kernel of their own
       const int r = hpfg_conv_thin_try(*a, st, rows_only);
@@ -360,51 +340,6 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
   return -1;
 }
 
-// the argument checks of hpfg_conv_fwd (shared with hpfg_conv_fwd_multi, which applies them to every network's descriptor)
-static int conv_args_check(const HpfgConvArgs* a) {
-  HPFG_ARG_CHECK(a && a->wpk && a->out, "conv_fwd: null pointer");
-  HPFG_ARG_CHECK(a->taps == 9 || a->taps == 1, "conv_fwd: taps must be 1 or 9 (got %d)", a->taps);
-  HPFG_ARG_CHECK(a->CoutPad % 16 == 0 && a->Cout <= a->CoutPad && a->Cout > 0, "conv_fwd: bad Cout %d / pad %d", a->Cout, a->CoutPad);
-  HPFG_ARG_CHECK(a->N > 0 && a->H > 0 && a->W > 0 && a->N < 65536, "conv_fwd: bad N/H/W");
-  HPFG_ARG_CHECK(a->a0.mode != HPFG_ACT_NONE && a->a0.C > 0, "conv_fwd: a0 empty");
-  HPFG_ARG_CHECK(a->a1.mode == HPFG_ACT_NONE || a->a0.C % 16 == 0, "conv_fwd: concat needs a0.C %% 16 == 0");
-  HPFG_ARG_CHECK(a->out_split ? (a->out_pstride >= a->out_split) : (a->out_pstride >= a->Cout), "conv_fwd: out_pstride too small");
-  HPFG_ARG_CHECK(a->out_split == 0 || (a->out2 && a->out_split % 16 == 0 && a->out_split < a->Cout && a->out2_pstride >= a->Cout - a->out_split &&
-                                       !a->bwd_stats),
-                 "conv_fwd: out_split needs out2, a multiple of 16 below Cout, and no bwd_stats");
-  HPFG_ARG_CHECK(!a->stat_acc || ((a->math & 0xff) == HPFG_MATH_BF16X3 && a->Cout == a->CoutPad && a->stat_shards >= 1 &&
-                                  a->stat_shards <= HPFG_ACC_MAX_SHARDS && (a->stat_shards & (a->stat_shards - 1)) == 0),
-                 "conv_fwd: stat_acc is a bf16x3 forward feature (Cout == CoutPad, stat_shards a power of two <= %d)", HPFG_ACC_MAX_SHARDS);
-  for (const HpfgAct* s : {&a->a0, &a->a1}) {
-    if (!s->bn_acc) continue;
-    HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && (s->mode == HPFG_ACT_BNACT || s->mode == HPFG_ACT_BNACT_POOL || s->mode == HPFG_ACT_DZ) &&
-                       s->bn_gamma && (s->bn_beta || s->mode == HPFG_ACT_DZ) && s->bn_count >= 1.f && s->C <= 256 && s->bn_shards >= 1 &&
-                       s->bn_shards <= HPFG_ACC_MAX_SHARDS,
-                   "conv_fwd: bn_acc needs a BNACT / BNACT_POOL / DZ source of the bf16x3 kernels with gamma (beta), count and at most 256 channels");
-  }
-  HPFG_ARG_CHECK((a->math & 0xff) != HPFG_MATH_BF16X3 || !(a->a0.mode == HPFG_ACT_BNACT || a->a0.mode == HPFG_ACT_BNACT_POOL || a->a0.mode == HPFG_ACT_DZ) ||
-                     a->a0.C <= 256,
-                 "conv_fwd(bf16x3): a BatchNorm'd source has at most 256 channels (got %d)", a->a0.C);
-  HPFG_ARG_CHECK(!a->stage_out || ((a->math & 0xff) == HPFG_MATH_BF16X3 && a->taps == 9 && hpfg_kind_of(a->a0, a->a1) > HPFG_KIND_PLAIN &&
-                                    (a->a0.C + a->a1.C) % 8 == 0 && (a->H % 16 || a->W % 16)),
-                 "conv_fwd: stage_out is a feature of the 3x3 bf16x3 kernels (non-PLAIN source, channels a multiple of 8, H or W not a multiple of 16)");
-  if (a->bwd_stats) {
-    const int kind = hpfg_kind_of(a->a0, a->a1);
-    HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && (kind == HPFG_KIND_DZ || kind == HPFG_KIND_PLAIN),
-                   "conv_fwd: bwd_stats is a dgrad feature of the bf16x3 kernels (DZ or PLAIN source)");
-    HPFG_ARG_CHECK((a->stat_partials || a->stat_acc) && a->bwd_of.z && a->bwd_of.bn && !a->bias,
-                   "conv_fwd: bwd_stats needs stat_partials or stat_acc, bwd_of.z / .bn and no bias");
-    const int up = a->bwd_stats == 2 ? 2 : 1;      // 2: `out` is the gradient w.r.t. MaxPool2d(2) of bwd_of's activation (bwd_of at twice the size)
-    HPFG_ARG_CHECK(a->bwd_stats == 1 || a->bwd_stats == 2, "conv_fwd: bwd_stats must be 0, 1 or 2");
-    HPFG_ARG_CHECK(a->bwd_of.C == a->Cout && a->Cout == a->CoutPad && a->bwd_of.Hs == up * a->H && a->bwd_of.Ws == up * a->W && a->bwd_of.pstride % 4 == 0,
-                   "conv_fwd: bwd_of must describe a layer with C == Cout == CoutPad (%d/%d/%d) at the output size (twice it for bwd_stats == 2)",
-                   a->bwd_of.C, a->Cout, a->CoutPad);
-    HPFG_ARG_CHECK(a->bwd_stats == 1 || (a->taps == 9 && (a->H % 16 || a->W % 16) && a->bwd_of.aux && a->bwd_of.aux_pstride % 4 == 0 && a->bwd_of.drop_p == 0.f && !a->out_split),
-                   "conv_fwd: bwd_stats == 2 (max-pool backward in the epilogue) needs a 3x3 dgrad at a size that is not a multiple of 16, bwd_of.aux (the gradient so far) and no dropout behind bwd_of");
-  }
-  return 0;
-}
-
 static int conv_first_impl(const HpfgFirstConvArgs* q, int N, int H, int W, int Cin, int Cout, void* stream) {
   HPFG_ARG_CHECK(Cin >= 1 && Cin <= 4 && Cout == 16, "conv_first: needs Cin<=4, Cout==16 (got %d,%d)", Cin, Cout);
   HPFG_ARG_CHECK(q->x.z && q->w_oihw && q->bias && q->out, "conv_first: null pointer");
@@ -420,24 +355,6 @@ static int conv_first_impl(const HpfgFirstConvArgs* q, int N, int H, int W, int 
   }
   hipLaunchKernelGGL(conv_first_kernel, g1, dim3(256), 0, (hipStream_t)stream, *q, N, H, W, Cin, tx, ty);
   return hpfg_launch_status("conv_first_kernel");
-}
-
-extern "C" int hpfg_conv3x3_first_fwd_acc_multi(const HpfgAct* x, const float* const* w_oihw, const float* const* bias, float* const* out,
-                                                long long* const* stat_acc, int nnets, int stat_shards, int N, int H, int W, int Cin, int Cout, void* stream) {
-  HPFG_ARG_CHECK(x && w_oihw && bias && out && stat_acc && nnets >= 1 && nnets <= HPFG_MAX_NETS, "conv_first_multi: null pointer / 1 .. %d networks", HPFG_MAX_NETS);
-  HPFG_ARG_CHECK(stat_shards >= 1 && stat_shards <= HPFG_ACC_MAX_SHARDS && (stat_shards & (stat_shards - 1)) == 0, "conv_first_multi: bad shard count %d", stat_shards);
-  HPFG_ARG_CHECK((Cin == 1 || Cin == 3) && Cout == 16 && tile_is_big(H, W), "conv_first_multi: the 1- / 3-channel MFMA form on sizes that are multiples of 16");
-  HpfgFirstConvMulti q;
-  for (int k = 0; k < HPFG_MAX_NETS; ++k) {
-    const int j = k < nnets ? k : 0;
-    HPFG_ARG_CHECK(x[j].z && x[j].mode == HPFG_ACT_STRIDED && w_oihw[j] && bias[j] && out[j] && stat_acc[j], "conv_first_multi: null pointer (network %d)", j);
-    q.net[k] = HpfgFirstConvArgs{x[j], w_oihw[j], bias[j], out[j], nullptr, stat_acc[j], stat_shards};
-  }
-  const int tx = (W + 15) / 16, ty = (H + 15) / 16;
-  const dim3 g(conv_first_grid(N, H, W, nnets), nnets);
-  if (Cin == 1) hipLaunchKernelGGL((conv_first_mfma_multi_kernel<1>), g, dim3(256), 0, (hipStream_t)stream, q, N, H, W, tx, ty);
-  else hipLaunchKernelGGL((conv_first_mfma_multi_kernel<3>), g, dim3(256), 0, (hipStream_t)stream, q, N, H, W, tx, ty);
-  return hpfg_launch_status("conv_first_mfma_multi_kernel");
 }
 
 extern "C" int hpfg_conv3x3_first_fwd(const HpfgAct* x, const float* w_oihw, const float* bias, float* out, float* stat_partials,

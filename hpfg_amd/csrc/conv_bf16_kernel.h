@@ -330,7 +330,7 @@ constexpr int wg_per_cu() {
 // BWD: the dgrad variant whose epilogue also produces the BatchNorm-backward sums of the layer below (p.bwd_stats); a separate
 // instantiation so that the plain kernels keep their register budget.
 template <class C, int KIND, int BWD = 0>
-__device__ __forceinline__ void conv_bf16x3_body(const HpfgConvArgs& p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   static_assert(C::TAPS == 9, "persistent kernel is the 3x3 path");
   constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
   constexpr int NR = eff_nr<KIND>();
@@ -663,20 +663,9 @@ __device__ __forceinline__ void conv_bf16x3_body(const HpfgConvArgs& p, int tile
   HPFG_TR_REAL(12)
 }
 
-template <class C, int KIND, int BWD = 0>
-__global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
-  conv_bf16x3_body<C, KIND, BWD>(p, tiles_x, tiles_y);
-}
-// the same layer of several networks in one launch (hpfg_conv_fwd_multi): blockIdx.z names the network, whose descriptor is read from the
-// kernel-argument segment with a scalar offset -- the body is the single-network kernel's
-template <class C, int KIND>
-__global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_multi_kernel(HpfgConvMulti q, int tiles_x, int tiles_y) {
-  conv_bf16x3_body<C, KIND, 0>(q.net[blockIdx.z], tiles_x, tiles_y);
-}
-
 // 1x1: one tile per workgroup, K = 32 input channels per MFMA step, no halo.
 template <class C, int KIND, int BWD = 0>
-__device__ __forceinline__ void conv1x1_bf16x3_body(const HpfgConvArgs& p, int tiles_x, int tiles_y, int n) {
+__global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   static_assert(C::TAPS == 1, "1x1 path");
   constexpr int STAT_BYTES = 2 * 4 * C::BN * 4;
   constexpr int NR = RawCount<KIND>::N;
@@ -687,7 +676,7 @@ __device__ __forceinline__ void conv1x1_bf16x3_body(const HpfgConvArgs& p, int t
   (void)ldsBN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % C::WM, wn = wave / C::WM;
-  const int tile = blockIdx.x, cb = blockIdx.z;
+  const int tile = blockIdx.x, n = blockIdx.y, cb = blockIdx.z;
   const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
   const int H = p.H, W = p.W;
   const ActCtx cx0 = make_ctx(p.a0);
@@ -756,19 +745,9 @@ __device__ __forceinline__ void conv1x1_bf16x3_body(const HpfgConvArgs& p, int t
   conv16_flush_stats<C, BWD>(p, s1, s2, ldsf, tid, lane, wm, wn, cb, n * (tiles_x * tiles_y) + tile);
 }
 
-template <class C, int KIND, int BWD = 0>
-__global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
-  conv1x1_bf16x3_body<C, KIND, BWD>(p, tiles_x, tiles_y, (int)blockIdx.y);
-}
-template <class C, int KIND>      // several networks: blockIdx.y = network * N + image
-__global__ __launch_bounds__(256) void conv1x1_bf16x3_multi_kernel(HpfgConvMulti q, int tiles_x, int tiles_y) {
-  const int net = (int)blockIdx.y / q.net[0].N;
-  conv1x1_bf16x3_body<C, KIND, 0>(q.net[net], tiles_x, tiles_y, (int)blockIdx.y - net * q.net[0].N);
-}
-
 // number of stat_partials rows the kernel for this configuration writes (persistent 3x3: one per workgroup)
 template <class C, int KIND>
-int persistent_grid(const HpfgConvArgs& a, int nnets = 1) {
+int persistent_grid(const HpfgConvArgs& a) {
   const int tx = (a.W + C::TW - 1) / C::TW, ty = (a.H + C::TH - 1) / C::TH;
   const int lds_bytes = 2 * C::BUF_BYTES + 2 * 4 * C::BN * 4;
   int per_cu = 160 * 1024 / lds_bytes;
@@ -780,29 +759,15 @@ int persistent_grid(const HpfgConvArgs& a, int nnets = 1) {
   // ceil(tiles / capacity) rounds need, not over the whole capacity.
   const long nwork = (long)tx * ty * a.N;
   const long gy = a.CoutPad / C::BN;
-  long cap = 256L * per_cu / ((gy > 0 ? gy : 1) * nnets);      // (several networks per launch share the chip: all of their workgroups resident)
+  long cap = 256L * per_cu / (gy > 0 ? gy : 1);
   if (cap < 1) cap = 1;
   const long rounds = (nwork + cap - 1) / cap;
   return (int)((nwork + rounds - 1) / rounds);
 }
 
-// MULTI: `a` is the first of `nnets` contiguous descriptors of the same layer in several networks (hpfg_conv_fwd_multi validated that they
-// select the same kernel); the multi-network kernels are instantiated only from the conv_m_*.hip units
-template <class C, int KIND, bool MULTI = false>
-int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only, int nnets = 1) {
+template <class C, int KIND>
+int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   int tx = (a.W + C::TW - 1) / C::TW, ty = (a.H + C::TH - 1) / C::TH;
-  if constexpr (MULTI) {
-    HpfgConvMulti q;
-    for (int k = 0; k < HPFG_MAX_NETS; ++k) q.net[k] = (&a)[k < nnets ? k : 0];
-    if constexpr (C::TAPS == 9) {
-      dim3 grid((unsigned)persistent_grid<C, KIND>(a, nnets), a.CoutPad / C::BN, nnets);
-      hipLaunchKernelGGL((conv_bf16x3_multi_kernel<C, KIND>), grid, dim3(256), 0, st, q, tx, ty);
-    } else {
-      dim3 grid(tx * ty, a.N * nnets, a.CoutPad / C::BN);
-      hipLaunchKernelGGL((conv1x1_bf16x3_multi_kernel<C, KIND>), grid, dim3(256), 0, st, q, tx, ty);
-    }
-    return hpfg_launch_status("conv_bf16x3_multi_kernel");
-  }
   if (rows_only) {
     if constexpr (C::TAPS == 9) *rows_only = persistent_grid<C, KIND>(a);
     else *rows_only = tx * ty * a.N;
@@ -840,17 +805,17 @@ int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only, int nnets 
   return hpfg_launch_status("conv_bf16x3_kernel");
 }
 
-template <int KIND, int TAPS, bool MULTI = false>
-int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st, int* rows_only, int nnets = 1) {
+template <int KIND, int TAPS>
+int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   const bool big = (a.H % 16 == 0) && (a.W % 16 == 0);
   const int cp = a.CoutPad;
   constexpr int KCB = TAPS == 9 ? 16 : 32;
   if (big) {
     if constexpr (TAPS == 1) {
-      if (cp % 64 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 4, TAPS, KCB>, KIND, MULTI>(a, st, rows_only, nnets);
+      if (cp % 64 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 4, TAPS, KCB>, KIND>(a, st, rows_only);
     }
-    if (cp % 32 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 2, TAPS, KCB>, KIND, MULTI>(a, st, rows_only, nnets);   // 3x3: 32-channel slices (B ring = 80 VGPRs)
-    return launch_cfg<Cfg<16, 16, 4, 1, 1, TAPS, KCB>, KIND, MULTI>(a, st, rows_only, nnets);
+    if (cp % 32 == 0) return launch_cfg<Cfg<16, 16, 4, 1, 2, TAPS, KCB>, KIND>(a, st, rows_only);   // 3x3: 32-channel slices (B ring = 80 VGPRs)
+    return launch_cfg<Cfg<16, 16, 4, 1, 1, TAPS, KCB>, KIND>(a, st, rows_only);
   }
   if constexpr (TAPS == 9) {
     // 3x3 on sizes that are not multiples of 16 (56, 28, 14, ...): 4x16-pixel tiles.  Same 64 pixels per workgroup as an 8x8 tile
@@ -863,16 +828,16 @@ int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st, int* rows_only, in
     // (round 4: the same 64 x 64 tile as 2 x 2 waves of 2 pixel tiles x 2 channel tiles -- half the LDS reads of A fragments, which the SQ
     // counters make the longest of the kernel's three pipes, but a B ring of 3 instead of 9 k-steps -- measured +7 % on the step,
     // profiles/r04_schedule_experiments.txt)
-    if (cp % 64 == 0) return launch_cfg<Cfg<4, 16, 1, 4, 1, TAPS, 32>, KIND, MULTI>(a, st, rows_only, nnets);
-    if (cp % 32 == 0) return launch_cfg<Cfg<4, 16, 2, 2, 1, TAPS, 32>, KIND, MULTI>(a, st, rows_only, nnets);
-    return launch_cfg<Cfg<4, 16, 4, 1, 1, TAPS, 32>, KIND, MULTI>(a, st, rows_only, nnets);
+    if (cp % 64 == 0) return launch_cfg<Cfg<4, 16, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only);
+    if (cp % 32 == 0) return launch_cfg<Cfg<4, 16, 2, 2, 1, TAPS, 32>, KIND>(a, st, rows_only);
+    return launch_cfg<Cfg<4, 16, 4, 1, 1, TAPS, 32>, KIND>(a, st, rows_only);
   }
   // 1x1 on small spatial sizes (8x8 tiles): narrow the output-channel slice per workgroup until there are >= 2 workgroups per CU
   const long nwork = (long)a.N * ((a.H + 7) / 8) * ((a.W + 7) / 8);
-  if (cp % 128 == 0 && nwork * (cp / 128) >= 512) return launch_cfg<Cfg<8, 8, 1, 4, 2, TAPS, 32>, KIND, MULTI>(a, st, rows_only, nnets);
-  if (cp % 64 == 0 && (nwork * (cp / 64) >= 512 || cp % 32 != 0)) return launch_cfg<Cfg<8, 8, 1, 4, 1, TAPS, 32>, KIND, MULTI>(a, st, rows_only, nnets);
-  if (cp % 32 == 0) return launch_cfg<Cfg<8, 8, 2, 2, 1, TAPS, 32>, KIND, MULTI>(a, st, rows_only, nnets);
-  return launch_cfg<Cfg<8, 8, 4, 1, 1, TAPS, 32>, KIND, MULTI>(a, st, rows_only, nnets);
+  if (cp % 128 == 0 && nwork * (cp / 128) >= 512) return launch_cfg<Cfg<8, 8, 1, 4, 2, TAPS, 32>, KIND>(a, st, rows_only);
+  if (cp % 64 == 0 && (nwork * (cp / 64) >= 512 || cp % 32 != 0)) return launch_cfg<Cfg<8, 8, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only);
+  if (cp % 32 == 0) return launch_cfg<Cfg<8, 8, 2, 2, 1, TAPS, 32>, KIND>(a, st, rows_only);
+  return launch_cfg<Cfg<8, 8, 4, 1, 1, TAPS, 32>, KIND>(a, st, rows_only);
 }
 
 }  // namespace hpfg_conv16
@@ -884,8 +849,3 @@ int hpfg_conv16_launch_bnact(const HpfgConvArgs& a, hipStream_t st, int* rows_on
 int hpfg_conv16_launch_pool(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
 int hpfg_conv16_launch_cat(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
 int hpfg_conv16_launch_dz(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
-// several networks per launch (a = the first of nnets contiguous descriptors): conv_m_*.hip
-int hpfg_conv16_multi_bnact(const HpfgConvArgs& a, int nnets, hipStream_t st);
-int hpfg_conv16_multi_pool(const HpfgConvArgs& a, int nnets, hipStream_t st);
-int hpfg_conv16_multi_cat(const HpfgConvArgs& a, int nnets, hipStream_t st);
-int hpfg_conv_thin_multi_try(const HpfgConvArgs& a, int nnets, hipStream_t st);      // conv_thin_m.hip

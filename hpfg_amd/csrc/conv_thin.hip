@@ -16,15 +16,6 @@ int launch(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   return hpfg_launch_status("conv_thin_kernel");
 }
 
-template <int CI, int CO, int AK, int NW, int WGS>
-int launch_multi(const HpfgConvArgs& a, int nnets, hipStream_t st) {
-  const int grid = thin_grid<CI, CO, AK, NW, WGS>(a, nnets);
-  HpfgConvMulti q;
-  for (int k = 0; k < HPFG_MAX_NETS; ++k) q.net[k] = (&a)[k < nnets ? k : 0];
-  hipLaunchKernelGGL((conv_thin_multi_kernel<CI, CO, AK, NW, WGS>), dim3(grid, nnets), dim3(64 * NW), 0, st, q, a.W / T, a.H / T);
-  return hpfg_launch_status("conv_thin_multi_kernel");
-}
-
 bool enabled() { return hpfg_opt(HPFG_OPT_CONV_THIN) != 0; }      // (tests switch it inside one process: hpfg_set_option)
 
 }  // namespace
@@ -46,26 +37,6 @@ int hpfg_conv_thin_try(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   // (32 -> 32 @112^2 is not here: with its weight fragments in LDS only one 8-wave workgroup fits a CU: 29.9 us against 28.3 us)
   HPFG_THIN_CASE(1, 2, HPFG_KIND_POOL, 8, 1)       // down1.c1
   HPFG_THIN_CASE(2, 1, HPFG_KIND_CAT, 4, 2)        // up4.c1
-#undef HPFG_THIN_CASE
-  return HPFG_THIN_NONE;
-}
-
-// the forward shapes of the list above for several networks in one launch (a = the first of nnets contiguous descriptors that
-// hpfg_conv_fwd_multi found to agree in everything the selection below reads)
-int hpfg_conv_thin_multi_try(const HpfgConvArgs& a, int nnets, hipStream_t st) {
-  if (!enabled() || a.taps != 9 || a.H % T || a.W % T || a.bwd_stats || a.out_split || (a.math & ~0xff)) return HPFG_THIN_NONE;
-  for (int k = 0; k < nnets; ++k)
-    if ((&a)[k].stage_out) return HPFG_THIN_NONE;
-  if (a.Cout % 4 || a.out_pstride % 4 || a.CoutPad > 32) return HPFG_THIN_NONE;
-  const int cin = a.a0.C + a.a1.C, ci = cin / 16, co = a.CoutPad / 16;
-  if (cin % 16 || a.a0.pstride % 4) return HPFG_THIN_NONE;
-  const int ak = hpfg_kind_of(a.a0, a.a1);
-  if (ak == HPFG_KIND_CAT && (a.a0.C != a.a1.C || a.a0.C % 16 || a.a1.pstride % 4)) return HPFG_THIN_NONE;
-#define HPFG_THIN_CASE(CI, CO, AK, NW, WGS) \
-  if (ci == CI && co == CO && ak == AK) return launch_multi<CI, CO, AK, NW, WGS>(a, nnets, st);
-  HPFG_THIN_CASE(1, 1, HPFG_KIND_BNACT, 4, 3)
-  HPFG_THIN_CASE(1, 2, HPFG_KIND_POOL, 8, 1)
-  HPFG_THIN_CASE(2, 1, HPFG_KIND_CAT, 4, 2)
 #undef HPFG_THIN_CASE
   return HPFG_THIN_NONE;
 }

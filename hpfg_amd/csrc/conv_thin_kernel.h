@@ -51,8 +51,8 @@ struct Geo {
   static_assert(USH * USW * 2 <= NTH, "one source piece per thread");
 };
 
-template <int CI, int CO, int AK, int NW>
-__device__ __forceinline__ void conv_thin_body(const HpfgConvArgs& p, int tiles_x, int tiles_y) {
+template <int CI, int CO, int AK, int NW, int WGS>
+__global__ __launch_bounds__(64 * NW, WGS) void conv_thin_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
   using C = Cfg<16, 16, 4, 1, CO, 9, 16>;               // (weight-fragment indexing: CO output-channel tiles)
   using G = Geo<CI, CO, AK, NW>;
   constexpr int AK0 = G::AK0, NA0 = G::NA0, NA1 = G::NA1, NTH = G::NTH, ND = G::ND, MI = G::MI, KS = G::KS;
@@ -353,24 +353,14 @@ __device__ __forceinline__ void conv_thin_body(const HpfgConvArgs& p, int tiles_
   }
 }
 
-template <int CI, int CO, int AK, int NW, int WGS>
-__global__ __launch_bounds__(64 * NW, WGS) void conv_thin_kernel(HpfgConvArgs p, int tiles_x, int tiles_y) {
-  conv_thin_body<CI, CO, AK, NW>(p, tiles_x, tiles_y);
-}
-// the same layer of several networks in one launch (hpfg_conv_fwd_multi): blockIdx.y names the network
-template <int CI, int CO, int AK, int NW, int WGS>
-__global__ __launch_bounds__(64 * NW, WGS) void conv_thin_multi_kernel(HpfgConvMulti q, int tiles_x, int tiles_y) {
-  conv_thin_body<CI, CO, AK, NW>(q.net[blockIdx.y], tiles_x, tiles_y);
-}
-
 // workgroups of the launch = rows of stat_partials
 template <int CI, int CO, int AK, int NW, int WGS>
-inline int thin_grid(const HpfgConvArgs& a, int nnets = 1) {
+inline int thin_grid(const HpfgConvArgs& a) {
   const long nwork = (long)a.N * (a.H / T) * (a.W / T);
   int per_cu = 160 * 1024 / Geo<CI, CO, AK, NW>::LDS;
   if (per_cu > WGS) per_cu = WGS;
   if (per_cu < 1) per_cu = 1;
-  const long cap = 256L * per_cu / nnets / 8 * 8;      // (several networks per launch share the chip)
+  const long cap = 256L * per_cu;
   const long rounds = (nwork + cap - 1) / cap;           // equal work per workgroup, all of them resident
   long grid = (nwork + rounds - 1) / rounds;
   grid = (grid + 7) / 8 * 8;                             // the same number of workgroups on every XCD

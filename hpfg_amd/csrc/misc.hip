@@ -31,8 +31,6 @@ namespace {
 // dgrad: wpk[tap][ch][nt][lane][ks] = W[co = ch*16 + ks*4 + (lane>>4)][ci = nt*16 + (lane&15)][taps-1-tap]
 // Two per-forward device counters ride along (one workgroup, before any packing): num_batches_tracked of the network's BatchNorm layers
 // (+1 each) and the dropout seed word of the engine (+seed_add) -- no launches of their own in front of every forward.
-__device__ __forceinline__ void pack_layer(const HpfgPackDesc* __restrict__ table);
-
 __global__ __launch_bounds__(256) void pack_weights_kernel(const HpfgPackDesc* __restrict__ table, long long* __restrict__ counters, int n_counters,
                                                            int* __restrict__ seed_word, int seed_add, long long* __restrict__ zero, long n_zero) {
   if (blockIdx.x == 0 && blockIdx.y == 0) {
@@ -41,20 +39,6 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const HpfgPackDesc* _
   }
   // the BatchNorm sum accumulators of the pass that follows (HpfgConvArgs.stat_acc) start from zero
   for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < n_zero; i += (long)gridDim.x * gridDim.y * 256) zero[i] = 0;
-  pack_layer(table);
-}
-
-// the layers of SEVERAL networks (one concatenated table) in one launch, with each network's per-forward counters (hpfg_pack_weights_multi)
-__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const HpfgPackDesc* __restrict__ table, HpfgPackBumps b) {
-  if (blockIdx.x == 0 && blockIdx.y < HPFG_MAX_NETS) {
-    const HpfgPackBump& q = b.net[blockIdx.y];
-    for (int i = threadIdx.x; i < q.n_counters; i += 256) q.counters[i] += 1;
-    if (threadIdx.x == 0 && q.seed_word && q.seed_add) *q.seed_word = (*q.seed_word + q.seed_add) & 0x7FFFFFFF;
-  }
-  pack_layer(table);
-}
-
-__device__ __forceinline__ void pack_layer(const HpfgPackDesc* __restrict__ table) {
   const HpfgPackDesc d = table[blockIdx.y];
   const long total = (long)d.taps * d.CinPad * d.CoutPad;
   const int nt_f = d.CoutPad / 16, nch_f = d.CinPad / 16;
@@ -560,30 +544,6 @@ extern "C" int hpfg_pack_weights_bump(const HpfgPackDesc* table_dev, const HpfgP
   hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(mx, 256), nlayers), dim3(256), 0, (hipStream_t)stream, table_dev, counters, n_counters, seed_word,
                      seed_add, zero_words, n_zero);
   return hpfg_launch_status("pack_weights_kernel");
-}
-
-extern "C" int hpfg_pack_weights_multi(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, const HpfgPackBump* bumps, int nnets,
-                                       void* stream) {
-  HPFG_ARG_CHECK(table_dev && table_host && nlayers >= HPFG_MAX_NETS && nlayers < 65536, "pack_weights_multi: bad args");
-  HPFG_ARG_CHECK(bumps && nnets >= 1 && nnets <= HPFG_MAX_NETS, "pack_weights_multi: 1 .. %d networks", HPFG_MAX_NETS);
-  HpfgPackBumps b;
-  memset(&b, 0, sizeof(b));
-  for (int k = 0; k < nnets; ++k) {
-    HPFG_ARG_CHECK(bumps[k].n_counters >= 0 && (bumps[k].n_counters == 0 || bumps[k].counters) && (bumps[k].seed_add == 0 || bumps[k].seed_word),
-                   "pack_weights_multi: bad counter arguments (network %d)", k);
-    b.net[k] = bumps[k];
-  }
-  long mx = 0;
-  for (int i = 0; i < nlayers; ++i) {
-    const HpfgPackDesc& d = table_host[i];
-    HPFG_ARG_CHECK(d.CinPad % 16 == 0 && d.CoutPad % 16 == 0 && d.Cin <= d.CinPad && d.Cout <= d.CoutPad && (d.taps == 1 || d.taps == 9),
-                   "pack_weights: bad descriptor %d", i);
-    HPFG_ARG_CHECK((!d.wpk16_fwd && !d.wpk16_dgrad) || d.kc == 32 || (d.kc == 16 && d.taps == 9), "pack_weights: bad kc in descriptor %d", i);
-    long t = (long)d.taps * d.CinPad * d.CoutPad;
-    if (t > mx) mx = t;
-  }
-  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(grid_for(mx, 256), nlayers), dim3(256), 0, (hipStream_t)stream, table_dev, b);
-  return hpfg_launch_status("pack_weights_multi_kernel");
 }
 
 extern "C" int hpfg_pack_weights(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, void* stream) {

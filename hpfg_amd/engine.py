@@ -351,13 +351,6 @@ class UNetEngine:
     def _finalize_all(self, track: bool):
         """hpfg_bn_acc_finalize: every BatchNorm table of this forward (+ running statistics) in one launch, from the sum accumulators."""
         if track not in self._acc_tables:
-            self._finalize_all_table(track)
-        host, dev = self._acc_tables[track]
-        self._run("bn_fin_all", lambda: L.check(self.lib.hpfg_bn_acc_finalize(dev.data_ptr(), host, len(self.bn_layers), BN_MOMENTUM, BN_EPS, self._stream()),
-                                                "bn_acc_finalize"))
-
-    def _finalize_all_table(self, track: bool):
-        if track not in self._acc_tables:
             descs = (L.BnAccDesc * len(self.bn_layers))()
             for d, s in zip(descs, self.bn_layers):
                 d.acc, d.gamma, d.beta = L.ptr(self.acc_of[s.name]), L.ptr(self.params[f"{s.bn}.weight"]), L.ptr(self.params[f"{s.bn}.bias"])
@@ -365,6 +358,9 @@ class UNetEngine:
                 d.running_var = L.ptr(self.buffers[f"{s.bn}.running_var"]) if track else None
                 d.bn, d.C, d.count, d.shards = L.ptr(self.bn[s.name]), s.cout, float(self.N * s.h * s.w), self.acc_shards[s.name]
             self._acc_tables[track] = (descs, torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.dev))
+        host, dev = self._acc_tables[track]
+        self._run("bn_fin_all", lambda: L.check(self.lib.hpfg_bn_acc_finalize(dev.data_ptr(), host, len(self.bn_layers), BN_MOMENTUM, BN_EPS, self._stream()),
+                                                "bn_acc_finalize"))
 
     def _finalize_bn(self, s: ConvSpec, nblk: int, track: bool):
         st = self._stream()
@@ -388,8 +384,7 @@ class UNetEngine:
                 L.ptr(self.partials), nblk, None, count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), BN_MOMENTUM, BN_EPS, L.ptr(self.bn[s.name]), s.cout, st),
                 "bn_fwd_finalize"))
 
-    def _fwd_begin(self, x: torch.Tensor, train: bool, dropout: Optional[bool], seed_step: Optional[int], needs_grad: bool,
-                   defer_pack: bool = False) -> torch.Tensor:
+    def _fwd_begin(self, x: torch.Tensor, train: bool, dropout: Optional[bool], seed_step: Optional[int], needs_grad: bool) -> torch.Tensor:
         assert x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (self.N, self.in_ch, self.H, self.W), (x.shape, x.dtype, x.device)
         self.x = x
         self.train_mode = train
@@ -407,7 +402,7 @@ class UNetEngine:
                 self.acc_all.zero_()
             self._acc_dirty = True
         self._pack_args = dict(with_dgrad=bool(train and needs_grad), counters=counters, seed_add=1 if seed_step == SEED_BUMP else 0)
-        if not ((self.pack_overlap and train) or defer_pack):      # (defer_pack: forward_multi packs every network of the step in one launch)
+        if not (self.pack_overlap and train):
             self.pack(**self._pack_args)
             self._pack_args = None
         if self.marks is not None:
@@ -474,7 +469,15 @@ class UNetEngine:
                     L.ptr(self.partials) if want_stats else None, self.N, s.h, s.w, s.cin, s.cout, st), "conv3x3_first_fwd"))
             nblk = self.lib.hpfg_conv_first_rows(self.N, s.h, s.w)
         else:
-            ca = self._fwd_conv_args(s, out, want_stats, acc)
+            ca = self._conv_args(s, out, want_stats and not acc)
+            if acc:
+                ca.stat_acc, ca.stat_shards = L.ptr(self.acc_of[s.name]), self.acc_shards[s.name]
+            if self._stage_inputs and self._side_layer(s) and s.cin % 8 == 0 and ca.a0.mode != L.ACT_PLAIN:
+                buf = self.actbuf.get(s.name)
+                if buf is None:
+                    buf = self.actbuf[s.name] = torch.empty(self.N, s.h, s.w, s.cin, dtype=torch.float32, device=self.dev)
+                ca.stage_out = L.ptr(buf)
+                self._act_live.add(s.name)
             self._run("fwd:" + s.name, lambda: L.check(self.lib.hpfg_conv_fwd(C.byref(ca), st), f"conv_fwd[{s.name}]"))
             if want_stats and not acc:
                 nblk = self.lib.hpfg_conv_stat_rows(C.byref(ca))
@@ -487,20 +490,6 @@ class UNetEngine:
                 L.check(self.lib.hpfg_bn_eval_table(L.ptr(self.params[f"{s.bn}.weight"]), L.ptr(self.params[f"{s.bn}.bias"]),
                                                     L.ptr(self.buffers[f"{s.bn}.running_mean"]), L.ptr(self.buffers[f"{s.bn}.running_var"]), BN_EPS,
                                                     L.ptr(self.bn[s.name]), s.cout, st), "bn_eval_table")
-
-    def _fwd_conv_args(self, s: ConvSpec, out: torch.Tensor, want_stats: bool, acc: bool) -> L.ConvArgs:
-        """hpfg_conv_fwd descriptor of forward layer s (not the first conv) of this network: the BatchNorm sums into the layer accumulator
-        (acc) or partial rows, and -- a layer whose weight gradient will read it -- the staged input stored as a side tensor."""
-        ca = self._conv_args(s, out, want_stats and not acc)
-        if acc:
-            ca.stat_acc, ca.stat_shards = L.ptr(self.acc_of[s.name]), self.acc_shards[s.name]
-        if self._stage_inputs and self._side_layer(s) and s.cin % 8 == 0 and ca.a0.mode != L.ACT_PLAIN:
-            buf = self.actbuf.get(s.name)
-            if buf is None:
-                buf = self.actbuf[s.name] = torch.empty(self.N, s.h, s.w, s.cin, dtype=torch.float32, device=self.dev)
-            ca.stage_out = L.ptr(buf)
-            self._act_live.add(s.name)
-        return ca
 
     def materialize(self, name: str, mode=L.ACT_BNACT) -> torch.Tensor:
         """Activated output of conv `name` as a real [N,h,w,C] tensor (projection-neck input, tests)."""
@@ -903,114 +892,3 @@ class UNetEngine:
             self._slab_reduce(0, len(self._slab_host))
         # (defer: the thin layers' slabs were reduced in front of the join above, everything else on the side stream)
         self.bwd_ready = False
-
-
-# -------------------------------------------------------------------------------------------------------------------------------------------
-# One launch per layer for ALL networks of a step (round 5).  Mean-Teacher's student and teacher (2017_03_NIPS_Mean-Teacher_ACDC.py:95-101),
-# the two CPS networks (2021_06_CVPR_CPS_ACDC.py:95-101) and HPFG's forwards (main.py:152-161) run the same layer sequence on batches of the
-# same shape: side by side on two streams they fought for the CUs launch by launch (student + teacher forward 0.92 ms against 0.52 ms each
-# alone); here the network is a grid dimension of every forward launch (hpfg_conv_fwd_multi), so a 14- or 28-pixel layer fills the chip
-# with both networks' tiles and the forward chain has one kernel boundary per layer instead of two competing ones.
-def can_forward_multi(engs: List["UNetEngine"], trains: List[bool]) -> bool:
-    """True when `engs` (2 .. MAX_NETS engines) can run their forward passes as multi-network launches: same problem shape, split-bf16 math,
-    train mode with the BatchNorm sums through the accumulators (per-rank statistics, no mailbox exchange)."""
-    if not (2 <= len(engs) <= L.MAX_NETS) or len(set(id(e) for e in engs)) != len(engs):
-        return False
-    e0 = engs[0]
-    for e, tr in zip(engs, trains):
-        if (e.N, e.H, e.W, e.in_ch, e.ncls, e.dev) != (e0.N, e0.H, e0.W, e0.in_ch, e0.ncls, e0.dev):
-            return False
-        if not tr or e.math != L.MATH_BF16X3 or not e.bn_acc_on or e.peer is not None or e.world > 1 or e.force_sync:
-            return False
-        if e.in_ch not in (1, 3):      # (the multi-network first conv is the 1- / 3-channel MFMA form)
-            return False
-    return True
-
-
-class _MultiTables:
-    """Concatenated descriptor tables (weight packing, BatchNorm finalize) of a group of engines, built once per (group, flags)."""
-    cache: Dict[tuple, tuple] = {}
-
-
-def forward_multi(engs: List["UNetEngine"], xs: List[torch.Tensor], needs_grad: List[bool], seed_steps: List[Optional[int]],
-                  dropout: Optional[bool] = None, track_running: bool = True, pack_on_side: bool = False) -> List[torch.Tensor]:
-    """Train-mode forward of every engine in `engs` (can_forward_multi) with ONE launch per layer.  Returns the logits ([N,H,W,ncls] each).
-    pack_on_side: the weight packing runs on engine 0's side stream beside the first conv (which reads OIHW weights) -- only from the
-    step's origin stream (UNetEngine.pack_overlap)."""
-    e0, n = engs[0], len(engs)
-    lib, dev = e0.lib, e0.dev
-    logits = [e._fwd_begin(x, True, dropout, sd, ng, defer_pack=True) for e, x, ng, sd in zip(engs, xs, needs_grad, seed_steps)]
-    assert all(e._acc_live for e in engs)
-    st = e0._stream()
-    mult = f"x{n}"
-
-    def pack():
-        key = ("pack",) + tuple((id(e), e._pack_args["with_dgrad"]) for e in engs)
-        if key not in _MultiTables.cache:
-            tabs = [e._pack_table(e.math, e._pack_args["with_dgrad"])[0] for e in engs]
-            host = (L.PackDesc * sum(len(t) for t in tabs))()
-            i = 0
-            for t in tabs:
-                for d in t:
-                    C.memmove(C.byref(host[i]), C.byref(d), C.sizeof(L.PackDesc))
-                    i += 1
-            _MultiTables.cache[key] = (host, torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(dev), tuple(engs))
-        host, devt, _ = _MultiTables.cache[key]
-        bumps = (L.PackBump * n)()
-        for b, e in zip(bumps, engs):
-            cnt = e._pack_args["counters"]
-            if cnt is not None:
-                assert cnt.dtype == torch.int64 and cnt.is_contiguous() and cnt.device == dev
-                b.counters, b.n_counters = L.ptr(cnt), cnt.numel()
-            b.seed_word, b.seed_add = L.ptr(e.seed_dev), int(e._pack_args["seed_add"])
-            e._pack_args = None
-        stp = e0._stream()
-        e0._run("pack_weights" + mult, lambda: L.check(lib.hpfg_pack_weights_multi(devt.data_ptr(), host, len(host), bumps, n, stp), "pack_weights_multi"), stp)
-
-    for i, s in enumerate(e0.order):
-        if s.idx == 0:
-            acts = (L.Act * n)(*[e._act_input(x) for e, x in zip(engs, xs)])
-            arr = lambda ts: (C.c_void_p * n)(*[L.ptr(t) for t in ts])
-            w, b = arr([e.params[f"{s.name}.weight"] for e in engs]), arr([e.params[f"{s.name}.bias"] for e in engs])
-            o, a = arr([e.z[s.name] for e in engs]), arr([e.acc_of[s.name] for e in engs])
-            first = lambda: e0._run("fwd" + mult + ":" + s.name, lambda: L.check(lib.hpfg_conv3x3_first_fwd_acc_multi(
-                acts, w, b, o, a, n, e0.acc_shards[s.name], e0.N, s.h, s.w, s.cin, s.cout, st), "conv3x3_first_fwd_acc_multi"))
-            if pack_on_side:
-                main = torch.cuda.current_stream(dev)
-                if e0._side is None:
-                    e0._side = torch.cuda.Stream(device=dev)
-                e0._side.wait_stream(main)
-                with torch.cuda.stream(e0._side):
-                    pack()
-                first()
-                main.wait_stream(e0._side)
-            else:
-                pack()
-                first()
-            continue
-        cas = (L.ConvArgs * n)()
-        for k, e in enumerate(engs):
-            out = logits[k] if s.name == "decoder.out_conv" else e.z[s.name]
-            ca = e._fwd_conv_args(e.specs[s.name], out, bool(s.bn), bool(s.bn))
-            C.memmove(C.byref(cas[k]), C.byref(ca), C.sizeof(L.ConvArgs))
-        e0._run("fwd" + mult + ":" + s.name, lambda: L.check(lib.hpfg_conv_fwd_multi(cas, n, st), f"conv_fwd_multi[{s.name}]"))
-    # every BatchNorm table of every network (+ running statistics) in one launch
-    key = ("fin", track_running) + tuple(id(e) for e in engs)
-    if key not in _MultiTables.cache:
-        for e in engs:
-            if track_running not in e._acc_tables:
-                e._finalize_all_table(track_running)
-        tabs = [e._acc_tables[track_running][0] for e in engs]
-        host = (L.BnAccDesc * sum(len(t) for t in tabs))()
-        i = 0
-        for t in tabs:
-            for d in t:
-                C.memmove(C.byref(host[i]), C.byref(d), C.sizeof(L.BnAccDesc))
-                i += 1
-        _MultiTables.cache[key] = (host, torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(dev), tuple(engs))
-    host, devt, _ = _MultiTables.cache[key]
-    e0._run("bn_fin_all" + mult, lambda: L.check(lib.hpfg_bn_acc_finalize(devt.data_ptr(), host, len(host), BN_MOMENTUM, BN_EPS, st), "bn_acc_finalize"))
-    for e, ng in zip(engs, needs_grad):
-        e._acc_dirty = False
-        e.bwd_ready = bool(ng)
-    return logits

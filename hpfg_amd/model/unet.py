@@ -81,14 +81,11 @@ class _UNetFn(torch.autograd.Function):
     """Whole-network autograd node: forward = engine.forward, backward = engine.backward into the flat gradient buffer."""
 
     @staticmethod
-    def forward(ctx, anchor: torch.Tensor, x: torch.Tensor, net: "UNet", want_feat: bool, needs_grad: bool, pre=None):
-        if pre is not None:          # (engine, logits): the forward already ran as part of a multi-network launch sequence (forward_multi)
-            eng, logits = pre
-        else:
-            eng = net._acquire_engine(x)
-            if getattr(net, "_bn_bump_pending", False):
-                eng.bump_counters, net._bn_bump_pending = net._flat_long, False
-            logits = eng.forward(x, train=net.training, track_running=True, seed_step=net._next_seed(), needs_grad=needs_grad)
+    def forward(ctx, anchor: torch.Tensor, x: torch.Tensor, net: "UNet", want_feat: bool, needs_grad: bool):
+        eng = net._acquire_engine(x)
+        if getattr(net, "_bn_bump_pending", False):
+            eng.bump_counters, net._bn_bump_pending = net._flat_long, False
+        logits = eng.forward(x, train=net.training, track_running=True, seed_step=net._next_seed(), needs_grad=needs_grad)
         ctx.net, ctx.eng, ctx.want_feat = net, eng, want_feat
         out = logits.permute(0, 3, 1, 2)
         if want_feat:
@@ -118,7 +115,7 @@ class _UNetFn(torch.autograd.Function):
             net._buckets_launched = True
         eng.backward(dl, df, cb)
         net._accumulate_grads(eng)
-        return None, None, None, None, None, None
+        return None, None, None, None, None
 
 
 class UNet(nn.Module):
@@ -350,11 +347,7 @@ class UNet(nn.Module):
         (UNetEngine.bump_counters -> hpfg_pack_weights_bump), not by a kernel of its own."""
         self._bn_bump_pending = True
 
-    def _run(self, x: torch.Tensor, want_feat: bool, _pre=None):
-        if _pre is not None:          # forward_multi did the per-forward bookkeeping below and ran the engine
-            trainable = next(iter(self.parameters())).requires_grad
-            anchor = self._anchor if trainable else self._anchor.detach()
-            return _UNetFn.apply(anchor, x, self, want_feat, bool(trainable and torch.is_grad_enabled()), _pre)
+    def _run(self, x: torch.Tensor, want_feat: bool):
         self._ensure_flat()
         if self.training:
             self._bump_bn_counters()
@@ -362,8 +355,8 @@ class UNet(nn.Module):
         anchor = self._anchor if trainable else self._anchor.detach()
         return _UNetFn.apply(anchor, x.float(), self, want_feat, bool(trainable and torch.is_grad_enabled()))
 
-    def forward(self, x: torch.Tensor, _pre=None) -> torch.Tensor:
-        return self._run(x, False, _pre)[0]
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run(x, False)[0]
 
 
 class UNet_Plus(UNet):
@@ -380,57 +373,12 @@ class UNet_Plus(UNet):
     def val(self, x):
         return self._run(x, False)[0]
 
-    def forward(self, x, _pre=None):
+    def forward(self, x):
         self._prepare_head_grads()
-        logits, feat = self._run(x, True, _pre)
+        logits, feat = self._run(x, True)
         if getattr(self, "skip_necks", False):      # set by a step that discards them (HPFG's first student, main.py:152): nothing to compute, no gradient
             return logits, None, None
         direct = bool(getattr(self, "direct_grads", False)) and torch.is_grad_enabled()
         high = heads.projection_neck(self.dense_projection_high, feat, direct=direct)
         head = heads.projection_neck(self.dense_projection_head, logits, direct=direct)
         return logits, high, head
-
-
-def forward_multi(nets, xs, grad=None, origin: bool = False, node_streams=None):
-    """``[net(x) for net, x in zip(nets, xs)]`` with ONE launch per layer for all the networks (hpfg_conv_fwd_multi; round 5) -- the student
-    and the train-mode teacher of a Mean-Teacher step on the same x (2017_03_NIPS_Mean-Teacher_ACDC.py:95-101), the two CPS networks, HPFG's
-    forwards (main.py:152-161).  ``grad[k] = False`` runs network k under ``torch.no_grad()`` (the reference's ``with torch.no_grad():
-    ema_output = ema_model(x)``).  Returns None when the networks cannot share launches (different batch shapes, exact-fp32 math, eval mode,
-    global-batch data parallel): the caller then runs them one by one -- never a different arithmetic: per network the launches compute what
-    ``net(x)`` computes, bit for bit.  origin: the call is on the stream a capture began on (the weight packing may then fork a side stream).
-    node_streams[k]: a stream forked from the current one on which network k's autograd node (and its projection necks) is created, so that
-    autograd runs that network's BACKWARD there (a backward node executes on the stream of its forward) -- two trainable networks keep
-    back-propagating side by side; the caller joins the stream."""
-    grad = [True] * len(nets) if grad is None else list(grad)
-    if not (2 <= len(nets) <= L.MAX_NETS) or any(not isinstance(m, UNet) or not x.is_cuda for m, x in zip(nets, xs)):
-        return None
-    if any(tuple(x.shape) != tuple(xs[0].shape) or x.device != xs[0].device for x in xs) or len(set(id(m) for m in nets)) != len(nets):
-        return None
-    if any((not m.training) or m.math != "bf16x3" or (m.dp is not None and getattr(m.dp, "sync_bn", True) and (m.dp.world_size > 1 or getattr(m.dp, "force_sync", False)))
-           for m in nets):
-        return None
-    xs = [x.float() for x in xs]
-    engs = []
-    for m, x in zip(nets, xs):
-        m._ensure_flat()
-        engs.append(m._acquire_engine(x))
-    if not E.can_forward_multi(engs, [m.training for m in nets]):
-        return None
-    needs, seeds = [], []
-    for m, e, g in zip(nets, engs, grad):
-        m._bump_bn_counters()
-        e.bump_counters, m._bn_bump_pending = m._flat_long, False
-        needs.append(bool(g and torch.is_grad_enabled() and next(iter(m.parameters())).requires_grad))
-        seeds.append(m._next_seed())
-    logits = E.forward_multi(engs, xs, needs, seeds, pack_on_side=bool(origin))
-    outs = []
-    cur = torch.cuda.current_stream(xs[0].device)
-    for k, (m, x, e, lg, g) in enumerate(zip(nets, xs, engs, logits, grad)):
-        side = node_streams[k] if node_streams is not None else None
-        if side is not None:
-            side.wait_stream(cur)
-        with torch.cuda.stream(side if side is not None else cur), torch.set_grad_enabled(bool(g) and torch.is_grad_enabled()):
-            outs.append(m.forward(x, _pre=(e, lg)))
-        if side is not None:
-            lg.record_stream(side)
-    return outs

@@ -25,7 +25,6 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .model.unet import forward_multi
 from .utils import (BoxMaskGenerator, build_lr_scheduler, build_optimizer, ema_alpha, linear_rampup, seg_loss, sigmoid_rampup,
                     update_ema_variables, update_ema_variables_backbone)
 from .utils.loss import _nhwc
@@ -120,9 +119,6 @@ class _StepBase:
         # kernel chains (and, data parallel, their small BatchNorm collectives) overlap; joins before the loss.
         self.overlap = os.environ.get("HPFG_OVERLAP", "1") == "1"
         self.side = torch.cuda.Stream(device=dev) if self.overlap else None
-        # the forwards of a step's networks as multi-network launches (model.unet.forward_multi: one launch per layer for all of them) where
-        # their shapes allow; 0: one network per stream, side by side (rounds 2 - 4)
-        self.paired = os.environ.get("HPFG_PAIRED", "0") == "1"
 
     def _mark(self, i):
         if self.marks is not None:
@@ -301,11 +297,6 @@ class MeanTeacherStep(_StepBase):
         nl = label_img.shape[0]
         x = cat_batch(label_img, unlabel_img)
         self._mark(0)
-        outs = forward_multi([self.model, self.ema_model], [x, x], grad=[True, False], origin=True) if self.paired else None
-        if outs is not None:      # one launch per layer for student AND teacher (same x, 2017_03_NIPS_Mean-Teacher_ACDC.py:95-101)
-            out, t_out = outs
-            self._mark(4)
-            return self._loss_bwd(out, t_out, target_label, nl)
         if self.overlap:
             # A captured graph submits its nodes in creation order and the earlier-submitted network wins the CUs layer by layer: with the
             # teacher captured first the student -- whose forward also stores the side tensors and is what the loss waits for -- started 120 us
@@ -570,12 +561,7 @@ class CPSStep(_StepBase):
         """Everything up to (not including) the gradient exchange."""
         nl = label_img.shape[0]
         x = cat_batch(label_img, unlabel_img)
-        outs = forward_multi([self.model1, self.model2], [x, x], origin=True, node_streams=[None, self.side]) if (self.paired and self.overlap) else None
-        if outs is not None:      # one launch per layer for both networks' forwards; model2's backward still runs on the side stream
-            o1, o2 = outs
-            cur = torch.cuda.current_stream(self.dev)
-            cur.wait_stream(self.side)
-        elif self.overlap:
+        if self.overlap:
             # the two students are independent until the losses: the second one's forward runs on the side stream, and autograd runs its
             # backward there too (a backward node executes on the stream of its forward), so both chains of small kernels overlap
             cur = torch.cuda.current_stream(self.dev)
@@ -676,19 +662,6 @@ class HPFGStep(_StepBase):
         mix_un = cutmix_blend(label_img1, img_unlabel, cutmix_mask)
         batch_mix = torch.cat([label_img, mix_un], 0)
         split = self.overlap
-        volume = cat_batch(label_img, img_unlabel)
-        outs = None
-        if self.paired and split:
-            if getattr(self, "side2", None) is None:
-                self.side2 = torch.cuda.Stream(device=self.dev)
-            outs = forward_multi([self.model2, self.ema_model, self.model1], [volume, volume, batch_mix], grad=[True, False, True], origin=True,
-                                 node_streams=[None, None, self.side2])
-        if outs is not None:      # the three forwards (main.py:152-161) as one launch per layer; student 1 back-propagates on its own stream
-            (o2, h1, h2), (ot, th1, th2), (o1, _, _) = outs
-            cur = torch.cuda.current_stream(self.dev)
-            cur.wait_stream(self.side2)
-            pseudo = argmax_labels(ot[nl:], target_label1, cutmix_mask[:, 0])
-            return self._losses_bwd(o1, o2, ot, h1, h2, th1, th2, target_label, nl, pseudo)
         if split:      # student 1 (fed the CutMix batch) is independent of student 2 and the teacher until the losses: a stream of its own,
             # forward and -- through autograd, which runs a backward node on the stream of its forward -- backward (see CPSStep)
             cur = torch.cuda.current_stream(self.dev)
@@ -699,6 +672,7 @@ class HPFGStep(_StepBase):
                 o1, _, _ = self.model1(batch_mix)
         else:
             o1, _, _ = self.model1(batch_mix)
+        volume = cat_batch(label_img, img_unlabel)
         volume_t = volume
         ot, th1, th2 = self._teacher_forward(self.ema_model, volume_t)
         o2, h1, h2 = self.model2(volume)
@@ -708,9 +682,6 @@ class HPFGStep(_StepBase):
             o1.record_stream(cur)
             batch_mix.record_stream(self.side2)
         pseudo = argmax_labels(ot[nl:], target_label1, cutmix_mask[:, 0])
-        return self._losses_bwd(o1, o2, ot, h1, h2, th1, th2, target_label, nl, pseudo)
-
-    def _losses_bwd(self, o1, o2, ot, h1, h2, th1, th2, target_label, nl, pseudo):
         r1 = seg_loss(o1, target_label, nl, coef=self.sc.view(S_COEF_A, 8), pseudo=pseudo, dp=self.dp)
         r2 = seg_loss(o2, target_label, nl, coef=self.sc.view(S_COEF_B, 8), teacher_logits=ot, dp=self.dp)
         contrast = self.dense_loss(h1, th1) + self.dense_loss(h2, th2)

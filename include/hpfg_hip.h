@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 140
+#define HPFG_VERSION 130
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -171,19 +171,9 @@ int hpfg_conv_first_rows(int N, int H, int W);            /* rows of stat_partia
 /* the same layer with its BatchNorm sums added to a layer accumulator (HpfgConvArgs.stat_acc / stat_shards) as well as / instead of rows of partial sums */
 int hpfg_conv3x3_first_fwd_acc(const HpfgAct* x, const float* w_oihw, const float* bias, float* out, float* stat_partials, long long* stat_acc,
                                int stat_shards, int N, int H, int W, int Cin, int Cout, void* stream);
-/* ... of nnets networks in one launch (see hpfg_conv_fwd_multi): x / w_oihw / bias / out / stat_acc are host arrays of nnets device pointers */
-int hpfg_conv3x3_first_fwd_acc_multi(const HpfgAct* x, const float* const* w_oihw, const float* const* bias, float* const* out, long long* const* stat_acc,
-                                     int nnets, int stat_shards, int N, int H, int W, int Cin, int Cout, void* stream);
 /* nn.Conv2d k3/k1 (+ fused producer BN/LeakyReLU/Dropout/MaxPool/Upsample/cat on load) + BN partial sums.
  * Also serves dgrad: a0 = dZ (mode DZ/PLAIN), wpk = wpk_dgrad. */
 int hpfg_conv_fwd(const HpfgConvArgs* args, void* stream);
-/* The same layer of up to HPFG_MAX_NETS NETWORKS in ONE launch (round 5): args[0 .. nnets) describe the layer in every network of a step --
- * Mean-Teacher's student and teacher (2017_03_NIPS_Mean-Teacher_ACDC.py:95-101 feeds both the same x), the two CPS networks, HPFG's three
- * forwards (main.py:152-161) -- with their own weights, BatchNorm accumulators, dropout seeds and side tensors; the network index is a grid
- * dimension.  All descriptors must select the same kernel (same shapes, loader kind and math; bf16x3, forward kinds, sums through stat_acc):
- * anything else is an argument error, not a silent fallback.  Arithmetic per network is that of hpfg_conv_fwd (bit-identical outputs). */
-#define HPFG_MAX_NETS 3
-int hpfg_conv_fwd_multi(const HpfgConvArgs* args, int nnets, void* stream);
 int hpfg_conv_stat_blocks(int N, int H, int W);          /* rows written by the fp32 kernels / upper bound for workspace sizing */
 int hpfg_conv_stat_rows(const HpfgConvArgs* args);         /* rows hpfg_conv_fwd(args) writes (depends on args->math) */
 /* BatchNorm2d train-mode statistics -> table rows mean/rstd/scale/shift, running stats (momentum .1, unbiased var)
@@ -238,14 +228,6 @@ int hpfg_pack_weights(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_h
  * zero_words[0..n_zero) = 0: the BatchNorm sum accumulators (HpfgConvArgs.stat_acc) of the pass this launch precedes. */
 int hpfg_pack_weights_bump(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, long long* counters, int n_counters,
                            int32_t* seed_word, int seed_add, long long* zero_words, long n_zero, void* stream);
-/* The weight packing of SEVERAL networks in one launch (the front of a multi-network forward, hpfg_conv_fwd_multi): one concatenated
- * descriptor table; bumps[k] = the per-forward counters of network k as in hpfg_pack_weights_bump */
-typedef struct HpfgPackBump {
-  long long* counters;      /* num_batches_tracked words of the network's BatchNorm layers (+1 each), or NULL */
-  int32_t* seed_word;       /* the engine's dropout seed word, or NULL */
-  int32_t n_counters, seed_add;
-} HpfgPackBump;
-int hpfg_pack_weights_multi(const HpfgPackDesc* table_dev, const HpfgPackDesc* table_host, int nlayers, const HpfgPackBump* bumps, int nnets, void* stream);
 /* evaluate a virtual activation into memory (tests, projection-neck inputs): out [N,H,W,a0.C+a1.C] */
 int hpfg_act_materialize(const HpfgAct* a0, const HpfgAct* a1, int N, int H, int W, float* out, void* stream);
 /* the dropout keep-mask the loaders use, as bytes [n_elems] (tests feed it to the oracle) */
