@@ -14,11 +14,11 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 
 # enums from include/hpfg_hip.h
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
-ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ = range(7)
+ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ, ACT_SPLIT16 = range(8)
 OPT_CONV_THIN, OPT_FIRST_MFMA = 0, 1          # hpfg_set_option
 LOSS_NSUM = 32
 ACC_MAX_SHARDS = 8          # HPFG_ACC_MAX_SHARDS: a BatchNorm sum accumulator is long long [shards][2][C][2]
-VERSION = 130
+VERSION = 131
 MATH_F32, MATH_BF16X3 = 0, 1
 
 

@@ -354,7 +354,7 @@ __device__ static inline f32x4 cat_load4(const HpfgAct& a0, const ActCtx& c0, co
 
 
 // ---- single-mode loaders (compile-time mode): keep the conv kernels' staging code small and register-light -------------
-enum { HPFG_KIND_PLAIN = 0, HPFG_KIND_BNACT = 1, HPFG_KIND_POOL = 2, HPFG_KIND_CAT = 3, HPFG_KIND_DZ = 4 };
+enum { HPFG_KIND_PLAIN = 0, HPFG_KIND_BNACT = 1, HPFG_KIND_POOL = 2, HPFG_KIND_CAT = 3, HPFG_KIND_DZ = 4, HPFG_KIND_SPLIT = 5 };      // (SPLIT: HPFG_ACT_SPLIT16, weight gradient only)
 
 template <int MODE>
 __device__ static inline f32x4 act_load4_mode(const HpfgAct& s, const ActCtx& cx, int n, int y, int x, int c) {
@@ -385,6 +385,7 @@ static inline int hpfg_kind_of(const HpfgAct& a0, const HpfgAct& a1) {
     case HPFG_ACT_BNACT: return HPFG_KIND_BNACT;
     case HPFG_ACT_BNACT_POOL: return HPFG_KIND_POOL;
     case HPFG_ACT_DZ: return HPFG_KIND_DZ;
+    case HPFG_ACT_SPLIT16: return HPFG_KIND_SPLIT;
     default: return -1;
   }
 }

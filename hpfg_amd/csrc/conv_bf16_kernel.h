@@ -62,25 +62,26 @@ __device__ __forceinline__ Piece make_piece(int tid, int i) {
   return q;
 }
 
-template <class C, int KIND = HPFG_KIND_PLAIN>
-__device__ __forceinline__ void store_piece(unsigned char* buf, const Piece& q, const f32x4& v0, const f32x4& v1) {
+// HpfgConvArgs.stage_out (SIDE_ON: the instantiations that offer it; `on` is workgroup-uniform: output-channel slice 0 only): the staged
+// value of an interior, in-image piece (the virtual input of a forward conv, the dZ of a dgrad) also goes to memory -- as the (hi | lo) bf16
+// pair the LDS image receives, bf16 [N][H][W][C / 8][hi 8 | lo 8]: the same 32 contiguous bytes per 8-channel piece an fp32 copy took, and the
+// layer's weight gradient reads it back as an HPFG_ACT_SPLIT16 source without converting anything.  Halo pieces belong to a neighbouring
+// tile's interior.
+template <class C, int KIND = HPFG_KIND_PLAIN, bool SIDE_ON = false>
+__device__ __forceinline__ void store_piece(unsigned char* buf, const Piece& q, const f32x4& v0, const f32x4& v1, const HpfgConvArgs* p = nullptr,
+                                            bool on = false, int n = 0, int gy = 0, int gx = 0, int c0 = 0, bool ok = false) {
   if (!q.ok) return;
   bf16x8 hi, lo;
   split_piece<KIND>(v0, v1, hi, lo);
   *reinterpret_cast<bf16x8*>(buf + q.lds) = hi;
   *reinterpret_cast<bf16x8*>(buf + q.lds + C::PLANE) = lo;
-}
-
-// HpfgConvArgs.stage_out: the staged value of an interior, in-image piece (the virtual input of a forward conv, the dZ of a dgrad) goes to
-// memory as fp32 as well; the layer's weight gradient reads it as a PLAIN source.  Halo pieces belong to a neighbouring tile's interior;
-// `on` is workgroup-uniform (output-channel slice 0 only).
-template <class C>
-__device__ __forceinline__ void stage_side_store(const HpfgConvArgs& p, bool on, const Piece& q, const f32x4& v0, const f32x4& v1, int n, int gy,
-                                                 int gx, int c0, bool ok) {
-  if (on && ok && q.ly >= 0 && q.ly < C::TH && q.lx >= 0 && q.lx < C::TW) {
-    float* d = p.stage_out + (((long)n * p.H + gy) * p.W + gx) * (p.a0.C + p.a1.C) + c0;
-    *reinterpret_cast<f32x4*>(d) = v0;
-    *reinterpret_cast<f32x4*>(d + 4) = v1;
+  if constexpr (SIDE_ON) {
+    if (on && ok && q.ly >= 0 && q.ly < C::TH && q.lx >= 0 && q.lx < C::TW) {
+      const int ct = p->a0.C + p->a1.C;
+      __bf16* d = reinterpret_cast<__bf16*>(p->stage_out) + ((((long)n * p->H + gy) * p->W + gx) * ct + c0) * 2;
+      *reinterpret_cast<bf16x8*>(d) = hi;
+      *reinterpret_cast<bf16x8*>(d + 8) = lo;
+    }
   }
 }
 
@@ -454,8 +455,7 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
       f32x4 v0, v1;
       const int gyc = clampi(gy, 0, H - 1), gxc = clampi(gx, 0, W - 1);
       finish_piece<KIND>(v0, v1, raw0[i], tab, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
-      store_piece<C, KIND>(lds, pc[i], v0, v1);
-      if constexpr (SIDE) stage_side_store<C>(p, dzw, pc[i], v0, v1, n, gyc, gxc, c0c, ok);
+      store_piece<C, KIND, SIDE>(lds, pc[i], v0, v1, &p, dzw, n, gyc, gxc, c0c, ok);
     }
   }
   // B-fragment ring: the fragments of k-step g + BD are requested while k-step g computes (BD = ring size - 1 k-steps of latency
@@ -567,8 +567,7 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
               const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
               f32x4 v0, v1;       // also on the last item (more == false): the parked piece lands in the unused buffer, no branch
               finish_piece<SK>(v0, v1, raw[i & 1], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
-              store_piece<C, SK>(nxt, pc[i], v0, v1);
-              if constexpr (SIDE) stage_side_store<C>(p, dzw, pc[i], v0, v1, nn, gy, gx, c0c, ok);
+              store_piece<C, SK, SIDE>(nxt, pc[i], v0, v1, &p, dzw, nn, gy, gx, c0c, ok);
             }
             if (s < C::NLD) {
               const int i = s < C::NLD ? s : 0;
@@ -618,8 +617,7 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
             v0[j] = ok ? v0[j] : 0.f;
             v1[j] = ok ? v1[j] : 0.f;
           }
-          store_piece<C>(nxt, pc[i], v0, v1);
-          if constexpr (SIDE) stage_side_store<C>(p, dzw, pc[i], v0, v1, nn, gy, gx, c0c, ok);
+          store_piece<C, HPFG_KIND_PLAIN, SIDE>(nxt, pc[i], v0, v1, &p, dzw, nn, gy, gx, c0c, ok);
         }
       } else if (DEEP) {      // also on the last item: the pieces land in the unused buffer
 #pragma unroll
@@ -628,8 +626,7 @@ __global__ __launch_bounds__(256, (wg_per_cu<C, KIND>())) void conv_bf16x3_kerne
           const bool ok = pc[i].ok && chvn && gy >= 0 && gy < H && gx >= 0 && gx < W;
           f32x4 v0, v1;
           finish_piece<SK>(v0, v1, raw[DEEP ? i : 0], tab, p.a0, p.a1, cx0, nn, clampi(gy, 0, H - 1), clampi(gx, 0, W - 1), c0c, ok);
-          store_piece<C, SK>(nxt, pc[i], v0, v1);
-          if constexpr (SIDE) stage_side_store<C>(p, dzw, pc[i], v0, v1, nn, gy, gx, c0c, ok);
+          store_piece<C, SK, SIDE>(nxt, pc[i], v0, v1, &p, dzw, nn, gy, gx, c0c, ok);
         }
       }
       HPFG_TR(7)

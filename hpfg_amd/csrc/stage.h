@@ -51,7 +51,7 @@ struct Tab {   // per-chunk per-channel tables of this thread's 8 channels
 
 template <int KIND>
 __device__ __forceinline__ void load_tables(Tab& t, const HpfgAct& a0, int c0, bool chvalid) {
-  if (KIND == HPFG_KIND_PLAIN || !chvalid) return;
+  if (KIND == HPFG_KIND_PLAIN || KIND == HPFG_KIND_SPLIT || !chvalid) return;
   if (KIND == HPFG_KIND_CAT && c0 >= a0.C) return;
   const float* b = a0.bn + a0.bn_coff + c0;
   const int st = a0.bn_stride;
@@ -124,7 +124,11 @@ __device__ __forceinline__ void issue_piece(RawPiece<KIND>& rp, const HpfgAct& a
     for (int i = 0; i < RawCount<KIND>::N; ++i) raw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!ok) return;
   }
-  if (KIND == HPFG_KIND_PLAIN) {
+  if (KIND == HPFG_KIND_SPLIT) {      // 8 channels of the stored (hi | lo) pair: two 16-byte words, carried as bit patterns
+    const int off = ((n * a.Hs + gy) * a.Ws + gx) * a.pstride + c0;      // fp32 words == (hi, lo) pairs: 32 contiguous bytes per 8 channels
+    raw[0] = ld4(a.z, off);
+    raw[1] = ld4(a.z, off + 4);
+  } else if (KIND == HPFG_KIND_PLAIN) {
     if (a.mode == HPFG_ACT_STRIDED) {
       raw[0] = act_load4_mode<HPFG_ACT_STRIDED>(a, cx0, n, gy, gx, c0);
       raw[1] = act_load4_mode<HPFG_ACT_STRIDED>(a, cx0, n, gy, gx, c0 + 4);
@@ -193,7 +197,7 @@ __device__ __forceinline__ void finish_piece(f32x4& v0, f32x4& v1, const RawPiec
   bool need_ok = true;
   v0 = f32x4{0.f, 0.f, 0.f, 0.f};
   v1 = v0;
-  if (KIND == HPFG_KIND_PLAIN) {
+  if (KIND == HPFG_KIND_PLAIN || KIND == HPFG_KIND_SPLIT) {      // (SPLIT: v0 / v1 carry the hi / lo words; zero bits are bf16 zeros)
     v0 = raw[0];
     v1 = raw[1];
   } else if (KIND == HPFG_KIND_BNACT || (KIND == HPFG_KIND_CAT && c0 < a.C)) {
@@ -263,7 +267,12 @@ __device__ __forceinline__ void finish_piece(f32x4& v0, f32x4& v1, const RawPiec
 // (v0, v1) of finish_piece() -> the hi / lo bf16 fragments a staging store writes
 template <int KIND>
 __device__ __forceinline__ void split_piece(const f32x4& v0, const f32x4& v1, bf16x8& hi, bf16x8& lo) {
-  split8(v0, v1, hi, lo);
+  if (KIND == HPFG_KIND_SPLIT) {      // stored already split (HPFG_ACT_SPLIT16): a copy
+    hi = __builtin_bit_cast(bf16x8, v0);
+    lo = __builtin_bit_cast(bf16x8, v1);
+  } else {
+    split8(v0, v1, hi, lo);
+  }
 }
 
 }  // namespace hpfg_stage

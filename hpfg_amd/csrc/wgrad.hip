@@ -177,7 +177,10 @@ extern "C" int hpfg_wgrad(const HpfgWgradArgs* a, void* stream) {
   const bool b16 = (a->math & 0xff) == HPFG_MATH_BF16X3 && a->taps == 9;
   if ((a->math & 0xff) == HPFG_MATH_BF16X3 && a->taps == 1 && (a->g.mode == HPFG_ACT_PLAIN || a->g.mode == HPFG_ACT_STRIDED) && a->g.C % 4 == 0)
     rc = hpfg_wgrad16_launch_1x1(*a, akind, st);          // 1 = kind not covered, use the fp32 kernel below
-  if (rc != 1) {
+  if (a->g.mode == HPFG_ACT_SPLIT16 || akind == HPFG_KIND_SPLIT) {
+    HPFG_ARG_CHECK(b16, "wgrad: SPLIT16 sources are a feature of the 3x3 bf16x3 kernel");
+    rc = hpfg_wgrad16_launch_split(*a, akind, st);
+  } else if (rc != 1) {
   } else if (b16 && a->g.mode == HPFG_ACT_DZ) rc = hpfg_wgrad16_launch_dz(*a, akind, st);
   else if (b16 && (a->g.mode == HPFG_ACT_PLAIN || a->g.mode == HPFG_ACT_STRIDED)) rc = hpfg_wgrad16_launch_plain(*a, akind, st);
   else if (a->g.mode == HPFG_ACT_DZ) rc = hpfg_wgrad_launch_dz(*a, akind, st);

@@ -476,3 +476,4 @@ int launch_wgrad16(const HpfgWgradArgs& a, hipStream_t st) {
 int hpfg_wgrad16_launch_dz(const HpfgWgradArgs& a, int akind, hipStream_t st);
 int hpfg_wgrad16_launch_plain(const HpfgWgradArgs& a, int akind, hipStream_t st);
 int hpfg_wgrad16_launch_1x1(const HpfgWgradArgs& a, int akind, hipStream_t st);   // 1x1 convs: dZ is a plain gradient tensor
+int hpfg_wgrad16_launch_split(const HpfgWgradArgs& a, int akind, hipStream_t st);   // an operand stored already split (HPFG_ACT_SPLIT16)

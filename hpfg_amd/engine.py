@@ -258,6 +258,12 @@ class UNetEngine:
             a.sn, a.sc, a.sy, a.sx = h * w * a.pstride, 1, w * a.pstride, a.pstride
         return a
 
+    def _act_split(self, t: torch.Tensor, C_: int, h: int, w: int) -> L.Act:
+        """A side tensor stored by HpfgConvArgs.stage_out: bf16 [N][h][w][C / 8][hi 8 | lo 8] in a buffer of N*h*w*C fp32 words."""
+        a = L.Act()
+        a.z, a.mode, a.C, a.Hs, a.Ws, a.pstride = L.ptr(t), L.ACT_SPLIT16, C_, h, w, C_
+        return a
+
     def _act_input(self, x: torch.Tensor) -> L.Act:
         a = L.Act()
         a.z, a.mode, a.C, a.Hs, a.Ws = L.ptr(x), L.ACT_STRIDED, self.in_ch, self.H, self.W
@@ -645,11 +651,11 @@ class UNetEngine:
                 dz = self.dzbuf[s.name] = torch.empty(self.N, s.h, s.w, s.cout, dtype=torch.float32, device=self.dev)
         if self._deferred is not None:      # decoder half: the weight gradient is queued for the side stream (see backward())
             self._dgrad(s, g, dgrad_out, stats_for, out2, stage_out=dz, pool_of=pool_of)
-            self._deferred.append((s, g if dz is None else self._act_plain(dz, s.cout, s.h, s.w)))
+            self._deferred.append((s, g if dz is None else self._act_split(dz, s.cout, s.h, s.w)))
         else:
             if dz is not None:
                 self._dgrad(s, g, dgrad_out, stats_for, out2, stage_out=dz, pool_of=pool_of)
-                self._wgrad(s, self._act_plain(dz, s.cout, s.h, s.w))
+                self._wgrad(s, self._act_split(dz, s.cout, s.h, s.w))
             else:
                 self._wgrad(s, g)
                 self._dgrad(s, g, dgrad_out, stats_for, out2, pool_of=pool_of)
@@ -692,7 +698,7 @@ class UNetEngine:
         stream = self._side.cuda_stream if on_side else torch.cuda.current_stream(self.dev).cuda_stream
         wa = L.WgradArgs()
         if s.name in self._act_live:      # the forward conv stored the input it staged
-            wa.a0, wa.a1 = self._act_plain(self.actbuf[s.name], s.cin, s.h, s.w), L.Act()
+            wa.a0, wa.a1 = self._act_split(self.actbuf[s.name], s.cin, s.h, s.w), L.Act()
         else:
             wa.a0, wa.a1 = self.input_acts(s.name)
         wa.g = g

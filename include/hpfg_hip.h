@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 130
+#define HPFG_VERSION 131
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -37,7 +37,11 @@ enum {
   HPFG_ACT_BNACT = 3,      /* v = drop(lrelu(z*scale+shift))       unet.py:19-21,23-24 (BN train, LeakyReLU .01, Dropout) */
   HPFG_ACT_BNACT_POOL = 4, /* v = max 2x2 of lrelu(z*scale+shift)  unet.py:37 (MaxPool2d(2)) fused on load   */
   HPFG_ACT_UP2X = 5,       /* v = bilinear x2, align_corners=True  unet.py:51,56 fused on load               */
-  HPFG_ACT_DZ = 6          /* v = k1*g + k2*z + k3, g = aux*dropmask*lrelu'(z*scale+shift): BN/LeakyReLU/Dropout backward */
+  HPFG_ACT_DZ = 6,         /* v = k1*g + k2*z + k3, g = aux*dropmask*lrelu'(z*scale+shift): BN/LeakyReLU/Dropout backward */
+  HPFG_ACT_SPLIT16 = 7     /* a side tensor stored by HpfgConvArgs.stage_out (round 5): the value ALREADY split for the bf16x3 matrix-core
+                              products, v = hi + lo with hi = bf16(v), lo = bf16(v - hi): z = bf16 [N][Hs][Ws][pstride / 8][hi 8 | lo 8]
+                              (pstride = channels per pixel, C % 8 == 0: 32 contiguous bytes per 8 channels, the size of the fp32 tensor).
+                              Read by hpfg_wgrad only: its loader becomes a copy into LDS. */
 };
 
 typedef struct HpfgAct {
@@ -109,9 +113,11 @@ typedef struct HpfgConvArgs {
                            not multiples of 16 (the channel-rich 56 / 28 / 14-pixel levels; the aligned ones have fused kernels): the staging
                            derives the virtual input of every pixel anyway (BatchNorm + LeakyReLU + Dropout [+ max-pool | + bilinear upsample and
                            concat] in a forward conv; dZ = k1*g + k2*z + k3 in a dgrad) -- the workgroups of output-channel slice 0 also store
-                           it, fp32 [N][H][W][a0.C + a1.C] dense.  The layer's weight gradient reads the stored tensors as PLAIN sources (its
-                           input from the forward conv, its dZ from the dgrad) instead of deriving both again in every (input-channel slice x
-                           output-channel slice) workgroup */
+                           it -- as the (hi | lo) bf16 pair the staging has in registers anyway (conv_bf16_kernel.h store_piece):
+                           bf16 [N][H][W][(a0.C + a1.C) / 8][hi 8 | lo 8], the same 4 bytes per element an fp32 tensor takes.  The layer's weight
+                           gradient reads them as HPFG_ACT_SPLIT16 sources (its input from the forward conv, its dZ from the dgrad): no
+                           BatchNorm / LeakyReLU / Dropout chain, no fp32 -> bf16 split, in any of its (input-channel slice x output-channel
+                           slice) workgroups -- its loader is a copy (autograd's saved tensors of nn.Conv2d, model/unet.py:18,22) */
 } HpfgConvArgs;
 #define HPFG_ACC_MAX_SHARDS 8
 #define HPFG_ACC_WORDS(C, shards) ((shards) * 2 * 2 * (C))   /* long long words of one layer accumulator */
