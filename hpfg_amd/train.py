@@ -202,9 +202,9 @@ class _StepBase:
                 elif getattr(m, "_hpfg_flat_optimizer", None) is not None:
                     # SegFormer: autograd leaves per-parameter gradients; FusedAdamW packs them into the model's flat gradient buffer with ONE
                     # concat (what its step() does anyway) -- the exchange reduces that buffer in place and the step consumes it: no copy back
-                    opt = m._hpfg_flat_optimizer
+                    opt = m._hpfg_flat_optimizer      # (external_gather was set when the step was built: its step() consumes flat_grads as reduced here)
+                    assert opt.external_gather, "a flat-buffer optimizer under data parallel must be registered with _StepBase._own_gather"
                     red(opt.gather_flat_grads())
-                    opt._grads_gathered = True
                 else:                      # any other module: one flattened exchange of the SUM, copied back (the 1/world of the per-rank-BatchNorm
                     gs = [p.grad for p in m.parameters() if p.grad is not None]      # mode is the optimizer's grad_scale)
                     flat = torch.cat([g.reshape(-1) for g in gs])
@@ -213,6 +213,15 @@ class _StepBase:
                     for g in gs:
                         g.copy_(flat[o:o + g.numel()].view_as(g))
                         o += g.numel()
+
+    def _own_gather(self, *optimizers):
+        """Under data parallel the gradient exchange (_reduce_grads) packs a flat-buffer optimizer's per-parameter gradients and reduces them
+        in place; the optimizer's step() then never gathers again -- decided here, once, so that a captured update replays what the eager
+        one does (FusedAdamW.external_gather)."""
+        active = self.dp is not None and (self.dp.world_size > 1 or self.dp.force_sync)
+        for o in optimizers:
+            if hasattr(o, "external_gather"):
+                o.external_gather = bool(active)
 
     def _set_grad_scale(self, *optimizers):
         """sync_bn=False: the per-rank losses are means over the local batch, so the summed gradient is averaged over ranks
@@ -236,6 +245,7 @@ class SupervisedStep(_StepBase):
         self.lr_scheduler = build_lr_scheduler(args=args, optimizer=self.optimizer)
         self.optimizer._lr_dev = self.sc.view(S_LR1)
         self._set_grad_scale(self.optimizer)
+        self._own_gather(self.optimizer)
         self.sc.host[S_COEF_A:S_COEF_A + 2] = torch.tensor([0.5, 0.5])
 
     def host_scalars(self, cur_itrs):
@@ -281,6 +291,7 @@ class MeanTeacherStep(_StepBase):
         self.lr_scheduler = build_lr_scheduler(args=args, optimizer=self.optimizer)
         self.optimizer._lr_dev = self.sc.view(S_LR1)
         self._set_grad_scale(self.optimizer)
+        self._own_gather(self.optimizer)
         self.teacher_after = 7      # the teacher's launches enter the step behind this layer of the student's forward (see device_fwd_bwd)
 
     def host_scalars(self, cur_itrs, cons_w=None):
@@ -396,6 +407,7 @@ class ICTStep(_StepBase):
         self.lr_scheduler = build_lr_scheduler(args=args, optimizer=self.optimizer)
         self.optimizer._lr_dev = self.sc.view(S_LR1)
         self._set_grad_scale(self.optimizer)
+        self._own_gather(self.optimizer)
 
     def draw_mix_factors(self, unlabel_bs: int, rng=None) -> torch.Tensor:
         import numpy as np
@@ -491,6 +503,7 @@ class UAMTStep(_StepBase):
         self.lr_scheduler = build_lr_scheduler(args=args, optimizer=self.optimizer)
         self.optimizer._lr_dev = self.sc.view(S_LR1)
         self._set_grad_scale(self.optimizer)
+        self._own_gather(self.optimizer)
 
     def host_scalars(self, cur_itrs, cons_w=None):
         import math
@@ -548,6 +561,7 @@ class CPSStep(_StepBase):
         self.optimizer1._lr_dev = self.sc.view(S_LR1)
         self.optimizer2._lr_dev = self.sc.view(S_LR2)
         self._set_grad_scale(self.optimizer1, self.optimizer2)
+        self._own_gather(self.optimizer1, self.optimizer2)
 
     def host_scalars(self, cur_itrs, cons_w=None):
         a = self.args
@@ -625,6 +639,7 @@ class HPFGStep(_StepBase):
         self.optimizer1._lr_dev = self.sc.view(S_LR1)
         self.optimizer2._lr_dev = self.sc.view(S_LR2)
         self._set_grad_scale(self.optimizer1, self.optimizer2)
+        self._own_gather(self.optimizer1, self.optimizer2)
         if hasattr(model1, "dense_projection_high"):
             # main.py:152 discards the first student's neck outputs: their parameters never get a gradient (torch's SGD then skips them: no
             # weight decay, no momentum), so the necks are not computed at all and the optimizer stops at the backbone
@@ -739,6 +754,7 @@ class S4CVNetStep(_StepBase):
         self.optimizer1._lr_dev = self.sc.view(S_LR1)
         self.optimizer2._lr_dev = self.sc.view(S_LR2)
         self._set_grad_scale(self.optimizer1, self.optimizer2)
+        self._own_gather(self.optimizer1, self.optimizer2)
 
     def host_scalars(self, cur_itrs):
         a = self.args

@@ -108,7 +108,12 @@ class FusedAdamW(torch.optim.Optimizer):
         self._lr_host = torch.zeros(1, dtype=torch.float32).pin_memory()
         self._lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.grad_scale = 1.0
-        self._grads_gathered = False      # set by the data-parallel exchange, which packs (and reduces) the flat gradient buffer itself
+        # WHO packs the per-parameter gradients into model.flat_grads is a property of the step object, fixed when it is built -- not a
+        # per-call flag: a captured step evaluates host flags once, at capture time (round-4 advisor finding: graph_b captured step() with
+        # the flag False, so every replay re-concatenated the UN-reduced p.grad over the all-reduced buffer).  external_gather = True
+        # (data parallel: _StepBase._own_gather): the gradient exchange gathers, reduces in place, and step() consumes flat_grads as they
+        # are; False (one rank): step() gathers.
+        self.external_gather = False
         model._hpfg_flat_optimizer = self
 
     def zero_grad(self, set_to_none: bool = True):
@@ -131,8 +136,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None, push_lr: bool = True):
         g = self.param_groups[0]
         flat = self.model.flat_params
-        grad = self.model.flat_grads if self._grads_gathered else self.gather_flat_grads()
-        self._grads_gathered = False
+        grad = self.model.flat_grads if self.external_gather else self.gather_flat_grads()
         if push_lr:
             self.push_lr()
         st = torch.cuda.current_stream(flat.device).cuda_stream

@@ -182,3 +182,58 @@ def test_ctct_step_on_the_data_parallel_path(dp):
         assert max(abs(a - b) for a, b in zip(l0, l1)) < 1e-5, (sync_bn, l0, l1)
         assert maxerr(s0, s1) < 1e-5 and maxerr(u0, u1) < 1e-5, sync_bn
     dp.sync_bn = True
+
+
+def test_captured_ctct_update_consumes_the_reduced_gradients(dp):
+    """Round-4 advisor finding: with host-launched collectives the step replays as [forward + backward] | eager exchange | [update]; the captured
+    update must consume the flat gradient buffer the exchange REDUCED, not re-pack the local per-parameter gradients over it.  On one rank a
+    plain SUM is the identity and cannot tell the two apart, so the all-reduce is made to ADD a constant to every element (a scale would not
+    do: AdamW's update m / sqrt(v) is invariant to it): the captured chain must then follow the eager run of the same patched context -- and
+    differ from the unpatched one."""
+    from hpfg_amd.model import SegFormer
+    from hpfg_amd.train import CTCTStep
+    from oracle import segformer_ref as S
+
+    def run(graphed, shift):
+        torch.manual_seed(9)
+        reset_dropout_streams()
+        m1, m2 = UNet(1, 4).to(DEV), SegFormer(image_size=[64, 64], in_channels=1, num_classes=4).to(DEV)
+        m1.train()
+        m2.train()
+        opt = dict(opt="sgd", lr=0.01, momentum=0.9, weight_decay=5e-4, sched="medical", total_itrs=30000, step_size=1500, warmup_epochs=1, warmup_lr=1e-4,
+                   min_lr=1e-6)
+        a = AttrDict(dict(model1=AttrDict(opt), model2=AttrDict(dict(opt, opt="adamW", lr=0.0008, weight_decay=0.05)), consistency=0.1,
+                          consistency_rampup=200.0))
+        real = dp.allreduce_sum
+        dp.allreduce_sum = lambda t: real(t).add_(shift)
+        try:
+            st = CTCTStep(m1, m2, a, dp)
+            assert st.optimizer2.external_gather
+            xl, yl = synth_batch(1, 2, 64, 64, 1, 4, 8)
+            xu, _ = synth_batch(2, 2, 64, 64, 1, 4, 8)
+            inputs = [xl.to(DEV), yl.to(DEV), xu.to(DEV)]
+            torch.manual_seed(100)
+            m2.external_draws = S.draw_randomness(4)          # (fixed stochastic-depth / dropout draws: the same in every iteration and run)
+            g = None
+            for k in range(1, 5):
+                if graphed and k >= 2:
+                    if g is None:
+                        g = GraphedStep(st, inputs, warmup=0, alias_inputs=True)
+                        assert g.split
+                    g.step(inputs, k, cons_w=0.05)
+                else:
+                    st.step(*inputs, k, cons_w=0.05)
+            torch.cuda.synchronize()
+            return m2.flat_params.detach().clone(), m1.flat_params.detach().clone()
+        finally:
+            dp.allreduce_sum = real
+
+    dp.sync_bn = False
+    try:
+        s_eager, u_eager = run(False, 1e-3)
+        s_graph, u_graph = run(True, 1e-3)
+        s_plain, _ = run(False, 0.0)
+    finally:
+        dp.sync_bn = True
+    assert maxerr(s_eager, s_graph) < 1e-6 and maxerr(u_eager, u_graph) < 1e-6, (maxerr(s_eager, s_graph), maxerr(u_eager, u_graph))
+    assert maxerr(s_eager, s_plain) > 1e-5          # the control: the shifted exchange does change the SegFormer's trajectory
