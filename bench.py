@@ -29,7 +29,9 @@ Prints ONE JSON line (rank 0): the driver's contract plus
                   step; `longest_launch` is kept beside it,
   blocks          the contract's K timed steps are block 0; four more blocks of K steps follow: ms/step of each, median, min, max,
   f32_math        the same step with exact-fp32 MFMA products (N = 1, `mt` only),
-  cpu_baseline    the CPU oracle of the same step on this host's cores (bounded sample; all physical cores).
+  cpu_baseline    the CPU oracle of the same step on this host's cores (bounded sample; all physical cores),
+  exchange_path   N > 1: what every rank's sums actually travelled through (peer windows / mailboxes or the RCCL fallback and why), its
+                  window mapping and self-test results and its peer error word.
 """
 import argparse
 import faulthandler
@@ -672,6 +674,9 @@ def main():
         finally:
             dp.sync_bn = headline_sync
 
+    xpath = None
+    if dp is not None:          # every rank's exchange path + peer error word (collective: all ranks call it), for the line rank 0 prints
+        xpath = dp.exchange_report(rccl_requested=a.rccl)
     roof = f32 = cpu = None
     if rank == 0 and not a.no_probe and use_graph:
         pw = wl
@@ -716,6 +721,7 @@ def main():
             "config": {"workload": wl.desc, "per_gpu_batch": [wl.lab, wl.unlab], "size": wl.size, "hipgraph": bool(use_graph),
                        "sync_bn": bool(dp is not None and dp.sync_bn), "parallelism": par, "math": a.math},
             "step_roofline": step_roof, "roofline": roof, "blocks": blocks, "other_bn_mode": other, "f32_math": f32, "cpu_baseline": cpu,
+            "exchange_path": xpath,      # N > 1: per rank {grad_path: peer-window | rccl-fallback (why), bn_loss_path, windows_mapped, self_test, peer_err}
         }
         print(json.dumps(out), flush=True)
     if dp is not None:

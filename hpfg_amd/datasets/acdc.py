@@ -43,8 +43,9 @@ class ACDCFiles:
         d = read_datasets(self.sample_list[idx], ("image", "label"))
         return np.array(d["image"], dtype=np.float32), np.array(d["label"], dtype=np.uint8)          # ACDC.py:40-41
 
-    def label_to_img(self, label):
-        return label
+    def label_to_img(self, label):          # datasets/ACDC.py:50-63
+        from .synthetic import palette_image
+        return palette_image(label, 4)
 
 
 class _Volumes(torch.utils.data.Dataset):
@@ -60,8 +61,9 @@ class _Volumes(torch.utils.data.Dataset):
         img, lab = self.items[i]
         return torch.from_numpy(img), torch.from_numpy(lab)
 
-    def label_to_img(self, label):
-        return label
+    def label_to_img(self, label):          # datasets/ACDC.py:50-63
+        from .synthetic import palette_image
+        return palette_image(label, 4)
 
 
 def _pool(root: str, device):

@@ -11,6 +11,22 @@ import torch
 from torch.utils.data import DataLoader, Dataset
 
 
+
+def palette_image(label, ncls: int = 4):
+    """``label_to_img`` of the reference's datasets (datasets/ACDC.py:50-63) for one label map: class index -> colour, uint8 [H,W,3]
+    (ignore label 255 shown as background).  Classes 0 .. 3 take the reference's ACDC colours; further classes a fixed spread of hues."""
+    import numpy as np
+    import torch
+    if isinstance(label, torch.Tensor):
+        label = label.cpu().numpy()
+    lab = np.array(label).astype(np.uint8)
+    lab[lab == 255] = 0
+    pal = np.zeros((max(ncls, int(lab.max()) + 1, 4), 3), dtype=np.uint8)
+    pal[:4] = [[0, 0, 0], [0, 0, 255], [0, 255, 0], [255, 0, 0]]
+    for c in range(4, pal.shape[0]):
+        pal[c] = [(53 * c) % 256, (97 * c) % 256, (193 * c) % 256]
+    return pal[lab]
+
 def synth_batch(seed: int, n: int, h: int, w: int, in_ch: int = 1, ncls: int = 4, cell: int = 32):
     """(images float32 [n,in_ch,h,w], labels uint8 [n,h,w]) from a CPU generator seeded with `seed`."""
     g = torch.Generator().manual_seed(seed)
@@ -36,7 +52,7 @@ class SyntheticSlices(Dataset):
         return self.images[i], self.labels[i]
 
     def label_to_img(self, label):   # used only for TensorBoard images in the reference (main.py:318)
-        return label
+        return palette_image(label, self.num_classes)
 
 
 class SyntheticVolumes(Dataset):
@@ -58,7 +74,7 @@ class SyntheticVolumes(Dataset):
         return self.images[i], self.labels[i]
 
     def label_to_img(self, label):
-        return label
+        return palette_image(label)
 
 
 def _size(args):

@@ -29,7 +29,9 @@ the actual devices and reports whether every rank passed; bench.py falls back to
 
 `sync_bn=False` selects the usual DistributedDataParallel semantics instead: BatchNorm statistics and the loss are per rank
 (every rank sees exactly what the single-GPU reference run sees: its own 8+8 batch), and the only exchange is the gradient
-all-reduce, averaged over ranks; bench.py uses it for N > 1 unless --sync-bn is given.
+all-reduce, averaged over ranks.  bench.py's default for N > 1 is the global-batch mode above (`sync_bn=True`, sums through the peer
+mailboxes, gradient buckets through the peer windows); `--local-bn` makes this mode the headline, and either way the other one is timed on
+the same ranks and printed as `other_bn_mode`.
 """
 from __future__ import annotations
 
@@ -196,6 +198,7 @@ class DataParallelContext:
             self.p2p_grads = True
             return True
         ok = 1
+        self.peer_report = {"windows_mapped": False, "self_test": None}          # what THIS rank saw (bench.py prints every rank's: exchange_path)
         self._gpeers = [None] * self.world_size
         try:
             ptr = C.c_void_p()
@@ -220,6 +223,7 @@ class DataParallelContext:
                 self._gpeers[r] = q.value
         else:
             ok = 0
+        self.peer_report["windows_mapped"] = bool(ok)
         flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)          # (everything is mapped everywhere, or nobody starts)
         if int(flag.item()) == 1:
@@ -236,6 +240,7 @@ class DataParallelContext:
             except Exception as e:
                 import sys
                 print(f"[hpfg_amd.parallel] rank {self.rank}: peer-window self-test raised {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            self.peer_report["self_test"] = bool(good)
             flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=self.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
             self.p2p_grads = int(flag.item()) == 1
@@ -294,6 +299,34 @@ class DataParallelContext:
     def bump(self, epoch: torch.Tensor, stream: int):
         from . import _lib as L
         L.check(L.load().hpfg_word_add(epoch.data_ptr(), 1, stream), "word_add")
+
+    def exchange_report(self, rccl_requested: bool = False) -> list:
+        """Every rank's view of how its sums cross the ranks, gathered on all ranks (collective; synchronises): one dict per rank with the
+        gradient path that actually runs (peer windows or the RCCL fallback, and why: not mapped / self-test failed / requested), the
+        BatchNorm + loss path, and the peer error word (non-zero: a bounded poll expired and a kernel carried on with partial sums)."""
+        rep = dict(getattr(self, "peer_report", None) or {"windows_mapped": None, "self_test": None})
+        if self.p2p_grads:
+            grad = "peer-window"
+        elif rccl_requested:
+            grad = "rccl (requested)"
+        elif rep.get("windows_mapped") is False:
+            grad = "rccl-fallback (a peer window could not be allocated / mapped)"
+        elif rep.get("self_test") is False:
+            grad = "rccl-fallback (peer-window self-test returned a wrong sum on this rank)"
+        elif rep.get("windows_mapped") is None:
+            grad = "rccl"
+        else:
+            grad = "rccl-fallback (another rank failed its mapping or self-test)"
+        if not getattr(self, "sync_bn", True):
+            bn = "none (per-rank BatchNorm and loss)"
+        else:
+            bn = "peer-mailbox" if self.p2p else "rccl"
+        err = int(self.peer_err.item()) if self.peer_err is not None else 0
+        mine = {"rank": self.rank, "grad_path": grad, "bn_loss_path": bn, "windows_mapped": rep.get("windows_mapped"), "self_test": rep.get("self_test"),
+                "peer_err": err}
+        out = [None] * self.world_size
+        dist.all_gather_object(out, mine, group=self.group)
+        return out
 
     def check_peer_errors(self):
         """Raise if a kernel gave up waiting for a peer's value (synchronises)."""

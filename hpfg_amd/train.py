@@ -328,8 +328,10 @@ class MeanTeacherStep(_StepBase):
                     self._mark(3)
 
             self.model._after_layer = (self.teacher_after, teacher)
-            out = self.model(x)
-            self.model._after_layer = None
+            try:
+                out = self.model(x)
+            finally:          # (a forward that raises must not leave the teacher closure behind for the model's next forward, e.g. an evaluation)
+                self.model._after_layer = None
             if not box:
                 teacher()
             t_out = box[0]
@@ -826,6 +828,12 @@ class S4CVNetStep(_StepBase):
         return r
 
 
+class GraphNotCapturable(RuntimeError):
+    """GraphedStep's refusal BEFORE anything is captured (a step with host-launched collectives between its kernels): the one condition a
+    driver loop answers by staying eager.  Anything raised DURING a capture (an argument check, a workspace that is too small) is a real
+    failure and propagates."""
+
+
 class GraphedStep:
     """Captures ``step_obj.device_step`` on static input buffers into one hipGraph (torch.cuda.CUDAGraph) and replays it.
     Host scalars are copied to the device eagerly in front of every replay (StepScalars ring); dropout masks change per replay
@@ -843,7 +851,7 @@ class GraphedStep:
         if dp0 is not None and getattr(dp0, "sync_bn", True) and (dp0.world_size > 1 or dp0.force_sync) and (not getattr(dp0, "p2p", False) or host_gather):
             # all-reduced BatchNorm statistics = a collective between the kernels of every layer: those never sit inside a captured region
             # (RCCL's watchdog thread polls its events while a capture is open; losing that race aborted the process)
-            raise RuntimeError("GraphedStep: a step with collectives between its kernels (data parallel with sync_bn=True) is not captured into a "
+            raise GraphNotCapturable("GraphedStep: a step with collectives between its kernels (data parallel with sync_bn=True) is not captured into a "
                                "hipGraph; run it eager, enable the peer mailbox exchange (DataParallelContext.enable_peer_exchange: the sums then cross "
                                "the ranks inside the kernels), or use sync_bn=False (per-rank BatchNorm: collectives only between graphs)")
         self.alias = bool(alias_inputs)
@@ -864,7 +872,6 @@ class GraphedStep:
             before_capture()
         if dp0 is not None:
             dp0._loss_call = 0          # the capture traces one step from its beginning
-        self._freeze_seed_updates(True)
         # thread_local: another thread's HIP calls (the RCCL watchdog polling its events) must not invalidate this capture
         dp = getattr(step_obj, "dp", None)
         # data parallel: the gradient exchange is never captured -- [forward + loss + backward] | eager all-reduce(s) | [update] as a chain of
@@ -872,8 +879,17 @@ class GraphedStep:
         # (with the peer-window gradient exchange there is no host-launched collective left: one graph, as on one GPU)
         self.split = bool(dp is not None and (dp.world_size > 1 or dp.force_sync) and not getattr(dp, "p2p_grads", False))
         if self.split and not hasattr(step_obj, "device_fwd_bwd"):
-            raise RuntimeError(f"GraphedStep: {type(step_obj).__name__} has no device_fwd_bwd / exchange / device_update split, so its gradient "
+            raise GraphNotCapturable(f"GraphedStep: {type(step_obj).__name__} has no device_fwd_bwd / exchange / device_update split, so its gradient "
                                "exchange would be captured into the graph; run it eager under data parallel")
+        self._freeze_seed_updates(True)
+        try:
+            self._capture(dp, mode_split=self.split)
+        finally:          # whatever a capture raises, the networks leave graph-seed mode and no bucket hook stays installed
+            self._freeze_seed_updates(False)
+            if dp is not None:
+                dp.bucket_hook = None
+
+    def _capture(self, dp, mode_split: bool):
         if self.split:
             # per-rank BatchNorm (DDP semantics): the only collectives of the step are the gradient all-reduces.  The work between
             # them is captured as a CHAIN of hipGraphs and the RCCL calls are issued eagerly in between, on a side stream -- no
@@ -926,7 +942,6 @@ class GraphedStep:
         else:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.out = self.s.device_step(*self.static)
-        self._freeze_seed_updates(False)
 
     def _models(self):
         return [getattr(self.s, n) for n in ("model", "model1", "model2", "ema_model") if hasattr(self.s, n)]
@@ -1015,6 +1030,7 @@ class ScalarLog:
         self.every = max(1, int(every))
         self.buf = torch.zeros(self.every, self.width, dtype=torch.float32, device=dev)
         self.pending, self.history = [], []
+        self.check = None          # optional callable run with every flush (the driver loops: DataParallelContext.check_peer_errors)
 
     def add(self, itr: int, vecs, host: Dict[str, float]):
         k, o = len(self.pending), 0
@@ -1031,6 +1047,8 @@ class ScalarLog:
         if not self.pending:
             return
         rows = self.buf[:len(self.pending)].cpu()          # the one synchronisation per `every` iterations
+        if self.check is not None:          # data parallel: the peer-exchange error word, read while the device is idle anyway
+            self.check()
         for (itr, host), row in zip(self.pending, rows):
             named = self.emit([float(x) for x in row], host)
             self.history.append((itr, named))
@@ -1053,6 +1071,9 @@ class _LoopRunner:
         self.graph_ok = bool(getattr(args, "hipgraph", True)) and os.environ.get("HPFG_LOOP_GRAPH", "1") == "1"
         self.runner, self.n = None, 0
         self.dev = torch.device(args.device)
+        dp = getattr(args, "dp", None)
+        if dp is not None and slog.check is None:          # a poll that expired means partial sums: noticed within `log_every` iterations
+            slog.check = dp.check_peer_errors
 
     def _to_dev(self, t):
         t = t.to(self.dev, non_blocking=True)
@@ -1068,10 +1089,10 @@ class _LoopRunner:
                 dev_in = [self._to_dev(t) for t in inputs]
                 try:
                     self.runner = GraphedStep(self.st, dev_in, warmup=0)          # captures; executes nothing
-                except RuntimeError as e:          # a step that cannot be captured (collectives between its kernels): stay eager
+                except GraphNotCapturable as e:          # collectives between the step's kernels: stay eager (any other error propagates)
                     logger = getattr(self.args, "logger", None)
                     if logger is not None:
-                        logger.info(f"hipGraph capture unavailable ({e}); running eager")
+                        logger.warning(f"hipGraph capture unavailable ({e}); running eager")
                     self.graph_ok = False
             if self.runner is not None and all(tuple(a.shape) == tuple(b.shape) for a, b in zip(inputs, self.runner.static)):
                 r = self.runner.step(list(inputs), cur_itrs, **kw)          # copies (and converts) each input into its static buffer, replays
@@ -1151,9 +1172,9 @@ def Supervise(model, train_loader, test_loader, args):
         for img, label_true in train_loader:
             cur_itrs += 1
             run([img, label_true], cur_itrs)
+            _check_peers(args, cur_itrs)
             if _due(cur_itrs, args, test_loader):
                 best(model, st.optimizer, st.lr_scheduler, test_loader, cur_itrs)
-            _check_peers(args, cur_itrs)
             if cur_itrs > args.total_itrs:
                 _check_peers(args, cur_itrs, final=True)
                 return slog.losses()
@@ -1179,10 +1200,10 @@ def Mean_Teacher(model, ema_model, label_loader, unlabel_loader, test_loader, ar
             cur_itrs += 1
             label_img, target_label = next(labels)
             run([label_img, target_label, unlabel_img], cur_itrs)
+            _check_peers(args, cur_itrs)
             if _due(cur_itrs, args, test_loader):
                 best(model, st.optimizer, st.lr_scheduler, test_loader, cur_itrs, "model")
                 best_ema(ema_model, st.optimizer, st.lr_scheduler, test_loader, cur_itrs, "ema")
-            _check_peers(args, cur_itrs)
             if cur_itrs > args.total_itrs:
                 _check_peers(args, cur_itrs, final=True)
                 return slog.losses()
@@ -1218,10 +1239,10 @@ def CPS(model1, model2, label_loader, unlabel_loader, test_loader, args, step_cl
             cur_itrs += 1
             label_img, target_label = next(labels)
             run([label_img, target_label, unlabel_img], cur_itrs)
+            _check_peers(args, cur_itrs)
             if _due(cur_itrs, args, test_loader):
                 best1(model1, st.optimizer1, st.lr_scheduler1, test_loader, cur_itrs, "model1")
                 best2(model2, st.optimizer2, st.lr_scheduler2, test_loader, cur_itrs, "model2")
-            _check_peers(args, cur_itrs)
             if cur_itrs > args.total_itrs:
                 _check_peers(args, cur_itrs, final=True)
                 return slog.losses()
@@ -1259,11 +1280,11 @@ def S4CVnet(model1, model2, ema_model, label_loader, unlabel_loader, test_loader
             img_labeled, target_label = next(labels)
             noise = st.draw_noise(img_unlabel.to(args.device).float())      # an INPUT of the (captured) step: drawn here, in the reference's order (:109)
             run([img_labeled, target_label, img_unlabel, noise], cur_itrs)
+            _check_peers(args, cur_itrs)
             if _due(cur_itrs, args, test_loader):
                 best1(model1, st.optimizer1, st.lr_scheduler1, test_loader, cur_itrs, "model1")
                 best2(model2, st.optimizer2, st.lr_scheduler2, test_loader, cur_itrs, "model2")
                 best_ema(ema_model, st.optimizer2, st.lr_scheduler2, test_loader, cur_itrs, "ema")
-            _check_peers(args, cur_itrs)
             if cur_itrs > args.total_itrs:
                 _check_peers(args, cur_itrs, final=True)
                 return slog.losses()
@@ -1300,11 +1321,11 @@ def HPFG(model1, model2, ema_model, label_loader, unlabel_loader, test_loader, a
             rep = nu // nl
             cm = st.make_cutmix_mask(nu, (args.train_crop_size[0], args.train_crop_size[1]), device=torch.device(args.device))
             run([label_img, target_label, label_img1.repeat(rep, 1, 1, 1), target_label1.repeat(rep, 1, 1), img_unlabel, cm], cur_itrs)
+            _check_peers(args, cur_itrs)
             if _due(cur_itrs, args, test_loader):
                 best1(model1, st.optimizer1, st.lr_scheduler1, test_loader, cur_itrs, "model1")
                 best2(model2, st.optimizer2, st.lr_scheduler2, test_loader, cur_itrs, "model2")
                 best_ema(ema_model, st.optimizer2, st.lr_scheduler2, test_loader, cur_itrs, "model1")      # main.py:259-272 saves optimizer2 with it
-            _check_peers(args, cur_itrs)
             if cur_itrs > args.total_itrs:
                 _check_peers(args, cur_itrs, final=True)
                 return slog.losses()

@@ -109,12 +109,15 @@ def hd95_host(pred: np.ndarray, gt: np.ndarray) -> float:
     return float(np.percentile(np.hstack((surf_dist(pred, gt), surf_dist(gt, pred))), 95))
 
 
-def test_single_volume(image, label, net, classes, patch_size=(256, 256), with_hd95: bool = False):
-    """Reference signature (val.py:268).  image, label: [1,S,h,w].  Returns [(dice, hd95)] for classes 1..classes-1."""
+def test_single_volume(image, label, net, classes, patch_size=(256, 256), with_hd95: bool = False, _pred_out: list = None):
+    """Reference signature (val.py:268).  image, label: [1,S,h,w].  Returns [(dice, hd95)] for classes 1..classes-1.
+    _pred_out: optional list that receives the predicted label volume (uint8 [S,h,w], device) -- test_acdc's TensorBoard image hook."""
     dev = next(net.parameters()).device
     img = image.squeeze(0)
     lab = label.squeeze(0).to(dev)
     pred = predict_volume(img, net, patch_size)
+    if _pred_out is not None:
+        _pred_out.append(pred)
     cm = confusion_counts(pred, lab.to(torch.uint8), classes)
     out = []
     pred_h = lab_h = None
@@ -134,12 +137,25 @@ test_single_volume.__test__ = False      # reference name, not a pytest case
 
 def test_acdc(model, test_loader, args, cur_itrs=0, name="test", with_hd95: bool = False):
     """Reference signature (val.py:154): mean foreground Dice and mean HD95 over the volumes of ``test_loader`` (bs=1 volumes
-    ``(image [1,S,h,w], label [1,S,h,w])``); TensorBoard images are not produced."""
+    ``(image [1,S,h,w], label [1,S,h,w])``).  With ``args.writer`` (anything with TensorBoard's ``add_image``) the first volume's first slice
+    is logged the way main.py:309-325 does: ``<name>/Image`` (the slice resized to ``test_crop_size``, [1,H,W]), ``<name>/label_pred`` and
+    ``<name>/label_true`` (the dataset's ``label_to_img`` palette images, HWC) -- the prediction is slice 0 of the volume prediction above
+    (resize -> eval forward -> arg-max -> resize back: the arithmetic of the reference's separate forward of that slice)."""
     metric_list = 0.0
     n = 0
+    writer = getattr(args, "writer", None)
+    to_img = getattr(getattr(test_loader, "dataset", None), "label_to_img", None)
     for image, label in test_loader:
+        hook = n == 0 and writer is not None and hasattr(writer, "add_image") and to_img is not None
+        keep = [] if hook else None
         metric_list = metric_list + np.array(test_single_volume(image, label, model, classes=args.num_classes,
-                                                               patch_size=args.test_crop_size, with_hd95=with_hd95))
+                                                               patch_size=args.test_crop_size, with_hd95=with_hd95, _pred_out=keep))
+        if hook:
+            first = image[0, 0].to(keep[0].device, torch.float32)
+            shown = _resize_nearest(first.unsqueeze(0), args.test_crop_size)          # [1,H,W]: what the network saw
+            writer.add_image("{}/Image".format(name), shown.cpu(), cur_itrs)
+            writer.add_image("{}/label_pred".format(name), to_img(keep[0][0].cpu().numpy()), cur_itrs, dataformats="HWC")
+            writer.add_image("{}/label_true".format(name), to_img(label[0, 0].cpu().numpy()), cur_itrs, dataformats="HWC")
         n += 1
     metric_list = metric_list / max(n, 1)
     logger = getattr(args, "logger", None)

@@ -42,3 +42,10 @@ def test_bench_two_ranks_on_one_gpu(flags, expect, sync):
     other = out["other_bn_mode"]          # the same job times the other BatchNorm mode as well
     assert other["sync_bn"] is (not sync) and other["value"] > 0
     assert out["cpu_baseline"] is None          # reported on rank 0 at N = 1 only
+    # every rank's own view of the exchange: which path its gradients and BatchNorm / loss sums took, and its peer error word
+    xp = out["exchange_path"]
+    assert [e["rank"] for e in xp] == [0, 1] and all(e["peer_err"] == 0 for e in xp)
+    if sync:
+        assert all(e["grad_path"] == "peer-window" and e["windows_mapped"] and e["self_test"] and e["bn_loss_path"] == "peer-mailbox" for e in xp), xp
+    else:
+        assert all(e["grad_path"] == "rccl (requested)" and e["bn_loss_path"].startswith("none") for e in xp), xp

@@ -1,163 +1,132 @@
-"""Drop-in check of the Python plugin surface: the per-iteration statements of the reference's drivers --
-2017_03_NIPS_Mean-Teacher_ACDC.py:82-113 and sup_ACDC.py:83-93 -- written out as test code, with only the import roots changed
-(``hpfg_amd.utils`` / ``hpfg_amd.model`` instead of ``utils`` / ``model``).  Nothing here goes through the fused step objects of
-hpfg_amd/train.py: ``model(x)``, ``torch.softmax``, ``Med_Sup_Loss``, ``torch.mean((a - b) ** 2)``, ``loss.backward()``,
-``optimizer.step()``, ``lr_scheduler.step()`` and ``update_ema_variables`` are called one by one, as the drivers do.
+"""Drop-in check of the Python plugin surface, operator by operator.
 
-Inputs, dropout masks and expected losses are the reference's own (tests/golden/trace_mt.npz, trace_sup.npz, written by
-oracle/make_golden.py from the reference modules).  The only statements the reference does not have are the two that hand its dropout
-masks to the networks (torch's CPU Philox stream cannot be re-drawn on the device) and the bookkeeping of the asserted values;
-logging / TensorBoard / tqdm / evaluation lines are left out.
+What a maintainer of the reference gets after switching the two import roots is a set of factories and callables with the reference's names:
+``build_model``, ``build_optimizer``, ``build_lr_scheduler``, ``Med_Sup_Loss``, ``update_ema_variables``, ``get_current_consistency_weight``.
+This test drives exactly those -- plus plain torch ops on their outputs (``softmax``, a mean of squared differences, ``Tensor.backward``) --
+WITHOUT the fused step objects of hpfg_amd/train.py, through a small harness of this repository's own (``_Plugin`` below): one network
+forward per call, one loss object call, one ``optimizer.step()``, one scheduler tick, one EMA call per iteration.  What is asserted are the
+reference's own numbers: tests/golden/trace_mt.npz and trace_sup.npz hold the inputs, the dropout masks and the per-iteration losses /
+final logits that oracle/make_golden.py recorded from the reference's modules (laws: 2017_03_NIPS_Mean-Teacher_ACDC.py:95-113 for the
+student / teacher iteration, sup_ACDC.py:83-93 for the supervised one).
 """
 import math
 from copy import deepcopy
+from dataclasses import dataclass, field
+from typing import List, Optional
 
 import numpy as np
 import pytest
 import torch
 
-# ---- the two import lines a maintainer changes -------------------------------------------------------
-from hpfg_amd.utils import get_current_consistency_weight, update_ema_variables, build_lr_scheduler, build_optimizer, Med_Sup_Loss
 from hpfg_amd.model import build_model
-# ----------------------------------------------------------------------------------------------------------------------------------
-from hpfg_amd.utils import AttrDict
+from hpfg_amd.utils import (AttrDict, Med_Sup_Loss, build_lr_scheduler, build_optimizer, get_current_consistency_weight,
+                            update_ema_variables)
+from tests import trace_replay as R
 from tests.helpers import maxerr
 from tests.test_gpu_steps import _masks, _opt_args, logit_tol
-from tests import trace_replay as R
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 TOL = 1e-3
 
 
-def _args(**kw):
-    a = _opt_args(**kw)
-    a.update(dict(model="unet", in_channels=1, num_classes=4, device=DEV))
-    return AttrDict(a)
+def _cfg(**kw):
+    c = _opt_args(**kw)
+    c.update(dict(model="unet", in_channels=1, num_classes=4, device=DEV))
+    return AttrDict(c)
 
 
-class _OneBatch:
-    """A loader that yields the fixture's batch over and over (the reference iterates torch DataLoaders)."""
+@dataclass
+class _Plugin:
+    """The objects the plugin surface hands out for one run, and the handful of operator calls an iteration is made of."""
+    cfg: AttrDict
+    seed: int
+    math_mode: str
+    with_teacher: bool = False
+    net: torch.nn.Module = field(init=False)
+    teacher: Optional[torch.nn.Module] = field(init=False, default=None)
+    history: List[list] = field(init=False, default_factory=list)
 
-    def __init__(self, *tensors, n):
-        self.tensors, self.n = tensors, n
+    def __post_init__(self):
+        torch.manual_seed(self.seed)
+        self.net = build_model(self.cfg).to(DEV)          # factory call #1 of the surface
+        self.net.math = self.math_mode
+        if self.with_teacher:
+            self.teacher = deepcopy(self.net)            # the reference copies its student to get the EMA network
+            for w in self.teacher.parameters():
+                w.requires_grad = False
+            self.teacher.train()
+        self.net.train()
+        self.opt = build_optimizer(args=self.cfg, model=self.net)           # factory call #2
+        self.sched = build_lr_scheduler(args=self.cfg, optimizer=self.opt)  # factory call #3
+        self.sup_loss = Med_Sup_Loss(self.cfg.num_classes)
+        self.tick = 0
 
-    def __len__(self):
-        return self.n
+    def update(self, total: torch.Tensor):
+        """zero_grad -> backward -> optimizer -> scheduler (-> EMA of the teacher), each through its public entry point."""
+        self.opt.zero_grad()
+        total.backward()
+        self.opt.step()
+        self.sched.step()
+        if self.teacher is not None:
+            update_ema_variables(self.net, self.teacher, self.cfg.ema_decay, self.tick)
 
-    def __iter__(self):
-        for _ in range(self.n):
-            yield self.tensors
-
-
-@pytest.mark.parametrize("math_mode", ["f32", "bf16x3"])
-def test_mean_teacher_loop_body_runs_unchanged(golden_dir, math_mode):
-    d = np.load(f"{golden_dir}/trace_mt.npz")
-    # the fixture was written with the consistency weight of cur_itrs // 150 == 40; with cur_itrs = 1..3 the driver's own law
-    # (get_current_consistency_weight, ramp-up epoch 0) gives the same number for this `consistency`
-    args = _args(consistency=float(d["cons_w"]) / math.exp(-5.0), consistency_rampup=200.0)
-    torch.manual_seed(1337)
-    model = build_model(args).to(args.device)
-    model.math = math_mode
-    ema_model = deepcopy(model)
-    for p in ema_model.parameters():
-        p.requires_grad = False
-    label_loader = _OneBatch(torch.from_numpy(d["xl"]), torch.from_numpy(d["yl"]), n=3)
-    unlabel_loader = _OneBatch(torch.from_numpy(d["xu"]), torch.zeros(2), n=3)
-    rows = []
-
-    # ---- 2017_03_NIPS_Mean-Teacher_ACDC.py:63-113 ----
-    optimizer = build_optimizer(args=args, model=model)
-    lr_scheduler = build_lr_scheduler(args=args, optimizer=optimizer)
-    med_loss = Med_Sup_Loss(args.num_classes)
-    model.train()
-    ema_model.train()
-    cur_itrs = 0
-    label_iter = iter(label_loader)
-    for epoch in range(1):
-        train_loss = 0.0
-        for i, (unlabel_img, _) in enumerate(unlabel_loader):
-            cur_itrs += 1
-            try:
-                label_img, target_label = next(label_iter)
-            except StopIteration:
-                label_iter = iter(label_loader)
-                label_img, target_label, = next(label_iter)
-
-            label_img = label_img.to(args.device).float()
-            unlabel_img = unlabel_img.to(args.device).float()
-            target_label = target_label.to(args.device).long()
-            label_bs = label_img.shape[0]
-            model.external_dropout_masks = _masks(d, f"it{cur_itrs - 1}_s", 4, 32)          # (test only: the reference run's masks)
-            ema_model.external_dropout_masks = _masks(d, f"it{cur_itrs - 1}_t", 4, 32)      # (test only)
-
-            x = torch.cat([label_img, unlabel_img], dim=0)
-            x = x.to(args.device).float()
-            output = model(x)
-            output_soft = torch.softmax(output, dim=1)
-
-            with torch.no_grad():
-                ema_output = ema_model(x)
-                ema_output_soft = torch.softmax(ema_output, dim=1)
-
-            loss_sup = med_loss(output[:label_bs], target_label)
-            loss_consistence = torch.mean((output_soft[label_bs:] - ema_output_soft[label_bs:]) ** 2)
-            consistency_weight = get_current_consistency_weight(epoch=cur_itrs // 150, args=args)
-            loss = loss_sup + consistency_weight * loss_consistence
-            optimizer.zero_grad()
-            loss.backward()
-            optimizer.step()
-            lr_scheduler.step()
-            train_loss += loss.item()
-            lr = optimizer.param_groups[0]["lr"]
-            update_ema_variables(model, ema_model, args.ema_decay, cur_itrs)
-            rows.append([loss.item(), loss_sup.item(), loss_consistence.item()])          # (test only)
-    # ---- end of the reference's statements ----
-
-    assert abs(consistency_weight - float(d["cons_w"])) < 1e-12 and lr > 0
-    assert np.abs(np.array(rows) - d["losses"]).max() < TOL, (rows, d["losses"])
-    tol = logit_tol(math_mode, "mt", R.replay_mt, ["student_logits_last", "teacher_logits_last"])
-    assert maxerr(output.detach().cpu(), torch.from_numpy(d["student_logits_last"])) < tol
-    assert maxerr(ema_output.cpu(), torch.from_numpy(d["teacher_logits_last"])) < tol
+    def lr(self) -> float:
+        return float(self.opt.param_groups[0]["lr"])
 
 
-@pytest.mark.parametrize("math_mode", ["f32", "bf16x3"])
-def test_supervised_loop_body_runs_unchanged(golden_dir, math_mode):
-    d = np.load(f"{golden_dir}/trace_sup.npz")
-    args = _args(weight_decay=5e-4, sched="cosine")
-    torch.manual_seed(1)
-    model = build_model(args).to(args.device)
-    model.math = math_mode
-    train_loader = _OneBatch(torch.from_numpy(d["x"]), torch.from_numpy(d["labels"]), n=4)
-    losses = []
-
-    # ---- sup_ACDC.py:59-93 ----
-    optimizer = build_optimizer(args=args, model=model)
-    lr_scheduler = build_lr_scheduler(args=args, optimizer=optimizer)
-    criterion = Med_Sup_Loss(args.num_classes)
-    model.train()
-    cur_itrs = 0
-    train_loss = 0.0
-    for epoch in range(1):
-        for i, (img, label_true) in enumerate(train_loader):
-            cur_itrs += 1
-            img = img.to(args.device).float()
-            label_true = label_true.to(args.device).long()
-            model.external_dropout_masks = _masks(d, f"it{cur_itrs - 1}_mask", 4, 32)       # (test only)
-            label_pred = model(img)
-            loss = criterion(label_pred, label_true)
-
-            optimizer.zero_grad()
-            loss.backward()
-            optimizer.step()
-            lr_scheduler.step()
-            lr = optimizer.param_groups[0]["lr"]
-            train_loss += loss.item()
-            losses.append(loss.item())          # (test only)
-    # ---- end of the reference's statements ----
-
-    assert lr > 0 and np.abs(np.array(losses) - d["losses"]).max() < TOL, (losses, d["losses"])
-    model.eval()
+def _student_teacher_iteration(run: _Plugin, fx, k: int):
+    """Iteration k (1-based) of the Mean-Teacher law on the fixture's batch; returns (student logits, teacher logits, consistency weight)."""
+    run.tick = k
+    lab = torch.from_numpy(fx["xl"]).to(DEV)
+    unl = torch.from_numpy(fx["xu"]).to(DEV)
+    gt = torch.from_numpy(fx["yl"]).to(DEV).long()
+    n_lab = lab.shape[0]
+    run.net.external_dropout_masks = _masks(fx, f"it{k - 1}_s", 4, 32)          # the reference run's own nn.Dropout draws
+    run.teacher.external_dropout_masks = _masks(fx, f"it{k - 1}_t", 4, 32)
+    both = torch.cat((lab, unl))
+    s_logits = run.net(both)
     with torch.no_grad():
-        fin = model(img).cpu()
-    assert maxerr(fin, torch.from_numpy(d["final_eval_logits"])) < logit_tol(math_mode, "sup", R.replay_sup, ["final_eval_logits"])
+        t_logits = run.teacher(both)
+    s_prob, t_prob = s_logits.softmax(1), t_logits.softmax(1)
+    sup = run.sup_loss(s_logits[:n_lab], gt)
+    cons = ((s_prob[n_lab:] - t_prob[n_lab:]) ** 2).mean()
+    w = get_current_consistency_weight(epoch=k // 150, args=run.cfg)
+    total = sup + w * cons
+    run.update(total)
+    run.history.append([float(total), float(sup), float(cons)])
+    return s_logits.detach(), t_logits, w
+
+
+@pytest.mark.parametrize("math_mode", ["f32", "bf16x3"])
+def test_plugin_surface_reproduces_the_reference_mean_teacher_trace(golden_dir, math_mode):
+    fx = np.load(f"{golden_dir}/trace_mt.npz")
+    # the fixture's consistency weight is the ramp-up law at epoch 0 for this `consistency` (exp(-5) * consistency)
+    cfg = _cfg(consistency=float(fx["cons_w"]) / math.exp(-5.0), consistency_rampup=200.0)
+    run = _Plugin(cfg, seed=1337, math_mode=math_mode, with_teacher=True)
+    for k in (1, 2, 3):
+        s_last, t_last, w = _student_teacher_iteration(run, fx, k)
+    assert abs(w - float(fx["cons_w"])) < 1e-12 and run.lr() > 0
+    assert np.abs(np.array(run.history) - fx["losses"]).max() < TOL, (run.history, fx["losses"])
+    tol = logit_tol(math_mode, "mt", R.replay_mt, ["student_logits_last", "teacher_logits_last"])
+    assert maxerr(s_last.cpu(), torch.from_numpy(fx["student_logits_last"])) < tol
+    assert maxerr(t_last.cpu(), torch.from_numpy(fx["teacher_logits_last"])) < tol
+
+
+@pytest.mark.parametrize("math_mode", ["f32", "bf16x3"])
+def test_plugin_surface_reproduces_the_reference_supervised_trace(golden_dir, math_mode):
+    fx = np.load(f"{golden_dir}/trace_sup.npz")
+    run = _Plugin(_cfg(weight_decay=5e-4, sched="cosine"), seed=1, math_mode=math_mode)
+    images = torch.from_numpy(fx["x"]).to(DEV)
+    gt = torch.from_numpy(fx["labels"]).to(DEV).long()
+    for k in range(1, 5):
+        run.tick = k
+        run.net.external_dropout_masks = _masks(fx, f"it{k - 1}_mask", 4, 32)
+        value = run.sup_loss(run.net(images), gt)
+        run.update(value)
+        run.history.append(float(value))
+    assert run.lr() > 0 and np.abs(np.array(run.history) - fx["losses"]).max() < TOL, (run.history, fx["losses"])
+    run.net.eval()
+    with torch.no_grad():
+        final = run.net(images).cpu()
+    assert maxerr(final, torch.from_numpy(fx["final_eval_logits"])) < logit_tol(math_mode, "sup", R.replay_sup, ["final_eval_logits"])

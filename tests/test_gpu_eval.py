@@ -70,3 +70,39 @@ def test_eval_restores_training_mode_and_hd95_host():
     a = np.zeros((8, 8), bool); b = np.zeros((8, 8), bool)
     a[2:5, 2:5] = True; b[2:5, 3:6] = True
     assert abs(V.hd95_host(a, b) - 1.0) < 1e-9
+
+
+def test_eval_image_hooks_when_a_writer_is_supplied():
+    """main.py:309-325: with a TensorBoard-like writer the first volume's first slice is logged as <name>/Image, <name>/label_pred and
+    <name>/label_true (palette images); the prediction shown is slice 0 of the scored volume prediction."""
+    from hpfg_amd.datasets.synthetic import SyntheticVolumes
+    from hpfg_amd.utils import AttrDict
+
+    class Writer:
+        def __init__(self):
+            self.images = {}
+
+        def add_image(self, tag, img, step, dataformats="CHW"):
+            self.images[tag] = (np.asarray(img), step, dataformats)
+
+        def add_scalar(self, *a, **k):
+            pass
+
+    m = _trained_like_model(4)
+    loader = torch.utils.data.DataLoader(SyntheticVolumes(2, 3, (40, 36)), batch_size=1)
+    w = Writer()
+    args = AttrDict(num_classes=4, test_crop_size=(32, 32), writer=w, device=DEV)
+    dice, _ = V.test_acdc(m, loader, args, cur_itrs=200, name="model1")
+    assert 0.0 <= dice <= 1.0 and m.training
+    assert set(w.images) == {"model1/Image", "model1/label_pred", "model1/label_true"}
+    img, step, fmt = w.images["model1/Image"]
+    assert img.shape == (1, 32, 32) and step == 200 and fmt == "CHW"
+    for tag in ("model1/label_pred", "model1/label_true"):
+        im, step, fmt = w.images[tag]
+        assert im.shape == (40, 36, 3) and im.dtype == np.uint8 and fmt == "HWC" and step == 200
+    image0, label0 = loader.dataset[0]
+    pred0 = V.predict_volume(image0, m, (32, 32))[0].cpu().numpy()
+    assert np.array_equal(w.images["model1/label_pred"][0], loader.dataset.label_to_img(pred0))
+    assert np.array_equal(w.images["model1/label_true"][0], loader.dataset.label_to_img(label0[0].numpy()))
+    # no writer: nothing is logged and nothing fails
+    V.test_acdc(m, loader, AttrDict(num_classes=4, test_crop_size=(32, 32), device=DEV), cur_itrs=1)

@@ -331,10 +331,15 @@ def grad_ensemble(st, x, lab, masks, math: str, k_runs: int = 8, ncls_loss=None)
     ("f32": fp32 products; "bf16x3": the emulated split-bf16 products of oracle/bf16x3_ref.py) re-run `k_runs` times from conv weights
     perturbed at the mode's noise level -- relative 1e-6 for exact fp32 (summation order, fp32-vs-fp64 BatchNorm statistics: about ten
     roundings), 2^-18 for split-bf16 (half an ulp of the lo word: what re-quantisation of an operand moves) -- plus once with fp64
-    accumulation.  Returns (nominal gradients of that arithmetic, [ensemble gradients])."""
+    accumulation -- plus three SUMMATION-ORDER controls with unperturbed weights (round 5): the same network function evaluated on the
+    mirrored problem (input, labels, dropout masks and every 3 x 3 kernel flipped along W, along H, along both; gradients flipped back).
+    A convolution, BatchNorm's batch sums, bilinear x2 with align_corners and the Dice sums are all mirror-symmetric, so mathematically
+    nothing changes -- but every sum runs over its terms in another order and a 2 x 2 max-pool tie resolves to another element, which is
+    exactly what separates two correct kernels with different reduction orders (a correct kernel with a new tiling used to fail the
+    16-pixel case on the luck of one tie; VERDICT r4 weak spot 1).  Returns (nominal gradients of that arithmetic, [ensemble gradients])."""
     from oracle import bf16x3_ref, losses_ref
 
-    def run(mode, seed, eps):
+    def run(mode, seed, eps, flip=()):
         st2 = unet_ref.clone_state(st)
         if seed is not None:
             g = torch.Generator().manual_seed(4000 + seed)
@@ -342,14 +347,25 @@ def grad_ensemble(st, x, lab, masks, math: str, k_runs: int = 8, ncls_loss=None)
                 if n_.endswith(".weight") and st2[n_].dim() == 4:
                     r = 2 * torch.rand(st2[n_].shape, generator=g, dtype=torch.float64) - 1
                     st2[n_] = (st2[n_].double() * (1 + eps * r)).float()
+        xf, lf, mf = x, lab, masks
+        if flip:
+            for n_ in st2:
+                if n_.endswith(".weight") and st2[n_].dim() == 4 and st2[n_].shape[-1] == 3:
+                    st2[n_] = st2[n_].flip(flip).contiguous()
+            xf, lf = x.flip(flip).contiguous(), lab.flip([d - 1 for d in flip]).contiguous()
+            mf = None if masks is None else [m_.flip(flip).contiguous() for m_ in masks]
         names = steps_ref._train_state(st2)
         with bf16x3_ref.math_mode(mode):
-            o = unet_ref.unet_forward(st2, x, True, masks, track_running=False)
-            return steps_ref._grads(losses_ref.med_sup_loss(o, lab.long()), st2, names)
+            o = unet_ref.unet_forward(st2, xf, True, mf, track_running=False)
+            gr = steps_ref._grads(losses_ref.med_sup_loss(o, lf.long()), st2, names)
+        if flip:
+            gr = {k_: (v.flip(flip).contiguous() if v.dim() == 4 and v.shape[-1] == 3 else v) for k_, v in gr.items()}
+        return gr
 
     mode, eps = ("f32", 1e-6) if math == "f32" else ("bf16x3", 2.0 ** -18)
     nominal = run(mode, None, 0.0)
     ens = [run(mode + "_f64acc" if mode == "bf16x3" else "f64acc", None, 0.0)] + [run(mode, s, eps) for s in range(k_runs)]
+    ens += [run(mode, None, 0.0, flip=f) for f in ((3,), (2,), (2, 3))]
     return nominal, ens
 
 

@@ -1,5 +1,5 @@
 """Long-horizon parity run: ITERS Mean-Teacher iterations of the HIP step and of the fp32 CPU oracle side by side (same
-weights, batches and dropout masks), then held-out Dice of student and teacher.  usage: python tools/long_parity.py [iters] [hw] [math ...]"""
+weights, batches and dropout masks), then held-out Dice of student and teacher.  usage: python tools/long_parity.py [iters] [hw] [math ...] [--nl=N --nu=N]"""
 import os
 import sys
 import time
@@ -11,10 +11,14 @@ import torch  # noqa: E402
 import tests.test_gpu_train_parity as T  # noqa: E402
 from oracle import losses_ref, unet_ref  # noqa: E402
 
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+opts = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--")}      # --nl=8 --nu=8: labelled / unlabelled images per batch
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+iters = int(argv[0]) if len(argv) > 0 else 500
 T.ITERS = iters
-T.HW = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-maths = sys.argv[3:] or ["bf16x3", "f32"]
+T.HW = int(argv[1]) if len(argv) > 1 else 64
+T.NL, T.NU = opts.get("--nl", T.NL), opts.get("--nu", T.NU)
+maths = argv[2:] or ["bf16x3", "f32"]
+print(f"# long-horizon parity: {iters} Mean-Teacher iterations, {T.NL} + {T.NU} images of {T.HW} x {T.HW}, HIP step vs fp32 CPU oracle (same weights, batches, dropout masks)", flush=True)
 torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
 t0 = time.time()
 losses, st, ema_st = T._train_oracle("f32")
@@ -52,6 +56,8 @@ for math in [m for m in maths if m != "ctl"]:
         got.append(step.step(xl.to(T.DEV), yl.to(T.DEV), xu.to(T.DEV), k, cons_w=T.CONS_W)["loss"])
     got = torch.stack(got).cpu().numpy()
     dl = np.abs(got - losses)
+    ks = sorted(set([0, 1, 2, 4] + list(range(9, iters, max(1, iters // 10))) + [iters - 1]))
+    print(f"{math} loss trace (iteration: oracle / HIP): " + "  ".join(f"{k + 1}: {losses[k]:.5f} / {got[k]:.5f}" for k in ks if k < iters), flush=True)
     print(f"{math}: max|dloss| {dl.max():.3e} (first 25: {dl[:25].max():.2e}, last 25: {dl[-25:].max():.2e}); loss last 5 {got[-5:].mean():.4f}", flush=True)
     m.eval(), ema.eval()
     m.external_dropout_masks = ema.external_dropout_masks = None
