@@ -46,11 +46,31 @@ class HostLoader:
             yield self.batches[i % len(self.batches)]
 
 
+class Limited:
+    """Exactly n batches of `loader` per epoch (restarting it as often as needed), with a length that keeps the driver loops to ONE epoch."""
+
+    def __init__(self, loader, n):
+        self.loader, self.n = loader, n
+        self.dataset = getattr(loader, "dataset", None)
+
+    def __len__(self):
+        return 10 ** 9
+
+    def __iter__(self):
+        k = 0
+        while k < self.n:
+            for b in self.loader:
+                yield b
+                k += 1
+                if k >= self.n:
+                    return
+
+
 def args_for(cfg_name, iters, lab, unlab):
     a = loadyaml(os.path.join(ROOT, "config", cfg_name))
     a.device = DEV
     a.batch_size, a.unlabel_batch_size = lab, unlab
-    a.total_itrs = iters - 1          # the loops return once cur_itrs > total_itrs
+    a.total_itrs = 30000              # (the loaders end the run: Limited)
     a.step_size = 10 ** 9             # no evaluation inside the timed region
     a.num_labeled, a.num_unlabeled = 64, 256
     a.log_every = 50
@@ -88,7 +108,7 @@ def run_loop(kind, loader_kind, iters):
             lab, unl, _ = build_loader(a)
         else:
             lab, unl = HostLoader(10, 8, 64), HostLoader(500, 8, 64)
-        return timed(lambda: len(Mean_Teacher(m, e, lab, unl, None, a)))
+        return timed(lambda: len(Mean_Teacher(m, e, lab, Limited(unl, iters), None, a)))
     a = args_for("unet_30k_224x224_ACDC.yaml", iters, 8, 0)
     m, _ = models(a, False)
     if loader_kind == "device":
@@ -97,7 +117,7 @@ def run_loop(kind, loader_kind, iters):
         lab, _, _ = build_loader(a)
     else:
         lab = HostLoader(10, 8, 64)
-    return timed(lambda: len(Supervise(m, lab, None, a)))
+    return timed(lambda: len(Supervise(m, Limited(lab, iters), None, a)))
 
 
 def run_bare(kind, iters):
