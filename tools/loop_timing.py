@@ -49,8 +49,8 @@ class HostLoader:
 class Limited:
     """Exactly n batches of `loader` per epoch (restarting it as often as needed), with a length that keeps the driver loops to ONE epoch."""
 
-    def __init__(self, loader, n):
-        self.loader, self.n = loader, n
+    def __init__(self, loader, n, warm=50):
+        self.loader, self.n, self.warm, self.t_warm = loader, n, warm, None
         self.dataset = getattr(loader, "dataset", None)
 
     def __len__(self):
@@ -60,6 +60,9 @@ class Limited:
         k = 0
         while k < self.n:
             for b in self.loader:
+                if k == self.warm:          # the steady state starts here: iterations 1 (eager) and 2 (capture) are long past
+                    torch.cuda.synchronize()
+                    self.t_warm = time.perf_counter()
                 yield b
                 k += 1
                 if k >= self.n:
@@ -71,7 +74,6 @@ def args_for(cfg_name, iters, lab, unlab):
     a.device = DEV
     a.batch_size, a.unlabel_batch_size = lab, unlab
     a.total_itrs = 30000              # (the loaders end the run: Limited)
-    a.step_size = 10 ** 9             # no evaluation inside the timed region
     a.num_labeled, a.num_unlabeled = 64, 256
     a.log_every = 50
     return a
@@ -91,12 +93,15 @@ def models(a, teacher):
     return m, e
 
 
-def timed(fn):
+def timed(fn, lim=None):
+    """(ms per iteration over the whole run, ms per iteration from iteration `lim.warm` on)"""
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
+    t1 = time.perf_counter()
+    steady = (t1 - lim.t_warm) / (n - lim.warm) * 1e3 if lim is not None and lim.t_warm is not None else None
+    return (t1 - t0) / n * 1e3, steady
 
 
 def run_loop(kind, loader_kind, iters):
@@ -108,7 +113,8 @@ def run_loop(kind, loader_kind, iters):
             lab, unl, _ = build_loader(a)
         else:
             lab, unl = HostLoader(10, 8, 64), HostLoader(500, 8, 64)
-        return timed(lambda: len(Mean_Teacher(m, e, lab, Limited(unl, iters), None, a)))
+        lim = Limited(unl, iters)
+        return timed(lambda: len(Mean_Teacher(m, e, lab, lim, None, a)), lim)
     a = args_for("unet_30k_224x224_ACDC.yaml", iters, 8, 0)
     m, _ = models(a, False)
     if loader_kind == "device":
@@ -117,7 +123,8 @@ def run_loop(kind, loader_kind, iters):
         lab, _, _ = build_loader(a)
     else:
         lab = HostLoader(10, 8, 64)
-    return timed(lambda: len(Supervise(m, Limited(lab, iters), None, a)))
+    lim = Limited(lab, iters)
+    return timed(lambda: len(Supervise(m, lim, None, a)), lim)
 
 
 def run_bare(kind, iters):
@@ -144,16 +151,18 @@ def run_bare(kind, iters):
         for k in range(iters):
             g.step(inputs, 20 + k)
         return iters
-    return timed(go)
+    return timed(go)[0]
 
 
 if __name__ == "__main__":
-    print(f"# tools/loop_timing.py: {ITERS} iterations per line, one MI355X; ms per iteration incl. iteration 1 (eager) and 2 (capture) of the loops")
+    print(f"# tools/loop_timing.py, one MI355X, {ITERS} iterations per run.  A loop's run contains iteration 1 (eager: allocates the engines' workspaces) and\n"
+          f"# iteration 2 (captures the step into a hipGraph), ~0.2 s together; 'steady' = iterations 51 .. {ITERS} of the same run.  ms per iteration:")
     for kind, name in (("mt", "Mean_Teacher (8 + 8 x 224^2)"), ("sup", "Supervise (8 x 224^2)")):
         bare = run_bare(kind, ITERS)
-        dev = run_loop(kind, "device", ITERS)
-        host = run_loop(kind, "host", ITERS)
-        dev2 = run_loop(kind, "device", 3 * ITERS)
-        print(f"{name}: captured step on resident inputs (bench.py's region) {bare:.4f} ms | loop, device-resident loader {dev:.4f} ms "
-              f"({100 * (dev / bare - 1):+.1f} %; {3 * ITERS} iterations: {dev2:.4f} ms, {100 * (dev2 / bare - 1):+.1f} %) | loop, host loader (pinned CPU "
-              f"batches) {host:.4f} ms ({100 * (host / bare - 1):+.1f} %)", flush=True)
+        d, h = run_loop(kind, "device", ITERS), run_loop(kind, "host", ITERS)
+        bare2 = run_bare(kind, ITERS)
+        b = 0.5 * (bare + bare2)
+        print(f"{name}: captured step on resident inputs (bench.py's timed region) {bare:.4f} (before the loops), {bare2:.4f} (after)\n"
+              f"    loop, device-resident loader (build_loader('device_synthetic')): whole run {d[0]:.4f}, steady {d[1]:.4f} ({100 * (d[1] / b - 1):+.1f} % vs the bare step)\n"
+              f"    loop, host loader (pinned CPU batches, one copy per input into the step's static buffers): whole run {h[0]:.4f}, steady {h[1]:.4f} "
+              f"({100 * (h[1] / b - 1):+.1f} %)", flush=True)
