@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 # enums from include/hpfg_hip.h
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ, ACT_SPLIT16 = range(8)
-OPT_CONV_THIN, OPT_FIRST_MFMA = 0, 1          # hpfg_set_option
+OPT_CONV_THIN, OPT_FIRST_MFMA, OPT_FIRST_WGRAD = 0, 1, 2          # hpfg_set_option
 LOSS_NSUM = 32
 ACC_MAX_SHARDS = 8          # HPFG_ACC_MAX_SHARDS: a BatchNorm sum accumulator is long long [shards][2][C][2]
 VERSION = 131
@@ -245,6 +245,8 @@ def load() -> C.CDLL:
             fn.argtypes = args
         if lib.hpfg_version() != VERSION:
             raise HipLibraryError(f"libhpfg_hip.so version {lib.hpfg_version()} != binding version {VERSION}; rebuild")
+        if os.environ.get("HPFG_FIRST_WGRAD", "1") == "0":      # A/B runs: the first layer's weight gradient on the tile kernel
+            lib.hpfg_set_option(OPT_FIRST_WGRAD, 0)
         _lib = lib
     return _lib
 

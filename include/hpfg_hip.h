@@ -165,8 +165,9 @@ int hpfg_version(void);
 const char* hpfg_last_error(void);
 /* Kernel-form switches for tests and A/B tools (the launch paths read no environment variables): returns the previous value (>= 0) or < 0.
  * HPFG_OPT_CONV_THIN: 0 = the thin forward layers on the chunked conv kernel instead of the whole-tile kernel;
- * HPFG_OPT_FIRST_MFMA: 0 = the 1- / 3-channel first layer as a VALU loop instead of the MFMA form (bit-identical outputs). */
-enum { HPFG_OPT_CONV_THIN = 0, HPFG_OPT_FIRST_MFMA = 1, HPFG_OPT_COUNT = 2 };
+ * HPFG_OPT_FIRST_MFMA: 0 = the 1- / 3-channel first layer as a VALU loop instead of the MFMA form (bit-identical outputs);
+ * HPFG_OPT_FIRST_WGRAD: 0 = the first layer's weight gradient on the tile kernel of hpfg_fused_bwd instead of the streaming kernel. */
+enum { HPFG_OPT_CONV_THIN = 0, HPFG_OPT_FIRST_MFMA = 1, HPFG_OPT_FIRST_WGRAD = 2, HPFG_OPT_COUNT = 3 };
 int hpfg_set_option(int which, int value);
 
 /* ---- forward ------------------------------------------------------------------------------------------- */
