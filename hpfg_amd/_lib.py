@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 # enums from include/hpfg_hip.h
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
 ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ, ACT_SPLIT16 = range(8)
-OPT_CONV_THIN, OPT_FIRST_MFMA, OPT_FIRST_WGRAD = 0, 1, 2          # hpfg_set_option
+OPT_CONV_THIN, OPT_FIRST_MFMA, OPT_FIRST_WGRAD, OPT_NARROW_DEEP = 0, 1, 2, 3          # hpfg_set_option
 LOSS_NSUM = 32
 ACC_MAX_SHARDS = 8          # HPFG_ACC_MAX_SHARDS: a BatchNorm sum accumulator is long long [shards][2][C][2]
 VERSION = 131
@@ -247,6 +247,8 @@ def load() -> C.CDLL:
             raise HipLibraryError(f"libhpfg_hip.so version {lib.hpfg_version()} != binding version {VERSION}; rebuild")
         if os.environ.get("HPFG_FIRST_WGRAD", "1") == "0":      # A/B runs: the first layer's weight gradient on the tile kernel
             lib.hpfg_set_option(OPT_FIRST_WGRAD, 0)
+        if os.environ.get("HPFG_NARROW_DEEP") is not None:      # A/B runs: workgroup threshold below which a 3x3 launch takes 32-wide slices (0: never)
+            lib.hpfg_set_option(OPT_NARROW_DEEP, int(os.environ["HPFG_NARROW_DEEP"]))
         _lib = lib
     return _lib
 

@@ -825,6 +825,14 @@ int conv_dispatch_kind(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
     // (round 4: the same 64 x 64 tile as 2 x 2 waves of 2 pixel tiles x 2 channel tiles -- half the LDS reads of A fragments, which the SQ
     // counters make the longest of the kernel's three pipes, but a B ring of 3 instead of 9 k-steps -- measured +7 % on the step,
     // profiles/r04_schedule_experiments.txt)
+    // (round 5) a 64-wide slice leaves a launch of <= 128 workgroups on half of the 256 CUs at one wave per SIMD -- the dgrad of down4.c1,
+    // 256 -> 128 channels on 16 x 14 x 14 pixels with the max-pool backward in its epilogue, took 44 - 73 us that way: 32-wide slices there
+    // (twice the workgroups; the staging is repeated per slice, but such a launch is latency-bound, not issue-bound)
+    {
+      const long tiles = (long)a.N * ((a.H + 3) / 4) * ((a.W + 15) / 16);
+      if (cp % 64 == 0 && tiles * (cp / 64) <= hpfg_opt(HPFG_OPT_NARROW_DEEP))      // (the option's value = the workgroup threshold; 0 = off)
+        return launch_cfg<Cfg<4, 16, 2, 2, 1, TAPS, 32>, KIND>(a, st, rows_only);
+    }
     if (cp % 64 == 0) return launch_cfg<Cfg<4, 16, 1, 4, 1, TAPS, 32>, KIND>(a, st, rows_only);
     if (cp % 32 == 0) return launch_cfg<Cfg<4, 16, 2, 2, 1, TAPS, 32>, KIND>(a, st, rows_only);
     return launch_cfg<Cfg<4, 16, 4, 1, 1, TAPS, 32>, KIND>(a, st, rows_only);

@@ -15,7 +15,7 @@ extern "C" const char* hpfg_last_error(void) { return g_err; }
 extern "C" int hpfg_version(void) { return HPFG_VERSION; }
 
 // ---- kernel-form switches (tests and A/B tools; never read from the environment in a launch path) -------------------------------------
-static int g_opt[HPFG_OPT_COUNT] = {1, 1, 1};
+static int g_opt[HPFG_OPT_COUNT] = {1, 1, 1, 128};
 int hpfg_opt(int which) { return which >= 0 && which < HPFG_OPT_COUNT ? g_opt[which] : 0; }
 extern "C" int hpfg_set_option(int which, int value) {
   HPFG_ARG_CHECK(which >= 0 && which < HPFG_OPT_COUNT, "set_option: unknown option %d", which);

@@ -166,8 +166,10 @@ const char* hpfg_last_error(void);
 /* Kernel-form switches for tests and A/B tools (the launch paths read no environment variables): returns the previous value (>= 0) or < 0.
  * HPFG_OPT_CONV_THIN: 0 = the thin forward layers on the chunked conv kernel instead of the whole-tile kernel;
  * HPFG_OPT_FIRST_MFMA: 0 = the 1- / 3-channel first layer as a VALU loop instead of the MFMA form (bit-identical outputs);
- * HPFG_OPT_FIRST_WGRAD: 0 = the first layer's weight gradient on the tile kernel of hpfg_fused_bwd instead of the streaming kernel. */
-enum { HPFG_OPT_CONV_THIN = 0, HPFG_OPT_FIRST_MFMA = 1, HPFG_OPT_FIRST_WGRAD = 2, HPFG_OPT_COUNT = 3 };
+ * HPFG_OPT_FIRST_WGRAD: 0 = the first layer's weight gradient on the tile kernel of hpfg_fused_bwd instead of the streaming kernel;
+ * HPFG_OPT_NARROW_DEEP: the workgroup count up to which a 3x3 launch on 4 x 16-pixel tiles takes 32-wide instead of 64-wide output-channel slices
+ *   (default 128: launches that would leave half of the CUs idle; 0 = never). */
+enum { HPFG_OPT_CONV_THIN = 0, HPFG_OPT_FIRST_MFMA = 1, HPFG_OPT_FIRST_WGRAD = 2, HPFG_OPT_NARROW_DEEP = 3, HPFG_OPT_COUNT = 4 };
 int hpfg_set_option(int which, int value);
 
 /* ---- forward ------------------------------------------------------------------------------------------- */

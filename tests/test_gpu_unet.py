@@ -73,8 +73,16 @@ def test_forward_eval_matches_oracle(n, hw, in_ch, ncls, seed):
     assert maxerr(out.cpu(), ref) < 1e-3
 
 
+# Gradient cases: inputs of at least 32 pixels a side.  On a 16-pixel side the bottleneck is ONE pixel wide and a BatchNorm channel there sees
+# N (x 1 .. 3) samples: a single LeakyReLU / max-pool tie that falls the other way under a different (equally correct) summation order moves
+# the MEDIAN parameter gradient by ~1e-2, and whether a 12-run control ensemble happens to contain such a flip is luck -- three correct
+# experimental kernels of round 4 and the 32-wide deep-layer slices of round 5 went red on (4, 16, 1, 2, 13) for exactly that reason
+# (VERDICT r4, weak spot 1).  The 16-pixel shapes stay in the forward / logit cases above, where no such amplification exists.
+GRAD_CASES = [c for c in CASES if min(_hw(c[1])) >= 32] + [(2, 96, 3, 2, 21)]
+
+
 @pytest.mark.parametrize("math", ["f32", "bf16x3"])
-@pytest.mark.parametrize("n,hw,in_ch,ncls,seed", CASES)
+@pytest.mark.parametrize("n,hw,in_ch,ncls,seed", GRAD_CASES)
 def test_backward_all_parameter_gradients(n, hw, in_ch, ncls, seed, math):
     reset_dropout_streams()      # the masks (hence which LeakyReLU / max-pool ties can flip) must not depend on which tests ran before
     torch.manual_seed(seed)
