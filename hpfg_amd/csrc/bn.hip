@@ -425,6 +425,7 @@ extern "C" int hpfg_bn_acc_finalize(const HpfgBnAccDesc* table_dev, const HpfgBn
     HPFG_ARG_CHECK(d.acc && d.gamma && d.beta && d.bn && d.C > 0 && d.count >= 1.f && (d.running_mean == nullptr) == (d.running_var == nullptr) &&
                        d.shards >= 1 && d.shards <= HPFG_ACC_MAX_SHARDS && (d.shards & (d.shards - 1)) == 0,
                    "bn_acc_finalize: bad descriptor %d", i);
+    HPFG_ARG_CHECK(table_host[i].count <= 16777216.f, "bn_acc_finalize: count of descriptor %d above 2^24 (a float holds N*H*W exactly up to there)", i);
     if (d.C > maxc) maxc = d.C;
   }
   hipLaunchKernelGGL(bn_acc_finalize_kernel, dim3((maxc + 255) / 256, nlayers), dim3(256), 0, (hipStream_t)stream, table_dev, momentum, eps);
@@ -438,6 +439,7 @@ extern "C" int hpfg_bn_acc_bwd_finalize(const HpfgBnAccBwdDesc* table_dev, const
     const HpfgBnAccBwdDesc& d = table_host[i];
     HPFG_ARG_CHECK(d.acc && d.gamma && d.bn && d.C > 0 && d.count >= 1.f && d.shards >= 1 && d.shards <= HPFG_ACC_MAX_SHARDS && (d.shards & (d.shards - 1)) == 0,
                    "bn_acc_bwd_finalize: bad descriptor %d", i);
+    HPFG_ARG_CHECK(table_host[i].count <= 16777216.f, "bn_acc_bwd_finalize: count of descriptor %d above 2^24", i);
     if (d.C > maxc) maxc = d.C;
   }
   hipLaunchKernelGGL(bn_acc_bwd_finalize_kernel, dim3((maxc + 255) / 256, nlayers), dim3(256), 0, (hipStream_t)stream, table_dev);
@@ -472,6 +474,7 @@ static int bn_bwd_reduce_impl(const HpfgAct* g, int N, int H, int W, float* part
   HPFG_ARG_CHECK(g->Hs == H && g->Ws == W, "bn_bwd_reduce: source size mismatch");
   long npix = (long)N * H * W;
   int nblk = hpfg_bn_bwd_blocks(N, H, W, g->C);
+  if (acc) HPFG_ACC_CHECK(nblk, shards, "bn_bwd_reduce_acc");
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *g, npix, partials, acc, shards);
   return hpfg_launch_status("bn_bwd_reduce_kernel");
 }
@@ -500,6 +503,7 @@ static int bn_bwd_reduce_pool_impl(const HpfgAct* g, const float* dP, int dp_pst
   HPFG_ARG_CHECK(g->Hs == 2 * Hp && g->Ws == 2 * Wp && N > 0, "bn_bwd_reduce_pool: the source must be exactly twice the pooled size");
   HPFG_ARG_CHECK(g->drop_p == 0.f, "bn_bwd_reduce_pool: a pooled block output has no dropout behind it");
   HPFG_ARG_CHECK(dp_pstride % 4 == 0 && g->aux_pstride % 4 == 0 && g->pstride % 4 == 0, "bn_bwd_reduce_pool: pixel strides must be multiples of 4");
+  if (acc) HPFG_ACC_CHECK(hpfg_bn_bwd_pool_blocks(N, Hp, Wp, g->C), shards, "bn_bwd_reduce_pool_acc");
   hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(hpfg_bn_bwd_pool_blocks(N, Hp, Wp, g->C)), dim3(256), 0, (hipStream_t)stream, *g, dP, dp_pstride,
                      (long)N * Hp * Wp, Hp, Wp, partials, acc, shards);
   return hpfg_launch_status("bn_bwd_reduce_pool_kernel");

@@ -57,8 +57,14 @@ __device__ static inline float lrelu(float y) { return fmaxf(y, HPFG_LEAKY * y);
 // A producer workgroup adds its per-channel partial sums to the layer accumulator, long long [SHARDS][which][limb][C]; every consumer reads
 // the 8 shards of its channels and derives the BatchNorm coefficients itself, so no finalize launch sits between the two kernels.  The
 // split t = hi + lo * 2^-52 (hi = rint(t), lo = (t - hi) * 2^52: both exact for a float t above 2^-29; |lo| <= 2^51, so 2^11 partial sums add
-// without overflow) loses nothing an fp64 sum would keep, and integer sums are associative: bit-reproducible totals without a fixed
+// without overflow -- every launcher that takes an accumulator checks its workgroups per shard against that: HPFG_ACC_CHECK) loses nothing an fp64 sum would keep, and integer sums are associative: bit-reproducible totals without a fixed
 // workgroup order (a float atomic would make BatchNorm, hence the run, non-deterministic).
+// host-side guard of that bound, for every launcher that accepts a sum accumulator: `workgroups` partial sums spread over `shards` shards
+#define HPFG_ACC_MAX_ADDS 2048
+#define HPFG_ACC_CHECK(workgroups, shards, who)                                                                                     \
+  HPFG_ARG_CHECK(((long)(workgroups) + (shards) - 1) / ((shards) > 0 ? (shards) : 1) <= HPFG_ACC_MAX_ADDS,                           \
+                 "%s: %ld workgroups on %d accumulator shards exceed the %d exact adds per shard of hpfg_acc_add", who, (long)(workgroups), (int)(shards), \
+                 HPFG_ACC_MAX_ADDS)
 __device__ __forceinline__ void hpfg_acc_add(long long* acc, int C, int shard, int which, int c, float t) {
   const float r = rintf(t);
   const long long hi = (long long)r, lo = (long long)rintf((t - r) * 4503599627370496.f);

@@ -282,9 +282,9 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
   for (const HpfgAct* s : {&a->a0, &a->a1}) {
     if (!s->bn_acc) continue;
     HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && (s->mode == HPFG_ACT_BNACT || s->mode == HPFG_ACT_BNACT_POOL || s->mode == HPFG_ACT_DZ) &&
-                       s->bn_gamma && (s->bn_beta || s->mode == HPFG_ACT_DZ) && s->bn_count >= 1.f && s->C <= 256 && s->bn_shards >= 1 &&
+                       s->bn_gamma && (s->bn_beta || s->mode == HPFG_ACT_DZ) && s->bn_count >= 1.f && s->bn_count <= 16777216.f && s->C <= 256 && s->bn_shards >= 1 &&
                        s->bn_shards <= HPFG_ACC_MAX_SHARDS,
-                   "conv_fwd: bn_acc needs a BNACT / BNACT_POOL / DZ source of the bf16x3 kernels with gamma (beta), count and at most 256 channels");
+                   "conv_fwd: bn_acc needs a BNACT / BNACT_POOL / DZ source of the bf16x3 kernels with gamma (beta), a count of at most 2^24 (a float holds N*H*W exactly up to there) and at most 256 channels");
   }
   HPFG_ARG_CHECK((a->math & 0xff) != HPFG_MATH_BF16X3 || !(a->a0.mode == HPFG_ACT_BNACT || a->a0.mode == HPFG_ACT_BNACT_POOL || a->a0.mode == HPFG_ACT_DZ) ||
                      a->a0.C <= 256,
@@ -348,6 +348,7 @@ static int conv_first_impl(const HpfgFirstConvArgs* q, int N, int H, int W, int 
   HPFG_ARG_CHECK((q->stat_partials == nullptr && q->stat_acc == nullptr) || tile_is_big(H, W), "conv_first: BN sums need H,W multiples of 16 (got %dx%d)", H, W);
   int tx = (W + 15) / 16, ty = (H + 15) / 16;
   const dim3 g1(conv_first_grid(N, H, W));
+  if (q->stat_acc) HPFG_ACC_CHECK(g1.x, q->stat_shards, "conv_first");
   if ((Cin == 1 || Cin == 3) && hpfg_opt(HPFG_OPT_FIRST_MFMA) != 0) {      // grey-scale (ACDC / LIDC) and RGB (CPS config) inputs (option 0: the VALU form, A/B runs)
     if (Cin == 1) hipLaunchKernelGGL((conv_first_mfma_kernel<1>), g1, dim3(256), 0, (hipStream_t)stream, *q, N, H, W, tx, ty);
     else hipLaunchKernelGGL((conv_first_mfma_kernel<3>), g1, dim3(256), 0, (hipStream_t)stream, *q, N, H, W, tx, ty);

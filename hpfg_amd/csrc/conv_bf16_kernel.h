@@ -772,6 +772,7 @@ int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   }
   if constexpr (C::TAPS == 9) {
     dim3 grid((unsigned)persistent_grid<C, KIND>(a), a.CoutPad / C::BN);
+    if (a.stat_acc) HPFG_ACC_CHECK((long)grid.x * grid.y, a.stat_shards, "conv_fwd");
     if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLAIN) {
       if constexpr (C::TH == 4) {      // (the max-pool-backward epilogue: an instantiation of its own, for the sizes that are not multiples of 16)
         if (a.bwd_stats == 2) {
@@ -791,6 +792,7 @@ int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
     hipLaunchKernelGGL((conv_bf16x3_kernel<C, KIND>), grid, dim3(256), 0, st, a, tx, ty);
   } else {
     dim3 grid(tx * ty, a.N, a.CoutPad / C::BN);
+    if (a.stat_acc) HPFG_ACC_CHECK((long)grid.x * grid.y * grid.z, a.stat_shards, "conv_fwd(1x1)");
     if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLAIN) {
       if (a.bwd_stats) {
         hipLaunchKernelGGL((conv1x1_bf16x3_kernel<C, KIND, 1>), grid, dim3(256), 0, st, a, tx, ty);

@@ -12,6 +12,7 @@ int launch(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
     *rows_only = grid;
     return 0;
   }
+  if (a.stat_acc) HPFG_ACC_CHECK(grid, a.stat_shards, "conv_fwd(thin)");
   hipLaunchKernelGGL((conv_thin_kernel<CI, CO, AK, NW, WGS>), dim3(grid), dim3(64 * NW), 0, st, a, a.W / T, a.H / T);
   return hpfg_launch_status("conv_thin_kernel");
 }

@@ -13,6 +13,7 @@ int launch(const HpfgFusedBwdArgs& a, hipStream_t st, bool grid_only) {
   const int grid = fused_grid<CI, CO, AK, GK, NW, WGS, BMAX>(a);
   if (grid_only) return grid;
   const int tx = a.d.W / T, ty = a.d.H / T;
+  if (a.d.stat_acc) HPFG_ACC_CHECK(grid, a.d.stat_shards, "fused_bwd");
   if constexpr (NODG) {
     hipLaunchKernelGGL((fused_bwd_kernel<CI, CO, AK, GK, false, NW, WGS, PFA, PFPOS, BMAX, true>), dim3(grid), dim3(64 * NW), 0, st, a, tx, ty);
   } else if (a.d.bwd_stats) {
