@@ -452,7 +452,7 @@ def roofline_objects(wl, fams, longest, calib, math):
                       f"({calib:.2f} us); bf16-MFMA passes per product: {passes:g}")
     # HBM bytes per launch of this family: NOT measured by this run -- the figure of the PMC passes (FETCH_SIZE x 2 / WRITE_SIZE, separate
     # rocprofv3 --pmc runs of the same step) committed under profiles/ by tools/family_traffic.py; `traffic_source` names the file
-    for tf in ("r04_family_traffic.json", "r03_family_traffic.json"):
+    for tf in ("r05_family_traffic.json", "r04_family_traffic.json", "r03_family_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
             if tj.get("workload") == wl.name and name in tj.get("families", {}):
