@@ -49,6 +49,10 @@ struct Lds {
   static constexpr int BYTES = A_BYTES + G_BYTES;
 };
 
+// a 32-byte zero piece: an out-of-image (or padding) piece of a SPLIT16 source is LOADED from here -- one 64-bit address select instead of
+// eight value selects per piece, and no clamped coordinates to compute
+static __device__ __attribute__((aligned(32))) const float hpfg_zero_piece[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
 __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* row0, const unsigned char* row1) {
   // row0/row1: this lane's addresses inside the two 4-pixel blocks (see header); result = 8 k-values of this lane's channel
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(row0));
@@ -172,6 +176,21 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
     pg[i].lx = (short)(pix % TW);
     pg[i].lds = (gg >> 4) * 2 * G_PLANE + pix * 32 + (gg & 8) * 2;
   }
+  // SPLIT16 operands (side tensors stored already split, dense at the layer's size): a piece's address is the tile's base plus a
+  // tile-invariant offset, and its staging is a copy -- no producer chain, no clamps, no value selects (VALU per MFMA 5.1 -> 3.9 from the copy
+  // alone, profiles/r05_step_sq_counters.txt; the address arithmetic below is what was left of the loader)
+  constexpr bool SPA = SA == HPFG_KIND_SPLIT, SPG = GK == HPFG_KIND_SPLIT;
+  int relA[SPA ? NA : 1], relG[SPG ? NG : 1];
+  if constexpr (SPA) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) relA[i] = (pa[i].ly * W + pa[i].lx) * p.a0.pstride + (cva ? ca : 0);
+  }
+  if constexpr (SPG) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) relG[i] = (pg[i].ly * W + pg[i].lx) * p.g.pstride + (cvg ? cg : 0);
+  }
+  (void)relA;
+  (void)relG;
   RawPiece<SA> rawA[PREA ? NA : 1];
   RawPiece<GK> rawG[GB];
   f32x4 rawU[NU][2];
@@ -198,6 +217,30 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
   const bool ok = pg[I].real && cvg && gy < H && gx < W;                                              \
   const int gyc = gy > H - 1 ? H - 1 : gy, gxc = gx > W - 1 ? W - 1 : gx, cgc = cvg ? cg : 0;
 
+  // issue of one A / dZ piece of work item (n, ty0, tx0) into RAW: the SPLIT16 fast path or the generic loader
+#define HPFG_WG_A_ISSUE(I, RAW)                                                                                               \
+  if constexpr (SPA) {                                                                                                        \
+    const int gy_ = ty0 + pa[I].ly, gx_ = tx0 + pa[I].lx;                                                                    \
+    const bool ok_ = pa[I].real && cva && (unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W;                         \
+    const float* src_ = ok_ ? p.a0.z + ((n * H + ty0) * W + tx0) * p.a0.pstride + relA[I] : hpfg_zero_piece;                  \
+    (RAW).v[0] = ld4(src_, 0);                                                                                                \
+    (RAW).v[1] = ld4(src_, 4);                                                                                                \
+  } else {                                                                                                                    \
+    HPFG_WG_A_COORD(I)                                                                                                        \
+    issue_piece<SA>(RAW, p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);                                                              \
+  }
+#define HPFG_WG_G_ISSUE(I, RAW)                                                                                               \
+  if constexpr (SPG) {                                                                                                        \
+    const int gy_ = ty0 + pg[I].ly, gx_ = tx0 + pg[I].lx;                                                                    \
+    const bool ok_ = pg[I].real && cvg && gy_ < H && gx_ < W;                                                                 \
+    const float* src_ = ok_ ? p.g.z + ((n * H + ty0) * W + tx0) * p.g.pstride + relG[I] : hpfg_zero_piece;                    \
+    (RAW).v[0] = ld4(src_, 0);                                                                                                \
+    (RAW).v[1] = ld4(src_, 4);                                                                                                \
+  } else {                                                                                                                    \
+    HPFG_WG_G_COORD(I)                                                                                                        \
+    issue_piece<GK>(RAW, p.g, none, cxg, n, gyc, gxc, cgc, ok);                                                               \
+  }
+
   // per-lane transposed-read offsets: group g = lane>>4 covers x = 4g..4g+3; lane 4q+p of the group addresses row (pixel) q, cols 4p..
   const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
   const int xoff = 4 * grp + q;                 // pixel x inside the 16-wide tile row handled by this lane's address
@@ -219,14 +262,12 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
     } else if (PREA) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        HPFG_WG_A_COORD(i)
-        issue_piece<SA>(rawA[PREA ? i : 0], p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);
+        HPFG_WG_A_ISSUE(i, rawA[PREA ? i : 0])
       }
     }
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
-      HPFG_WG_G_COORD(i)
-      issue_piece<GK>(rawG[i], p.g, none, cxg, n, gyc, gxc, cgc, ok);
+      HPFG_WG_G_ISSUE(i, rawG[i])
     }
   }
   HPFG_WTR(2)
@@ -280,15 +321,22 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
     } else {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        HPFG_WG_A_COORD(i)
-        f32x4 v0, v1;
-        if (!PREA) issue_piece<SA>(rawA[0], p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);      // one piece at a time
-        finish_piece<SA>(v0, v1, rawA[PREA ? i : 0], ta, p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);
-        if (pa[i].real) {
-          bf16x8 hi, lo;
-          split_piece<SA>(v0, v1, hi, lo);
-          *reinterpret_cast<bf16x8*>(ldsA + pa[i].lds) = hi;
-          *reinterpret_cast<bf16x8*>(ldsA + pa[i].lds + A_PLANE) = lo;
+        if constexpr (SPA) {          // a copy: the (hi | lo) words as they were loaded
+          if (pa[i].real) {
+            *reinterpret_cast<f32x4*>(ldsA + pa[i].lds) = rawA[PREA ? i : 0].v[0];
+            *reinterpret_cast<f32x4*>(ldsA + pa[i].lds + A_PLANE) = rawA[PREA ? i : 0].v[1];
+          }
+        } else {
+          HPFG_WG_A_COORD(i)
+          f32x4 v0, v1;
+          if (!PREA) issue_piece<SA>(rawA[0], p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);      // one piece at a time
+          finish_piece<SA>(v0, v1, rawA[PREA ? i : 0], ta, p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);
+          if (pa[i].real) {
+            bf16x8 hi, lo;
+            split_piece<SA>(v0, v1, hi, lo);
+            *reinterpret_cast<bf16x8*>(ldsA + pa[i].lds) = hi;
+            *reinterpret_cast<bf16x8*>(ldsA + pa[i].lds + A_PLANE) = lo;
+          }
         }
       }
     }
@@ -311,22 +359,28 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
 #pragma unroll
         for (int i = 0; i < GB; ++i) {
           if (b * GB + i < NG) {
-            HPFG_WG_G_COORD(b * GB + i)
-            issue_piece<GK>(rawG[i], p.g, none, cxg, n, gyc, gxc, cgc, ok);
+            HPFG_WG_G_ISSUE(b * GB + i, rawG[i])
           }
         }
       }
 #pragma unroll
       for (int i = 0; i < GB; ++i) {
         if (b * GB + i < NG) {
-          HPFG_WG_G_COORD(b * GB + i)
-          f32x4 v0, v1;
-          finish_piece<GK>(v0, v1, rawG[i], tg, p.g, none, cxg, n, gyc, gxc, cgc, ok);
-          if (pg[b * GB + i].real) {
-            bf16x8 hi, lo;
-            split_piece<GK>(v0, v1, hi, lo);
-            *reinterpret_cast<bf16x8*>(ldsG + pg[b * GB + i].lds) = hi;
-            *reinterpret_cast<bf16x8*>(ldsG + pg[b * GB + i].lds + G_PLANE) = lo;
+          if constexpr (SPG) {
+            if (pg[b * GB + i].real) {
+              *reinterpret_cast<f32x4*>(ldsG + pg[b * GB + i].lds) = rawG[i].v[0];
+              *reinterpret_cast<f32x4*>(ldsG + pg[b * GB + i].lds + G_PLANE) = rawG[i].v[1];
+            }
+          } else {
+            HPFG_WG_G_COORD(b * GB + i)
+            f32x4 v0, v1;
+            finish_piece<GK>(v0, v1, rawG[i], tg, p.g, none, cxg, n, gyc, gxc, cgc, ok);
+            if (pg[b * GB + i].real) {
+              bf16x8 hi, lo;
+              split_piece<GK>(v0, v1, hi, lo);
+              *reinterpret_cast<bf16x8*>(ldsG + pg[b * GB + i].lds) = hi;
+              *reinterpret_cast<bf16x8*>(ldsG + pg[b * GB + i].lds + G_PLANE) = lo;
+            }
           }
         }
       }
@@ -341,14 +395,12 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
       } else if (PREA) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-          HPFG_WG_A_COORD(i)
-          issue_piece<SA>(rawA[PREA ? i : 0], p.a0, p.a1, cxa, n, gyc, gxc, cac, ok);
+          HPFG_WG_A_ISSUE(i, rawA[PREA ? i : 0])
         }
       }
 #pragma unroll
       for (int i = 0; i < GB; ++i) {
-        HPFG_WG_G_COORD(i)
-        issue_piece<GK>(rawG[i], p.g, none, cxg, n, gyc, gxc, cgc, ok);
+        HPFG_WG_G_ISSUE(i, rawG[i])
       }
     }
     HPFG_WTR(6)
@@ -416,6 +468,8 @@ __global__ __launch_bounds__(NTHR, 2) void wgrad_bf16x3_kernel(HpfgWgradArgs p, 
     }
     HPFG_WTR(8)
   }
+#undef HPFG_WG_A_ISSUE
+#undef HPFG_WG_G_ISSUE
 #undef HPFG_WG_A_COORD
 #undef HPFG_WG_G_COORD
 #undef HPFG_WG_U_ISSUE
