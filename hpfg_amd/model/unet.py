@@ -85,7 +85,9 @@ class _UNetFn(torch.autograd.Function):
         eng = net._acquire_engine(x)
         if getattr(net, "_bn_bump_pending", False):
             eng.bump_counters, net._bn_bump_pending = net._flat_long, False
-        logits = eng.forward(x, train=net.training, track_running=True, seed_step=net._next_seed(), needs_grad=needs_grad)
+        # (an eval-mode forward draws no masks: it must not consume a seed either, or an evaluation between two training iterations would shift
+        # the masks of an eager loop against those of the captured one, whose seed words advance inside the graph)
+        logits = eng.forward(x, train=net.training, track_running=True, seed_step=net._next_seed() if net.training else None, needs_grad=needs_grad)
         ctx.net, ctx.eng, ctx.want_feat = net, eng, want_feat
         out = logits.permute(0, 3, 1, 2)
         if want_feat:

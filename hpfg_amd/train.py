@@ -957,7 +957,7 @@ class GraphedStep:
     def step(self, inputs, cur_itrs, **kw):
         for dst, src in zip(self.static, inputs):
             if dst is not src:
-                dst.copy_(src, non_blocking=True)
+                dst.copy_(src, non_blocking=_async_ok(src))
         self.s.host_scalars(cur_itrs, **kw)
         self.s.sc.push()          # eager H2D copy of this step's scalars from a fresh ring slot, ordered in front of the replay
         for m in self._models():
@@ -1063,6 +1063,13 @@ class ScalarLog:
         return torch.tensor(vals, dtype=torch.float32, device=self.dev)
 
 
+def _async_ok(src: torch.Tensor) -> bool:
+    """May a copy of `src` to the device be queued without waiting for it?  Device tensors and pinned host batches (what a DataLoader with
+    pin_memory hands over): yes.  A pageable host tensor -- e.g. the handful of per-iteration draws a driver makes with numpy -- is a
+    temporary whose memory may be reused before a queued copy has read it: copy it before returning."""
+    return src.is_cuda or src.is_pinned()
+
+
 class _LoopRunner:
     """One training iteration of a driver loop: eager for iteration 1, captured at iteration 2, replayed afterwards (see the section header)."""
 
@@ -1076,7 +1083,7 @@ class _LoopRunner:
             slog.check = dp.check_peer_errors
 
     def _to_dev(self, t):
-        t = t.to(self.dev, non_blocking=True)
+        t = t.to(self.dev, non_blocking=_async_ok(t))
         return t.float() if t.is_floating_point() and t.dtype != torch.float32 else t
 
     def __call__(self, inputs, cur_itrs: int, **kw):
@@ -1209,6 +1216,67 @@ def Mean_Teacher(model, ema_model, label_loader, unlabel_loader, test_loader, ar
                 return slog.losses()
     _check_peers(args, cur_itrs, final=True)
     return slog.losses()
+
+
+def _teacher_student_loop(st, tag, model, ema_model, label_loader, unlabel_loader, test_loader, args, extra_inputs, extra_scalars=None):
+    """The loop the teacher / student drivers besides Mean_Teacher share (2022_02_ISBI_ICT-MedSeg_ACDC.py:93-190,
+    2019_07_MICCAI_Uncertainty_Aware_ACDC.py:109-217): one unlabelled batch per iteration, the labelled loader cycled beside it, the
+    per-iteration random inputs drawn on the host side of the (captured) step in the reference's order, both networks evaluated every
+    ``step_size`` iterations.  Scalars: <tag>/loss, /lr, /consistency_weight, /consistency_loss [+ extra_scalars(st)]."""
+    best, best_ema = _Best(args, "model", "model_save_path"), _Best(args, "ema", "ema_model_save_path")
+    model.train()
+    ema_model.train()
+
+    def emit(row, h):
+        d = {f"{tag}/loss": row[0], f"{tag}/lr": h["lr"], f"{tag}/consistency_weight": h["w"], f"{tag}/consistency_loss": row[5]}
+        d.update({f"{tag}/{k}": v for k, v in h.items() if k not in ("lr", "w")})
+        return d
+
+    def host():
+        h = {"lr": st._lr(st.optimizer), "w": float(st.sc.host[S_COEF_A + 4])}
+        if extra_scalars is not None:
+            h.update(extra_scalars(st))
+        return h
+
+    slog = ScalarLog(torch.device(args.device), 8, emit, _writer(args), _log_every(args))
+    run = _LoopRunner(st, args, slog, ["parts"], host)
+    cur_itrs = 0
+    labels = _cycle(label_loader)
+    max_epoch = args.total_itrs // len(unlabel_loader) + 1
+    for epoch in range(max_epoch):
+        for unlabel_img, _ in unlabel_loader:
+            cur_itrs += 1
+            label_img, target_label = next(labels)
+            run([label_img, target_label, unlabel_img] + list(extra_inputs(unlabel_img)), cur_itrs)
+            _check_peers(args, cur_itrs)
+            if _due(cur_itrs, args, test_loader):
+                best(model, st.optimizer, st.lr_scheduler, test_loader, cur_itrs, "test_model")
+                best_ema(ema_model, st.optimizer, st.lr_scheduler, test_loader, cur_itrs, "test_ema_model")
+            if cur_itrs > args.total_itrs:
+                _check_peers(args, cur_itrs, final=True)
+                return slog.losses()
+    _check_peers(args, cur_itrs, final=True)
+    return slog.losses()
+
+
+def ICT_MedSeg(model, ema_model, label_loader, unlabel_loader, test_loader, args):
+    """2022_02_ISBI_ICT-MedSeg_ACDC.py:65-190: the mix factors are numpy Beta draws per iteration (:112) -- an input of the step."""
+    st = ICTStep(model, ema_model, args, getattr(args, "dp", None))
+    return _teacher_student_loop(st, "ICT_MedSeg", model, ema_model, label_loader, unlabel_loader, test_loader, args,
+                                 lambda u: [st.draw_mix_factors(u.shape[0])])
+
+
+def Uncertainty_Aware(model, ema_model, label_loader, unlabel_loader, test_loader, args):
+    """2019_07_MICCAI_Uncertainty_Aware_ACDC.py:82-217: the noise fields of the teacher passes are device draws per iteration (:130, :142),
+    in the reference's order -- inputs of the step (the T / 2 doubled-batch fields travel stacked)."""
+    st = UAMTStep(model, ema_model, args, getattr(args, "dp", None))
+
+    def noise(u):
+        n0, rest = st.draw_noise(u.to(args.device).float())
+        return [n0, torch.stack(rest)]
+
+    return _teacher_student_loop(st, "Uncertainty_Aware", model, ema_model, label_loader, unlabel_loader, test_loader, args, noise,
+                                 lambda s: {"threshold": float(s.sc.host[S_THRESH])})
 
 
 def CPS(model1, model2, label_loader, unlabel_loader, test_loader, args, step_cls=None):

@@ -177,3 +177,48 @@ def test_hpfg_loop_scalars(tmp_path):
         by.setdefault(i, {})[n] = v
     for i, d in by.items():
         assert abs(d["HPFG/loss"] - d["HPFG/loss_sup"] - d["HPFG/loss_semi"]) < 1e-5 and d["HPFG/loss_sup"] > 0
+
+
+def _ts_run(tmp, driver, graph, writer=None, seed_np=7, **kw):
+    """One run of a teacher / student driver with its per-iteration draws seeded (numpy Beta factors for ICT, torch device noise for UAMT)."""
+    import numpy as np
+    from hpfg_amd.model import reset_dropout_streams
+    reset_dropout_streams()
+    a = _args(tmp, total_itrs=4, step_size=2, hipgraph=graph, log_every=3, ict_alpha=0.2, **kw)
+    if writer is not None:
+        a.writer = writer
+    torch.manual_seed(1337)
+    np.random.seed(seed_np)
+    m = build_model(a).to(DEV)
+    e = _teacher(m)
+    lab, unl, test = build_loader(a)
+    torch.cuda.manual_seed(99)          # the UAMT noise fields are draws of the device generator
+    log = driver(m, e, lab, unl, test, a)
+    torch.cuda.synchronize()
+    return a, log.cpu(), m, e
+
+
+@pytest.mark.parametrize("name", ["ICT_MedSeg", "Uncertainty_Aware"])
+def test_teacher_student_driver_loops(tmp_path, name):
+    """2022_02_ISBI_ICT-MedSeg_ACDC.py:65-190 / 2019_07_MICCAI_Uncertainty_Aware_ACDC.py:82-217 with the reference's function names and
+    signature: iteration law, both networks evaluated and checkpointed at step_size, the reference's scalar names, and the captured loop
+    (iteration 2 on) equal to the eager one on the same draws."""
+    import hpfg_amd.train as T
+    driver = getattr(T, name)
+    w = _Writer()
+    a, lg, m, e = _ts_run(tmp_path / "g", driver, True, w)
+    assert lg.shape == (a.total_itrs + 1,) and torch.isfinite(lg).all()
+    _check_ckpt(a.model_save_path, m)
+    _check_ckpt(a.ema_model_save_path, e)
+    assert m.training and e.training
+    names = {n for n, _, _ in w.rows}
+    want = {f"{name}/loss", f"{name}/lr", f"{name}/consistency_weight", f"{name}/consistency_loss"}
+    if name == "Uncertainty_Aware":
+        want.add(f"{name}/threshold")          # 2019_07...py:177
+    assert names == want, names
+    assert sorted({i for _, _, i in w.rows}) == [1, 2, 3, 4, 5]
+    cons = [v for n, v, _ in w.rows if n.endswith("consistency_loss")]
+    assert all(v >= 0 for v in cons) and (max(cons) > 0 or name == "Uncertainty_Aware")          # (UAMT: every pixel is above the entropy threshold at first)
+    _, le, m2, e2 = _ts_run(tmp_path / "e", driver, False)
+    assert torch.allclose(lg, le, rtol=0, atol=1e-6), (lg, le)
+    assert torch.allclose(m.flat_params, m2.flat_params, rtol=0, atol=1e-6) and torch.allclose(e.flat_params, e2.flat_params, rtol=0, atol=1e-6)
