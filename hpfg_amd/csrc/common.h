@@ -383,6 +383,28 @@ __device__ static inline f32x4 kind_load4(const HpfgAct& a0, const ActCtx& c0, c
   return act_load4_mode<HPFG_ACT_UP2X>(a1, c1, n, y, x, c - a0.C);
 }
 
+// HPFG_NO_PK_F32 (kernel attribute): no packed fp32 VALU instructions in this kernel.  Round 5, first_wgrad_kernel: the broadcast products
+// `acc[k] += tap * dz` (f32x4 by a scalar that sits in the HIGH dword of a register pair) compile to `v_pk_fma_f32 ... op_sel:[0,1,0]`, and on
+// gfx950 / ROCm 7.2 the LOW half of such an instruction intermittently took the pair's low dword instead -- only with another stream's kernels
+// on the chip, never alone: the gradient of the first conv moved by 1e-6 .. 1e-5 from run to run (tests/test_gpu_fullsize.py; the same source
+// with volatile tap reads or per-component fmaf -- no cross-half op_sel in the ISA -- is bit-stable over hundreds of runs, explicit
+// s_waitcnt lgkmcnt(0) in front of the products is not: profiles/r05_chain_and_prepass.txt).  Every kernel whose ISA contains that operand
+// form is cured -- first_wgrad and upsample_bwd keep packed math and launder their broadcast scalars (hpfg_own_vgpr below: the attribute cost
+// sup +4.3 %, mt +2.4 %), conv_first, adamw and the fp32 linear weight gradient carry the attribute; tools/pk_opsel_scan.sh lists offenders.
+// hpfg_own_vgpr(x): the cheaper cure where it applies -- an empty asm that makes x a 32-bit value of its own, so a packed instruction broadcasts it
+// from the LOW dword of a pair (op_sel_hi form) instead of selecting the high dword of the pair an LDS read returned it in.
+__device__ __forceinline__ float hpfg_own_vgpr(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+#if defined(HPFG_NO_PK_F32)
+// (an A/B build defines it empty on the command line)
+#elif defined(__HIP_DEVICE_COMPILE__)
+#define HPFG_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define HPFG_NO_PK_F32
+#endif
+
 static inline int hpfg_kind_of(const HpfgAct& a0, const HpfgAct& a1) {
   if (a1.mode == HPFG_ACT_UP2X && a0.mode == HPFG_ACT_BNACT) return HPFG_KIND_CAT;
   if (a1.mode != HPFG_ACT_NONE) return -1;

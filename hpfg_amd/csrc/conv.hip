@@ -33,7 +33,7 @@ inline bool tile_is_big(int H, int W) { return (H % 16 == 0) && (W % 16 == 0); }
 // Persistent: a workgroup walks tiles w = blockIdx.x, + gridDim.x, ...; the BatchNorm partial sums stay in registers across its
 // tiles and are reduced once (the per-tile wave butterfly of 32 values used to cost more than the 144 FMAs of the convolution),
 // so the layer also hands only gridDim.x rows to the finalize instead of one per tile.
-__global__ __launch_bounds__(256) void conv_first_kernel(HpfgFirstConvArgs q, int N, int H, int W, int Cin, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) HPFG_NO_PK_F32 void conv_first_kernel(HpfgFirstConvArgs q, int N, int H, int W, int Cin, int tiles_x, int tiles_y) {
   constexpr int T = 16, TP = T + 2, CO = 16;
   const HpfgAct& x = q.x;
   const float* __restrict__ w = q.w_oihw;

@@ -15,14 +15,14 @@
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 256, XR_W = 514;
 
 template <int CIN>
 __global__ __launch_bounds__(NT) void first_wgrad_kernel(HpfgAct g, HpfgAct x, float* __restrict__ slab, int N, int H, int W) {
   constexpr int KT = 9 * CIN;
   __shared__ float tab[5][16];                       // scale, shift, k1, k2, k3 of the 16 output channels (table rows, or derived from the sums)
   __shared__ float red[NT / 64][KT][16];
-  extern __shared__ float xrows[];                   // the input rows y - 1, y, y + 1 of the current work item, zero padded: [CIN][3][W + 2]
+  __shared__ float xrows[CIN * 3 * XR_W];            // the input rows y - 1, y, y + 1 of the current work item, zero padded: [CIN][3][W + 2], W <= XR_W - 2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   hpfg_dz_rows_to_lds(g, &tab[0][0], 16, 16, tid, NT);
   __syncthreads();
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NT) void first_wgrad_kernel(HpfgAct g, HpfgAct x, f
 #pragma unroll
         for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
-          for (int t = 0; t < 9; ++t) acc[ci * 9 + t] += xr[(ci * 3 + t / 3) * WP + xx + t % 3] * dz;
+          for (int t = 0; t < 9; ++t) acc[ci * 9 + t] += hpfg_own_vgpr(xr[(ci * 3 + t / 3) * WP + xx + t % 3]) * dz;      // (common.h: HPFG_NO_PK_F32)
       }
     }
   }
@@ -138,8 +138,7 @@ int hpfg_first_wgrad_grid(int N, int H, int W) {
 int hpfg_first_wgrad_launch(const HpfgAct& g, const HpfgAct& x, float* slab, int Cin, int N, int H, int W, hipStream_t st) {
   if (Cin != 1) return -2;
   const int grid = hpfg_first_wgrad_grid(N, H, W);
-  const size_t dyn = (size_t)Cin * 3 * (W + 2) * sizeof(float);
-  if (dyn > 48 * 1024) return -2;
-  hipLaunchKernelGGL((first_wgrad_kernel<1>), dim3(grid), dim3(NT), dyn, st, g, x, slab, N, H, W);
+  if (W + 2 > XR_W) return -2;
+  hipLaunchKernelGGL((first_wgrad_kernel<1>), dim3(grid), dim3(NT), 0, st, g, x, slab, N, H, W);
   return hpfg_launch_status("first_wgrad_kernel");
 }

@@ -36,9 +36,9 @@ int dispatch(const HpfgFusedBwdArgs& a, hipStream_t st, bool grid_only) {
   if (ci == CI && co == CO && ak == AK && gk == GK) return launch<CI, CO, AK, GK, NW, WGS, PFA, PFPOS>(a, st, grid_only);
   if (!a.d.out) {      // weight gradient only: the first layer (network input, <= 4 channels, read through its strides)
     if (ci == 1 && co == 1 && ak == HPFG_KIND_PLAIN && gk == HPFG_KIND_DZ) {
-      // 1-channel inputs of at least 64 pixels a row: the streaming kernel (first_wgrad.hip); option HPFG_OPT_FIRST_WGRAD = 0 keeps the tile kernel
+      // 1-channel inputs of 64 .. 512 pixels a row: the streaming kernel (first_wgrad.hip); option HPFG_OPT_FIRST_WGRAD = 0 keeps the tile kernel
       // (tests, A/B runs).  RGB inputs (27 taps: 108 accumulators) measured slower there than on the tile kernel and stay on it.
-      if (a.Cin == 1 && a.d.W >= 64 && a.Cout == 16 && a.xa0.mode == HPFG_ACT_STRIDED && a.d.a0.pstride % 4 == 0 && a.d.a0.aux_pstride % 4 == 0 &&
+      if (a.Cin == 1 && a.d.W >= 64 && a.d.W <= 512 && a.Cout == 16 && a.xa0.mode == HPFG_ACT_STRIDED && a.d.a0.pstride % 4 == 0 && a.d.a0.aux_pstride % 4 == 0 &&
           hpfg_opt(HPFG_OPT_FIRST_WGRAD) != 0) {
         if (grid_only) return hpfg_first_wgrad_grid(a.d.N, a.d.H, a.d.W);
         return hpfg_first_wgrad_launch(a.d.a0, a.xa0, a.slab, a.Cin, a.d.N, a.d.H, a.d.W, st);

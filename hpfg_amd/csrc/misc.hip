@@ -226,9 +226,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 #pragma unroll
     for (int k = 0; k < UPB_TAPS; ++k) {
       iy[k] = t_idx[yl][k];
-      wy[k] = t_w[yl][k];
+      wy[k] = hpfg_own_vgpr(t_w[yl][k]);              // (broadcast factors of f32x4 products: common.h, HPFG_NO_PK_F32)
       ix[k] = t_idx[Hl + xl][k] * dup_ps;
-      wx[k] = t_w[Hl + xl][k];
+      wx[k] = hpfg_own_vgpr(t_w[Hl + xl][k]);
     }
     f32x4 v[UPB_TAPS][UPB_TAPS];
 #pragma unroll
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ p, con
 
 // torch.optim.AdamW (decoupled weight decay, bias-corrected moments) over flat buffers; *step_dev holds the number of steps already taken
 // (a one-thread kernel advances it afterwards, so a captured graph counts by itself)
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+__global__ __launch_bounds__(256) HPFG_NO_PK_F32 void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                     long n, const float* __restrict__ lr_dev, const float* __restrict__ step_dev, float b1, float b2,
                                                     float eps, float wd, float gscale) {
   const float lr = *lr_dev, t = *step_dev + 1.f;

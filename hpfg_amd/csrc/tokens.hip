@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_apply_kernel(const float* __re
 // over blockIdx.y, 64 x 64 output tile per blockIdx.x, 4 x 4 outputs per thread from LDS-staged 64-row panels; the per-split partial
 // matrices are summed in a fixed order by col_reduce_kernel.
 template <int TN, int TK>
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, long R,
+__global__ __launch_bounds__(256) HPFG_NO_PK_F32 void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, long R,
                                                            int N, int K, int rows_per_split) {
   constexpr int MN = TN / 16, MK = TK / 16;          // outputs per thread: MN x MK (16 x 16 threads)
   __shared__ float sa[64][TN + 4], sb[64][TK + 4];
