@@ -7,6 +7,6 @@ out=${TMPDIR:-/tmp}/pk_scan_$$; mkdir -p $out
 ls *.hip | xargs -P 6 -I{} sh -c "hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only {} -o $out/{}.s 2>/dev/null"
 echo "# kernels with v_pk_*_f32 ... op_sel cross-half operands:"
 for f in $out/*.s; do
-  awk -v F="$(basename $f .s)" '/^_Z[A-Za-z0-9_]*:/ {name=$1} /v_pk_[a-z]*_f32.*op_sel:\[[01],1|v_pk_[a-z]*_f32.*op_sel:\[1/ {a[name]++} END {for (n in a) print F, a[n], n}' $f
+  awk -v F="$(basename $f .s)" '/^_Z[A-Za-z0-9_]*:/ {name=$1} /v_pk_[a-z]*_f32.*op_sel:\[[01,]*1/ {a[name]++} END {for (n in a) print F, a[n], n}' $f
 done | while read f c n; do echo "$f $c $(echo $n | tr -d ':' | c++filt | cut -c1-120)"; done
 rm -rf $out
