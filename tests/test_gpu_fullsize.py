@@ -165,3 +165,50 @@ def test_every_gradient_is_reproducible_over_many_runs_of_the_overlapped_step():
         assert torch.equal(out[0], ref_out[0])
         bad = [k for k in g if not torch.equal(g[k], ref[k])]
         assert not bad, bad
+
+
+def _hpfg_grads():
+    from hpfg_amd.model import reset_dropout_streams
+    a = _cfg("hpfg_unet_plus_30k_224x224_ACDC.yaml")
+    torch.manual_seed(a.seed)
+    reset_dropout_streams()
+    m1, m2 = build_model(a.model1).to(DEV), build_model(a.model2).to(DEV)
+    ema = _teacher(m2)
+    m1.train()
+    m2.train()
+    st = HPFGStep(m1, m2, ema, a)
+    xl, yl = synth_batch(5, 16, 224, 224, 1, 4, 32)
+    xl1, yl1 = synth_batch(6, 16, 224, 224, 1, 4, 32)
+    xu, _ = synth_batch(7, 16, 224, 224, 1, 4, 32)
+    cm = st.make_cutmix_mask(16, (224, 224), rng=np.random.RandomState(1))
+    r = st.step(xl.to(DEV), yl.to(DEV), xl1.to(DEV), yl1.to(DEV), xu.to(DEV), cm.to(DEV), 1500)
+    torch.cuda.synchronize()
+    return float(r["loss"]), m1.flat_grads.clone(), m2.flat_grads.clone(), m1.flat_params.clone(), ema.flat_params.clone()
+
+
+def _cps_grads():
+    from hpfg_amd.model import reset_dropout_streams
+    a = _cfg("cps_unet_30k_96x96_LIDC.yaml")
+    torch.manual_seed(a.seed)
+    reset_dropout_streams()
+    m1, m2 = build_model(a.model1).to(DEV), build_model(a.model2).to(DEV)
+    m1.train()
+    m2.train()
+    st = CPSStep(m1, m2, a)
+    xl, yl = synth_batch(8, 32, 96, 96, 3, 2, 12)
+    xu, _ = synth_batch(9, 32, 96, 96, 3, 2, 12)
+    r = st.step(xl.to(DEV), yl.to(DEV), xu.to(DEV), 1, cons_w=0.05)
+    torch.cuda.synchronize()
+    return float(r["loss"]), m1.flat_grads.clone(), m2.flat_grads.clone(), m1.flat_params.clone(), m2.flat_params.clone()
+
+
+@pytest.mark.parametrize("law", ["hpfg", "cps"])
+def test_three_stream_and_two_network_steps_are_reproducible_at_full_size(law):
+    """BASELINE configs 3 (HPFG, 16 + 16 x 224^2, U-Net+ x 3, three streams) and 4 (CPS, 32 + 32 x 96^2 x 3 channels, two trainable networks):
+    five constructions + one step each, loss, every gradient and the updated parameters equal to the first run's bit for bit."""
+    fn = _hpfg_grads if law == "hpfg" else _cps_grads
+    ref = fn()
+    for _ in range(4):
+        cur = fn()
+        assert cur[0] == ref[0]
+        assert all(torch.equal(a, b) for a, b in zip(cur[1:], ref[1:]))
