@@ -14,11 +14,11 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpfg_hip.so")
 
 # enums from include/hpfg_hip.h
 BN_MEAN, BN_RSTD, BN_SCALE, BN_SHIFT, BN_K1, BN_K2, BN_K3, BN_SPARE, BN_ROWS = range(9)
-ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ, ACT_SPLIT16 = range(8)
+ACT_NONE, ACT_PLAIN, ACT_STRIDED, ACT_BNACT, ACT_BNACT_POOL, ACT_UP2X, ACT_DZ, ACT_SPLIT16, ACT_UPBWD = range(9)
 OPT_CONV_THIN, OPT_FIRST_MFMA, OPT_FIRST_WGRAD, OPT_NARROW_DEEP = 0, 1, 2, 3          # hpfg_set_option
 LOSS_NSUM = 32
 ACC_MAX_SHARDS = 8          # HPFG_ACC_MAX_SHARDS: a BatchNorm sum accumulator is long long [shards][2][C][2]
-VERSION = 131
+VERSION = 132
 MATH_F32, MATH_BF16X3 = 0, 1
 
 
@@ -40,7 +40,7 @@ class ConvArgs(C.Structure):
                 ("stat_partials", C.c_void_p), ("out_pstride", C.c_int32), ("Cout", C.c_int32), ("CoutPad", C.c_int32),
                 ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("taps", C.c_int32), ("math", C.c_int32),
                 ("bwd_stats", C.c_int32), ("bwd_of", Act), ("out2", C.c_void_p), ("out_split", C.c_int32), ("out2_pstride", C.c_int32),
-                ("stat_acc", C.c_void_p), ("stat_shards", C.c_int32), ("reserved2", C.c_int32), ("stage_out", C.c_void_p)]
+                ("stat_acc", C.c_void_p), ("stat_shards", C.c_int32), ("reserved2", C.c_int32), ("stage_out", C.c_void_p), ("side_sums", C.c_void_p)]
 
 
 class WgradArgs(C.Structure):

@@ -360,7 +360,7 @@ __device__ static inline f32x4 cat_load4(const HpfgAct& a0, const ActCtx& c0, co
 
 
 // ---- single-mode loaders (compile-time mode): keep the conv kernels' staging code small and register-light -------------
-enum { HPFG_KIND_PLAIN = 0, HPFG_KIND_BNACT = 1, HPFG_KIND_POOL = 2, HPFG_KIND_CAT = 3, HPFG_KIND_DZ = 4, HPFG_KIND_SPLIT = 5 };      // (SPLIT: HPFG_ACT_SPLIT16, weight gradient only)
+enum { HPFG_KIND_PLAIN = 0, HPFG_KIND_BNACT = 1, HPFG_KIND_POOL = 2, HPFG_KIND_CAT = 3, HPFG_KIND_DZ = 4, HPFG_KIND_SPLIT = 5, HPFG_KIND_UPB = 6 };      // (SPLIT: HPFG_ACT_SPLIT16, weight gradient only; UPB: HPFG_ACT_UPBWD, 1x1 dgrad only)
 
 template <int MODE>
 __device__ static inline f32x4 act_load4_mode(const HpfgAct& s, const ActCtx& cx, int n, int y, int x, int c) {
@@ -382,6 +382,31 @@ __device__ static inline f32x4 kind_load4(const HpfgAct& a0, const ActCtx& c0, c
   if (c < a0.C) return act_load4_mode<HPFG_ACT_BNACT>(a0, c0, n, y, x, c);
   return act_load4_mode<HPFG_ACT_UP2X>(a1, c1, n, y, x, c - a0.C);
 }
+
+// transpose of the align_corners=True bilinear x2 (nn.Upsample, unet.py:51): the outputs o of a 2L-long axis that read source index `lo`, and
+// with which weight -- at most 5 (on average 4); gather form of the backward pass (hpfg_upsample2x_bwd, and the HPFG_ACT_UPBWD loader)
+__device__ inline void hpfg_up_taps(int lo, int L, int* idx, float* wgt, int& cnt) {
+  const int O = 2 * L;
+  const float r = O > 1 ? (float)(L - 1) / (float)(O - 1) : 0.f;
+  cnt = 0;
+  int b = 2 * lo - 2, e = 2 * lo + 4;
+  if (b < 0) b = 0;
+  if (e > O - 1) e = O - 1;
+  for (int o = b; o <= e; ++o) {
+    float f = r * (float)o;
+    int i0 = (int)f;
+    int i1 = i0 + (i0 < L - 1 ? 1 : 0);
+    float w1 = f - (float)i0, w0 = 1.f - w1, w = 0.f;
+    if (i0 == lo) w += w0;
+    if (i1 == lo) w += w1;
+    if ((i0 == lo || i1 == lo) && cnt < 8) {
+      idx[cnt] = o;
+      wgt[cnt] = w;
+      ++cnt;
+    }
+  }
+}
+constexpr int HPFG_UPB_TAPS = 5;
 
 // HPFG_NO_PK_F32 (kernel attribute): no packed fp32 VALU instructions in this kernel.  Round 5, first_wgrad_kernel: the broadcast products
 // `acc[k] += tap * dz` (f32x4 by a scalar that sits in the HIGH dword of a register pair) compile to `v_pk_fma_f32 ... op_sel:[0,1,0]`, and on
@@ -414,6 +439,7 @@ static inline int hpfg_kind_of(const HpfgAct& a0, const HpfgAct& a1) {
     case HPFG_ACT_BNACT_POOL: return HPFG_KIND_POOL;
     case HPFG_ACT_DZ: return HPFG_KIND_DZ;
     case HPFG_ACT_SPLIT16: return HPFG_KIND_SPLIT;
+    case HPFG_ACT_UPBWD: return HPFG_KIND_UPB;
     default: return -1;
   }
 }

@@ -289,14 +289,19 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
   HPFG_ARG_CHECK((a->math & 0xff) != HPFG_MATH_BF16X3 || !(a->a0.mode == HPFG_ACT_BNACT || a->a0.mode == HPFG_ACT_BNACT_POOL || a->a0.mode == HPFG_ACT_DZ) ||
                      a->a0.C <= 256,
                  "conv_fwd(bf16x3): a BatchNorm'd source has at most 256 channels (got %d)", a->a0.C);
-  HPFG_ARG_CHECK(!a->stage_out || ((a->math & 0xff) == HPFG_MATH_BF16X3 && a->taps == 9 && hpfg_kind_of(a->a0, a->a1) > HPFG_KIND_PLAIN &&
+  const bool upb = a->a0.mode == HPFG_ACT_UPBWD;
+  HPFG_ARG_CHECK(!upb || ((a->math & 0xff) == HPFG_MATH_BF16X3 && a->taps == 1 && a->a1.mode == HPFG_ACT_NONE && a->a0.C % 8 == 0 && a->a0.pstride % 4 == 0 &&
+                          a->a0.Hs == a->H && a->a0.Ws == a->W && a->H <= 16383 && a->W <= 16383 && (long)a->N * 4 * a->H * a->W * a->a0.pstride < (1L << 31)),
+                 "conv_fwd: an UPBWD source belongs to the 1x1 bf16x3 dgrad (channels a multiple of 8, pixel stride of 4, Hs x Ws == H x W)");
+  HPFG_ARG_CHECK(!a->side_sums || upb, "conv_fwd: side_sums goes with an UPBWD source");
+  HPFG_ARG_CHECK(!a->stage_out || upb || ((a->math & 0xff) == HPFG_MATH_BF16X3 && a->taps == 9 && hpfg_kind_of(a->a0, a->a1) > HPFG_KIND_PLAIN &&
                                     (a->a0.C + a->a1.C) % 8 == 0 && (a->H % 16 || a->W % 16)),
                  "conv_fwd: stage_out is a feature of the 3x3 bf16x3 kernels (non-PLAIN source, channels a multiple of 8, H or W not a multiple of 16)");
   hipStream_t st = (hipStream_t)stream;
   if (a->bwd_stats) {
     const int kind = hpfg_kind_of(a->a0, a->a1);
-    HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && (kind == HPFG_KIND_DZ || kind == HPFG_KIND_PLAIN),
-                   "conv_fwd: bwd_stats is a dgrad feature of the bf16x3 kernels (DZ or PLAIN source)");
+    HPFG_ARG_CHECK((a->math & 0xff) == HPFG_MATH_BF16X3 && (kind == HPFG_KIND_DZ || kind == HPFG_KIND_PLAIN || (kind == HPFG_KIND_UPB && a->bwd_stats == 1)),
+                   "conv_fwd: bwd_stats is a dgrad feature of the bf16x3 kernels (DZ, PLAIN or UPBWD source)");
     HPFG_ARG_CHECK((a->stat_partials || a->stat_acc) && a->bwd_of.z && a->bwd_of.bn && !a->bias,
                    "conv_fwd: bwd_stats needs stat_partials or stat_acc, bwd_of.z / .bn and no bias");
     const int up = a->bwd_stats == 2 ? 2 : 1;      // 2: `out` is the gradient w.r.t. MaxPool2d(2) of bwd_of's activation (bwd_of at twice the size)
@@ -318,6 +323,7 @@ static int conv_fwd_impl(const HpfgConvArgs* a, void* stream, int* rows_only) {
       case HPFG_KIND_POOL: return hpfg_conv16_launch_pool(*a, st, rows_only);
       case HPFG_KIND_CAT: return hpfg_conv16_launch_cat(*a, st, rows_only);
       case HPFG_KIND_DZ: return hpfg_conv16_launch_dz(*a, st, rows_only);
+      case HPFG_KIND_UPB: return hpfg_conv16_launch_upb(*a, st, rows_only);
       default: break;
     }
     hpfg_set_error("conv_fwd(bf16x3): unsupported source combination (a0.mode=%d, a1.mode=%d)", a->a0.mode, a->a1.mode);

@@ -671,6 +671,17 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int
   constexpr bool TABK = tab_in_lds<KIND>();
   __shared__ __attribute__((aligned(16))) float ldsBN[TABK ? tab_rows<KIND>() * HPFG_BN_CMAX : 4];
   (void)ldsBN;
+  // HPFG_ACT_UPBWD source (the dgrad of a decoder block's 1x1 conv, unet.py:50-51): the staged value of a pixel is the transposed bilinear
+  // interpolation of the gradient w.r.t. the upsampled tensor -- hpfg_upsample2x_bwd's gather (same taps, same order of additions), made
+  // while the tile is staged instead of by a launch of its own in front of this one.  Output-channel slice 0 also stores the gathered
+  // tensor (p.stage_out: the dZ of the 1x1 conv's weight gradient) and its per-workgroup channel sums (p.side_sums: the bias gradient).
+  constexpr bool UPB = KIND == HPFG_KIND_UPB;
+  __shared__ short upI[UPB ? C::TH + C::TW : 1][HPFG_UPB_TAPS];
+  __shared__ float upW[UPB ? C::TH + C::TW : 1][HPFG_UPB_TAPS];
+  __shared__ __attribute__((aligned(16))) float upS[UPB ? 256 * 8 : 4];
+  (void)upI;
+  (void)upW;
+  (void)upS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % C::WM, wn = wave / C::WM;
   const int tile = blockIdx.x, n = blockIdx.y, cb = blockIdx.z;
@@ -700,12 +711,84 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int
     fill_tables_lds<KIND>(p.a0, ldsBN, tid, 256);
     __syncthreads();
   }
+  if constexpr (UPB) {      // tap lists of this tile's rows and columns: HPFG_UPB_TAPS entries each, unused ones repeat the last index with weight 0
+    if (tid < C::TH + C::TW) {
+      int idx[8], cnt;
+      float wgt[8];
+      const bool isrow = tid < C::TH;
+      const int L = isrow ? H : W;
+      const int lo = clampi(isrow ? ty0 + tid : tx0 + tid - C::TH, 0, L - 1);
+      hpfg_up_taps(lo, L, idx, wgt, cnt);
+      cnt = cnt > HPFG_UPB_TAPS ? HPFG_UPB_TAPS : cnt;
+      for (int k = 0; k < HPFG_UPB_TAPS; ++k) {
+        upI[tid][k] = (short)(k < cnt ? idx[k] : idx[cnt - 1]);
+        upW[tid][k] = k < cnt ? wgt[k] : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+  const bool side = UPB && cb == 0;      // (workgroup-uniform)
+  const int wg_row = n * (tiles_x * tiles_y) + tile;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int c0 = ch * C::KC + g8;
     const bool chv = c0 < cin_total;
     if constexpr (TABK) load_tables_lds<KIND>(tab, ldsBN, p.a0, chv ? c0 : 0);
-    else load_tables<KIND>(tab, p.a0, c0, chv);
+    else if constexpr (!UPB) load_tables<KIND>(tab, p.a0, c0, chv);
     __syncthreads();
+    if constexpr (UPB) {
+      const int c0c = chv ? c0 : 0, ps = p.a0.pstride, Wo = 2 * W;
+      const float* src = p.a0.z + (long)n * (2 * H) * Wo * ps + c0c;
+      f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = cs0;
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) {
+        const Piece q = make_piece<C>(tid, i);
+        if (!q.ok) continue;
+        const int gy = ty0 + q.ly, gx = tx0 + q.lx;
+        const bool ok = chv && gy < H && gx < W;
+        int ix[HPFG_UPB_TAPS];
+        float wx[HPFG_UPB_TAPS];
+#pragma unroll
+        for (int b = 0; b < HPFG_UPB_TAPS; ++b) {
+          ix[b] = upI[C::TH + q.lx][b] * ps;
+          wx[b] = hpfg_own_vgpr(upW[C::TH + q.lx][b]);
+        }
+        f32x4 v[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {          // the two channel quads of the piece: 25 loads in flight each
+          f32x4 t[HPFG_UPB_TAPS][HPFG_UPB_TAPS];
+#pragma unroll
+          for (int a = 0; a < HPFG_UPB_TAPS; ++a) {
+            const float* row = src + (long)upI[q.ly][a] * Wo * ps + 4 * hq;
+#pragma unroll
+            for (int b = 0; b < HPFG_UPB_TAPS; ++b) t[a][b] = *reinterpret_cast<const f32x4*>(row + ix[b]);
+          }
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int a = 0; a < HPFG_UPB_TAPS; ++a) {      // separable, in hpfg_upsample2x_bwd's order: a row's horizontal taps, then its vertical weight
+            f32x4 h = wx[0] * t[a][0];
+#pragma unroll
+            for (int b = 1; b < HPFG_UPB_TAPS; ++b) h += wx[b] * t[a][b];
+            acc += hpfg_own_vgpr(upW[q.ly][a]) * h;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[hq][j] = ok ? acc[j] : 0.f;
+        }
+        store_piece<C, HPFG_KIND_PLAIN>(lds, q, v[0], v[1]);
+        if (side && ok) {
+          if (p.stage_out) {
+            float* d = p.stage_out + ((long)(n * H + gy) * W + gx) * p.a0.C + c0c;
+            *reinterpret_cast<f32x4*>(d) = v[0];
+            *reinterpret_cast<f32x4*>(d + 4) = v[1];
+          }
+          cs0 += v[0];
+          cs1 += v[1];
+        }
+      }
+      if (side && p.side_sums) {
+        *reinterpret_cast<f32x4*>(upS + tid * 8) = cs0;
+        *reinterpret_cast<f32x4*>(upS + tid * 8 + 4) = cs1;
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < C::NLD; ++i) {
       const Piece q = make_piece<C>(tid, i);
@@ -718,9 +801,19 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_kernel(HpfgConvArgs p, int
       finish_piece<KIND>(v0, v1, raw, tab, p.a0, p.a1, cx0, n, gyc, gxc, c0c, ok);
       store_piece<C, KIND>(lds, q, v0, v1);
     }
+    }
     bf16x8 bh[C::NI], bl[C::NI];
     load_b<C>(bh, bl, wpk, ch, ntn, nt0, lane);
     __syncthreads();
+    if constexpr (UPB) {
+      if (side && p.side_sums && tid < C::KC) {      // channel tid of the chunk: the threads of its 8-channel group, in a fixed order
+        const int g = tid >> 3, j = tid & 7;
+        float tsum = 0.f;
+        for (int k = g; k < 256; k += C::NG) tsum += upS[k * 8 + j];
+        const int cch = ch * C::KC + tid;
+        if (cch < p.a0.C) p.side_sums[(long)wg_row * p.a0.C + cch] = tsum;
+      }
+    }
 #pragma unroll
     for (int m = 0; m < C::MI; ++m) {
       const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds + aoff[m]);
@@ -793,7 +886,7 @@ int launch_cfg(const HpfgConvArgs& a, hipStream_t st, int* rows_only) {
   } else {
     dim3 grid(tx * ty, a.N, a.CoutPad / C::BN);
     if (a.stat_acc) HPFG_ACC_CHECK((long)grid.x * grid.y * grid.z, a.stat_shards, "conv_fwd(1x1)");
-    if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLAIN) {
+    if constexpr (KIND == HPFG_KIND_DZ || KIND == HPFG_KIND_PLAIN || KIND == HPFG_KIND_UPB) {
       if (a.bwd_stats) {
         hipLaunchKernelGGL((conv1x1_bf16x3_kernel<C, KIND, 1>), grid, dim3(256), 0, st, a, tx, ty);
         return hpfg_launch_status("conv1x1_bf16x3_kernel<bwd stats>");
@@ -856,3 +949,4 @@ int hpfg_conv16_launch_bnact(const HpfgConvArgs& a, hipStream_t st, int* rows_on
 int hpfg_conv16_launch_pool(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
 int hpfg_conv16_launch_cat(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
 int hpfg_conv16_launch_dz(const HpfgConvArgs& a, hipStream_t st, int* rows_only);
+int hpfg_conv16_launch_upb(const HpfgConvArgs& a, hipStream_t st, int* rows_only);

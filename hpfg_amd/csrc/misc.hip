@@ -155,36 +155,14 @@ __global__ __launch_bounds__(256) void pool_scatter_kernel(HpfgAct s, const floa
   }
 }
 
-// transpose of the align_corners=True bilinear x2: gather form, one thread per (low-res pixel, channel quad)
-__device__ inline void up_taps(int lo, int L, int* idx, float* wgt, int& cnt) {
-  const int O = 2 * L;
-  const float r = O > 1 ? (float)(L - 1) / (float)(O - 1) : 0.f;
-  cnt = 0;
-  int b = 2 * lo - 2, e = 2 * lo + 4;
-  if (b < 0) b = 0;
-  if (e > O - 1) e = O - 1;
-  for (int o = b; o <= e; ++o) {
-    float f = r * (float)o;
-    int i0 = (int)f;
-    int i1 = i0 + (i0 < L - 1 ? 1 : 0);
-    float w1 = f - (float)i0, w0 = 1.f - w1, w = 0.f;
-    if (i0 == lo) w += w0;
-    if (i1 == lo) w += w1;
-    if ((i0 == lo || i1 == lo) && cnt < 8) {
-      idx[cnt] = o;
-      wgt[cnt] = w;
-      ++cnt;
-    }
-  }
-}
-
+// transpose of the align_corners=True bilinear x2: gather form, one thread per (low-res pixel, channel quad); taps: hpfg_up_taps (common.h)
 // The tap lists depend only on the low-res row / column: every workgroup builds both tables in LDS once (one table entry per
 // thread) instead of every thread re-deriving them for its pixel (that was ~170 VALU instructions per output float4).
 // (A tiled separable variant -- high-res patch staged once in LDS, vertical then horizontal pass -- was measured 1.4-1.8x SLOWER:
 // two 72 KB workgroups per CU keep too few loads in flight; this gather form runs 8 workgroups per CU and its re-reads hit L2.)
 // Optionally the per-channel sums of each workgroup's outputs go to csum[blockIdx][C]: the bias gradient of the 1x1 conv that
 // produced the low-res tensor (model/unet.py:50) is sum_p dU, and the slab reduction adds the rows in a fixed order.
-constexpr int UPB_MAXDIM = 512, UPB_TAPS = 5;      // a x2 align-corners map sends at most 5 (on average 4) outputs per axis to one source
+constexpr int UPB_MAXDIM = 512, UPB_TAPS = HPFG_UPB_TAPS;      // a x2 align-corners map sends at most 5 (on average 4) outputs per axis to one source
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void upsample_bwd_kernel(const float* __restrict__ dUp, int dup_ps, float* __restrict__ dU, int N, int Hl, int Wl,
                                                            int C, float* __restrict__ csum, int xcd_aware) {
   __shared__ short t_idx[UPB_MAXDIM][UPB_TAPS];
@@ -196,8 +174,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
   for (int e = threadIdx.x; e < Hl + Wl; e += 256) {
     int idx[8], cnt;
     float wgt[8];
-    if (e < Hl) up_taps(e, Hl, idx, wgt, cnt);
-    else up_taps(e - Hl, Wl, idx, wgt, cnt);
+    if (e < Hl) hpfg_up_taps(e, Hl, idx, wgt, cnt);
+    else hpfg_up_taps(e - Hl, Wl, idx, wgt, cnt);
     if (cnt > UPB_TAPS) cnt = UPB_TAPS;      // cannot happen for a x2 align-corners map
     for (int k = 0; k < UPB_TAPS; ++k) {
       t_idx[e][k] = (short)(k < cnt ? idx[k] : idx[cnt - 1]);

@@ -197,6 +197,10 @@ class UNetEngine:
         self._pool_done: set = set()
         self.dz_side = True      # (attributes, not environment switches: tests and A/B tools set them on the engine)
         self.act_side = True
+        # the upsample backward of a decoder block is gathered by the 1x1 conv's dgrad while it stages its tiles (HPFG_ACT_UPBWD) instead of
+        # by a launch of its own in front of it
+        self.upb_fuse = os.environ.get("HPFG_UPB_FUSE", "1") == "1"
+        self.upb_max_c1 = int(os.environ.get("HPFG_UPB_MAX_C1", "128"))
         self.dzbuf: Dict[str, torch.Tensor] = {}
         self.actbuf: Dict[str, torch.Tensor] = {}
         self._act_live: set = set()      # layers whose actbuf this forward wrote
@@ -516,7 +520,7 @@ class UNetEngine:
 
     # ---------------------------------------------------------------------------------------------------------
     def _alloc_bwd(self):
-        key = (self.math, self.fused_bwd)      # what the slab layout depends on
+        key = (self.math, self.fused_bwd, self.upb_fuse)      # what the slab layout depends on
         if self._bwd_alloc and self._bwd_alloc_key == key:
             return
         self._bwd_alloc_key = key
@@ -568,7 +572,7 @@ class UNetEngine:
         # bias gradients of the convs without BatchNorm (1x1 convs, out_conv): their per-block channel sums are summed by the same
         # launch, as pseudo layers {taps 1, Cin 1} (one kernel less per bias)
         self.bias_layers = [s for s in self.order if not s.bn]
-        self.csum_rows = {s.name: (self.lib.hpfg_upsample2x_bwd_blocks(N, s.h, s.w, s.cout) if s.taps == 1
+        self.csum_rows = {s.name: ((self._upb_rows(s) if self._upb_on(s) else self.lib.hpfg_upsample2x_bwd_blocks(N, s.h, s.w, s.cout)) if s.taps == 1
                                    else self.lib.hpfg_channel_sum_blocks(N * s.h * s.w, s.cout)) for s in self.bias_layers}
         self.csum_part = {s.name: torch.empty(self.csum_rows[s.name] * s.cout, **f32) for s in self.bias_layers}
         descs = (L.SlabDesc * (len(self.order) + len(self.bias_layers)))()
@@ -660,6 +664,18 @@ class UNetEngine:
                 self._wgrad(s, g)
                 self._dgrad(s, g, dgrad_out, stats_for, out2, pool_of=pool_of)
 
+    def _upb_on(self, su: ConvSpec) -> bool:
+        """Does the dgrad of this decoder 1x1 conv gather the upsample backward itself?  (bf16x3 kernels, channel groups of 8)"""
+        # (not the 14-pixel level, C1 = 256: the gather is repeated in each of its four output-channel slices, in a launch of few workgroups --
+        # up1 12.0 -> 23.3 us at 8 images; up4 31.7 -> 27.0, up3 19.9 -> 19.3 us; up2, two slices: +4.8 us at 8 images, -3.5 at 16.
+        # Same-box A/B of the threshold: profiles/r05_upb_fuse.txt)
+        return bool(self.upb_fuse and self.math == L.MATH_BF16X3 and su.taps == 1 and su.cout % 8 == 0 and su.cin <= self.upb_max_c1)
+
+    def _upb_rows(self, su: ConvSpec) -> int:
+        """Workgroups of that dgrad launch = rows of the bias-gradient sums it leaves (16 x 16-pixel tiles at the aligned sizes, 8 x 8 otherwise)."""
+        t = 16 if (su.h % 16 == 0 and su.w % 16 == 0) else 8
+        return self.N * ((su.h + t - 1) // t) * ((su.w + t - 1) // t)
+
     @staticmethod
     def _side_layer(s: ConvSpec) -> bool:
         """3x3 layers below the 16-pixel-aligned resolutions: separate dgrad + wgrad on the persistent conv kernel (the aligned ones run the
@@ -710,7 +726,7 @@ class UNetEngine:
         self._run("wgrad:" + s.name, lambda: L.check(self.lib.hpfg_wgrad(C.byref(wa), stream), f"wgrad[{s.name}]"), stream)
 
     def _dgrad(self, s: ConvSpec, g: L.Act, out: torch.Tensor, stats_for: Optional[str] = None, out2: Optional[torch.Tensor] = None,
-               stage_out: Optional[torch.Tensor] = None, pool_of: Optional[str] = None):
+               stage_out: Optional[torch.Tensor] = None, pool_of: Optional[str] = None, side_sums: Optional[torch.Tensor] = None):
         """out [N,h,w,cin] = conv-transpose of dZ with this layer's weights.
         stats_for: name of the BatchNorm layer whose activated output `out` is the COMPLETE gradient of (this conv is its only
         consumer): the bf16x3 kernel's epilogue then also leaves that layer's backward sums in self.partials, and the following
@@ -726,6 +742,11 @@ class UNetEngine:
         ca.N, ca.H, ca.W, ca.taps = self.N, s.h, s.w, s.taps
         if stage_out is not None:
             ca.stage_out = L.ptr(stage_out)
+        if side_sums is not None:
+            ca.side_sums = L.ptr(side_sums)
+            rows = self.lib.hpfg_conv_stat_rows(C.byref(ca))
+            if rows != self.csum_rows[s.name]:
+                raise RuntimeError(f"dgrad[{s.name}]: {rows} workgroups, {self.csum_rows[s.name]} rows of bias-gradient sums allocated")
         # (not for the 32-channel slices of 16x16-pixel tiles: that instantiation is out of registers and the extra epilogue spills)
         spills = s.taps == 9 and s.cin_pad % 32 == 0 and s.h % 16 == 0 and s.w % 16 == 0
         if stats_for is not None and self.math == L.MATH_BF16X3 and self.fuse_bwd_stats and s.cin == s.cin_pad and (not spills or self.fuse_bwd_stats == 2):
@@ -842,13 +863,25 @@ class UNetEngine:
             else:
                 self._wgrad_dgrad(s1, g1, self.dcat[k])            # [dSkip | dUp]
                 dup, dup_ps = self.dcat[k].view(-1)[c2:], 2 * c2   # channel offset c2, pixel stride 2*c2
-            self._run("upbwd:" + su.name, lambda: L.check(self.lib.hpfg_upsample2x_bwd_sums(
-                L.ptr(dup), dup_ps, L.ptr(self.dU[k]), N, su.h, su.w, c2, L.ptr(self.csum_part[su.name]), st),
-                "upsample2x_bwd"))                               # + per-workgroup channel sums of dU: the 1x1 conv's bias gradient
-            gu = self._act_plain(self.dU[k], c2, su.h, su.w)
             prev = enc_prefix(4) + ".4" if k == 1 else f"decoder.up{k - 1}.conv.conv_conv.4"
             # the 1x1 conv is the only consumer of the block output below (the bottleneck also feeds the dense head of UNet_Plus)
-            self._wgrad_dgrad(su, gu, self.dA[prev], prev if (k > 1 or dfeat4 is None) else None)
+            stats_prev = prev if (k > 1 or dfeat4 is None) else None
+            gu = self._act_plain(self.dU[k], c2, su.h, su.w)
+            if self._upb_on(su):
+                # the dgrad gathers the upsample backward while it stages (and leaves dU + the bias-gradient rows for the weight gradient / the
+                # slab reduction): one launch of the chain instead of two, dU written once and read once less
+                gsrc = L.Act()
+                gsrc.z, gsrc.mode, gsrc.C, gsrc.Hs, gsrc.Ws, gsrc.pstride = L.ptr(dup), L.ACT_UPBWD, c2, su.h, su.w, dup_ps
+                self._dgrad(su, gsrc, self.dA[prev], stats_prev, stage_out=self.dU[k], side_sums=self.csum_part[su.name])
+                if self._deferred is not None:
+                    self._deferred.append((su, gu))
+                else:
+                    self._wgrad(su, gu)
+            else:
+                self._run("upbwd:" + su.name, lambda: L.check(self.lib.hpfg_upsample2x_bwd_sums(
+                    L.ptr(dup), dup_ps, L.ptr(self.dU[k]), N, su.h, su.w, c2, L.ptr(self.csum_part[su.name]), st),
+                    "upsample2x_bwd"))                               # + per-workgroup channel sums of dU: the 1x1 conv's bias gradient
+                self._wgrad_dgrad(su, gu, self.dA[prev], stats_prev)
         if dfeat4 is not None:
             self.dA[enc_prefix(4) + ".4"].add_(dfeat4)
         defer = self._deferred is not None

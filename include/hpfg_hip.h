@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HPFG_VERSION 131
+#define HPFG_VERSION 132
 enum { HPFG_MATH_F32 = 0, HPFG_MATH_BF16X3 = 1 };
 
 /* rows of a per-layer BatchNorm table `bn` ([HPFG_BN_ROWS][C] floats) */
@@ -38,10 +38,14 @@ enum {
   HPFG_ACT_BNACT_POOL = 4, /* v = max 2x2 of lrelu(z*scale+shift)  unet.py:37 (MaxPool2d(2)) fused on load   */
   HPFG_ACT_UP2X = 5,       /* v = bilinear x2, align_corners=True  unet.py:51,56 fused on load               */
   HPFG_ACT_DZ = 6,         /* v = k1*g + k2*z + k3, g = aux*dropmask*lrelu'(z*scale+shift): BN/LeakyReLU/Dropout backward */
-  HPFG_ACT_SPLIT16 = 7     /* a side tensor stored by HpfgConvArgs.stage_out (round 5): the value ALREADY split for the bf16x3 matrix-core
+  HPFG_ACT_SPLIT16 = 7,    /* a side tensor stored by HpfgConvArgs.stage_out (round 5): the value ALREADY split for the bf16x3 matrix-core
                               products, v = hi + lo with hi = bf16(v), lo = bf16(v - hi): z = bf16 [N][Hs][Ws][pstride / 8][hi 8 | lo 8]
                               (pstride = channels per pixel, C % 8 == 0: 32 contiguous bytes per 8 channels, the size of the fp32 tensor).
                               Read by hpfg_wgrad only: its loader becomes a copy into LDS. */
+  HPFG_ACT_UPBWD = 8       /* (round 5, 1x1 dgrad only) the gradient w.r.t. a tensor BEFORE nn.Upsample(x2, bilinear, align_corners=True) (unet.py:51),
+                              gathered on load from the gradient w.r.t. the upsampled tensor: z = that gradient [N][2*Hs][2*Ws] with pstride
+                              floats per pixel, C channels; the value at (n, y, x) is the transposed interpolation -- what
+                              hpfg_upsample2x_bwd writes into a tensor of its own */
 };
 
 typedef struct HpfgAct {
@@ -117,7 +121,11 @@ typedef struct HpfgConvArgs {
                            bf16 [N][H][W][(a0.C + a1.C) / 8][hi 8 | lo 8], the same 4 bytes per element an fp32 tensor takes.  The layer's weight
                            gradient reads them as HPFG_ACT_SPLIT16 sources (its input from the forward conv, its dZ from the dgrad): no
                            BatchNorm / LeakyReLU / Dropout chain, no fp32 -> bf16 split, in any of its (input-channel slice x output-channel
-                           slice) workgroups -- its loader is a copy (autograd's saved tensors of nn.Conv2d, model/unet.py:18,22) */
+                           slice) workgroups -- its loader is a copy (autograd's saved tensors of nn.Conv2d, model/unet.py:18,22).
+                           With an HPFG_ACT_UPBWD source (1x1 dgrad): fp32 [N][H][W][a0.C], the gathered gradient itself -- the dZ of the 1x1
+                           conv's weight gradient -- stored by the workgroups of output-channel slice 0 */
+  float* side_sums;     /* optional, HPFG_ACT_UPBWD source only: [hpfg_conv_stat_rows()][a0.C] per-workgroup channel sums of the gathered
+                           gradient (slice 0), the rows of the 1x1 conv's bias gradient (summed in a fixed order by hpfg_slab_reduce_multi) */
 } HpfgConvArgs;
 #define HPFG_ACC_MAX_SHARDS 8
 #define HPFG_ACC_WORDS(C, shards) ((shards) * 2 * 2 * (C))   /* long long words of one layer accumulator */

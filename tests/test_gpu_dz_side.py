@@ -117,3 +117,33 @@ def test_max_pool_backward_in_the_dgrad_epilogue(n, hw):
     for k in g0:
         d = float((g1[k] - g0[k]).abs().max())
         assert d <= 5e-5 * max(1e-3, float(g0[k].abs().max())), (k, d, float(g0[k].abs().max()))
+
+
+@pytest.mark.parametrize("n,hw", [(2, 48), (2, 112), (3, 80)])
+def test_upsample_backward_gathered_by_the_1x1_dgrad(n, hw):
+    """HPFG_ACT_UPBWD: the dgrad of a decoder block's 1x1 conv evaluates the transposed bilinear interpolation while it stages its tiles (the
+    taps and the order of additions of hpfg_upsample2x_bwd), stores the gathered gradient for the 1x1 conv's weight gradient and leaves the
+    bias-gradient rows -- instead of the separate launch in front of it.  Every parameter gradient must agree with the two-launch path."""
+    def run(fuse):
+        reset_dropout_streams()
+        torch.manual_seed(31)
+        m = UNet(1, 4).to(DEV)
+        m.train()
+        x, lab = synth_batch(7, n, hw, hw, 1, 4, cell=8)
+        with torch.no_grad():
+            m(x.to(DEV))
+        eng = next(iter(m._engines.values()))[0]
+        eng.upb_fuse = fuse
+        out = m(x.to(DEV))
+        Med_Sup_Loss(4)(out, lab.to(DEV)).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}, {k: v.detach().cpu().clone() for k, v in eng.dU.items()}
+
+    g1, u1 = run(True)
+    g0, u0 = run(False)
+    for k in u0:          # the gathered gradient itself: the same taps in the same order (the two kernels contract their FMAs independently)
+        d = float((u1[k] - u0[k]).abs().max())
+        assert d <= 1e-6 * max(1e-6, float(u0[k].abs().max())), (k, d, float(u0[k].abs().max()))
+    for k in g0:
+        d = float((g1[k] - g0[k]).abs().max())
+        assert d <= 5e-6 * max(1e-4, float(g0[k].abs().max())), (k, d, float(g0[k].abs().max()))
